@@ -1,0 +1,248 @@
+"""Weight inventory, synthetic weights and checkpoint reading.
+
+The checkpoint contract is the reference's: a Lightning checkpoint read with
+`torch.load(path)['state_dict']`, keys filtered by prefix `G.` / `plm.` / `adm.`
+and loaded strictly (reference `models/megatts2.py:107-117,184-198,278-292`).
+The inventories below reproduce the reference modules' `state_dict()` key set
+and shapes from the hyper-parameters alone (checked against the live reference
+modules in tests/test_inventory_vs_reference.py when /root/reference exists),
+so that the GPU box - which has no reference tree - can build identical models.
+
+No checkpoints ship with the reference, so parity and benchmarks run on
+*synthetic* weights: every tensor is drawn from a generator seeded by the
+tensor's name (`synth_state_dict`), which makes the same weights available to
+the reference modules (golden generation), the CPU oracle and the HIP model.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .config import ADMConfig, GConfig, HifiGanConfig, PLMConfig
+
+Inventory = "OrderedDict[str, Tuple[int, ...]]"
+
+
+def _conv_block(inv, prefix, c, k):
+    inv[f"{prefix}.conv.weight"] = (c, c, k)
+    inv[f"{prefix}.conv.bias"] = (c,)
+    inv[f"{prefix}.norm.weight"] = (c,)
+    inv[f"{prefix}.norm.bias"] = (c,)
+
+
+def _residual_stack(inv, prefix, c, k, n_stacks, n_blocks):
+    # reference modules/convnet.py:52-72 (ResidualBlockStack -> ConvStack -> ConvBlock)
+    for s in range(n_stacks):
+        for b in range(n_blocks):
+            _conv_block(inv, f"{prefix}.conv_stacks.{s}.blocks.{b}", c, k)
+
+
+def _encoder_layers(inv, prefix, n_layers, d, ff, conv_ff):
+    # reference modules/transformer.py:59-86
+    for l in range(n_layers):
+        p = f"{prefix}.{l}"
+        inv[f"{p}.norm1.weight"] = (d,)
+        inv[f"{p}.norm1.bias"] = (d,)
+        inv[f"{p}.norm2.weight"] = (d,)
+        inv[f"{p}.norm2.bias"] = (d,)
+        for w in ("w_q", "w_k", "w_v"):
+            inv[f"{p}.attn.{w}.weight"] = (d, d)
+            inv[f"{p}.attn.{w}.bias"] = (d,)
+        inv[f"{p}.attn.out_proj.0.weight"] = (d, d)
+        inv[f"{p}.attn.out_proj.0.bias"] = (d,)
+        if conv_ff:
+            inv[f"{p}.ff.0.weight"] = (ff, d, 5)
+            inv[f"{p}.ff.0.bias"] = (ff,)
+            inv[f"{p}.ff.2.weight"] = (d, ff, 5)
+            inv[f"{p}.ff.2.bias"] = (d,)
+        else:
+            inv[f"{p}.ff.0.weight"] = (ff, d)
+            inv[f"{p}.ff.0.bias"] = (ff,)
+            inv[f"{p}.ff.3.weight"] = (d, ff)
+            inv[f"{p}.ff.3.bias"] = (d,)
+
+
+def inventory_g(cfg: GConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Key set of reference `MegaG.state_dict()` (models/megatts2.py:30-54)."""
+    inv: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    m, v = cfg.mrte, cfg.vqpe
+    h = m.hidden_size
+    # --- MRTE (modules/mrte.py:85-139)
+    inv["mrte.phone_embedding.word_embeddings.weight"] = (m.phone_vocab_size, h)
+    inv["mrte.phone_pos_embedding.alpha"] = (1,)
+    inv["mrte.mel_encoder_middle_layer.weight"] = (h, h, m.mel_stride + 1)
+    inv["mrte.mel_encoder_middle_layer.bias"] = (h,)
+    inv["mrte.mel_encoder.first_layer.weight"] = (h, m.mel_bins, m.mel_kernel_size)
+    inv["mrte.mel_encoder.first_layer.bias"] = (h,)
+    for l in range(m.mel_n_layer):
+        p = f"mrte.mel_encoder.layers.{l}"
+        _residual_stack(inv, f"{p}.conv_stack1", h, m.mel_kernel_size, m.mel_n_stack, m.mel_n_block)
+        # the ONE shared Conv1d registered again under every branch (mrte.py:101-115)
+        inv[f"{p}.middle_layer.weight"] = (h, h, m.mel_stride + 1)
+        inv[f"{p}.middle_layer.bias"] = (h,)
+        _residual_stack(inv, f"{p}.conv_stack2", h, m.mel_kernel_size, m.mel_n_stack, m.mel_n_block)
+    inv["mrte.mel_encoder.last_layer.weight"] = (h, h, m.mel_kernel_size)
+    inv["mrte.mel_encoder.last_layer.bias"] = (h,)
+    _encoder_layers(inv, "mrte.phone_encoder.layers", m.content_n_layers, h, m.content_ff_dim, True)
+    for w in ("w_q", "w_k", "w_v"):
+        inv[f"mrte.mha.{w}.weight"] = (h, h)
+        inv[f"mrte.mha.{w}.bias"] = (h,)
+    inv["mrte.mha.out_proj.0.weight"] = (h, h)
+    inv["mrte.mha.out_proj.0.bias"] = (h,)
+    inv["mrte.norm.weight"] = (h,)
+    inv["mrte.norm.bias"] = (h,)
+    # --- VQ prosody encoder (modules/vqpe.py:28-48)
+    c = v.hidden_size
+    inv["vqpe.convnet.first_layer.weight"] = (c, v.mel_bins, v.kernel_size)
+    inv["vqpe.convnet.first_layer.bias"] = (c,)
+    for l in range(v.n_layers):
+        p = f"vqpe.convnet.layers.{l}"
+        _residual_stack(inv, f"{p}.conv_stack1", c, v.kernel_size, v.n_stacks, v.n_blocks)
+        _residual_stack(inv, f"{p}.conv_stack2", c, v.kernel_size, v.n_stacks, v.n_blocks)
+    inv["vqpe.convnet.last_layer.weight"] = (v.vq_dim, c, v.kernel_size)
+    inv["vqpe.convnet.last_layer.bias"] = (v.vq_dim,)
+    q = "vqpe.vq.vq.layers.0._codebook"   # core_vq.py:135-138 (buffers), n_q = 1 (vqpe.py:45)
+    inv[f"{q}.inited"] = (1,)
+    inv[f"{q}.cluster_size"] = (v.vq_bins,)
+    inv[f"{q}.embed"] = (v.vq_bins, v.vq_dim)
+    inv[f"{q}.embed_avg"] = (v.vq_bins, v.vq_dim)
+    # --- mel decoder (models/megatts2.py:46-54, modules/convnet.py:74-119)
+    d = cfg.hidden_size
+    inv["decoder.first_layer.weight"] = (d, cfg.decoder_in, cfg.kernel_size)
+    inv["decoder.first_layer.bias"] = (d,)
+    _residual_stack(inv, "decoder.conv_stack", d, cfg.kernel_size, cfg.decoder_n_stack, cfg.decoder_n_block)
+    inv["decoder.last_layer.weight"] = (m.mel_bins, d, cfg.kernel_size)
+    inv["decoder.last_layer.bias"] = (m.mel_bins,)
+    return inv
+
+
+def inventory_plm(cfg: PLMConfig):
+    """Key set of reference `MegaPLM.state_dict()` (models/megatts2.py:120-146)."""
+    inv = OrderedDict()
+    _encoder_layers(inv, "plm.layers", cfg.n_layers, cfg.d_model, cfg.ff_dim, False)
+    inv["predict_layer.weight"] = (cfg.vq_bins, cfg.d_model)
+    inv["pos.alpha"] = (1,)
+    inv["pc_embedding.weight"] = (cfg.vq_bins + 2, cfg.vq_dim)
+    return inv
+
+
+def inventory_adm(cfg: ADMConfig):
+    """Key set of reference `MegaADM.state_dict()` (models/megatts2.py:201-231)."""
+    inv = OrderedDict()
+    _encoder_layers(inv, "adm.layers", cfg.n_layers, cfg.d_model, cfg.ff_dim, False)
+    inv["dt_linear_emb.weight"] = (cfg.emb_dim, 1)
+    inv["tc_linear_emb.weight"] = (cfg.tc_emb_dim, cfg.tc_latent_dim)
+    inv["pos_emb.alpha"] = (1,)
+    inv["predict_layer.weight"] = (1, cfg.d_model)
+    return inv
+
+
+def inventory_hifigan(cfg: HifiGanConfig):
+    """HiFi-GAN V1 generator tensors, named as `transformers.SpeechT5HifiGan`
+    (the in-container stand-in oracle for the un-vendored speechbrain vocoder,
+    SURVEY 8c); weight-norm already folded, ConvTranspose1d weights [Cin, Cout, k]."""
+    inv = OrderedDict()
+    c0 = cfg.upsample_initial_channel
+    inv["conv_pre.weight"] = (c0, cfg.in_dim, 7)
+    inv["conv_pre.bias"] = (c0,)
+    ch = c0
+    for i, (r, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+        inv[f"upsampler.{i}.weight"] = (ch, ch // 2, k)
+        inv[f"upsampler.{i}.bias"] = (ch // 2,)
+        ch //= 2
+    nk = len(cfg.resblock_kernel_sizes)
+    ch = c0
+    for i in range(len(cfg.upsample_rates)):
+        ch //= 2
+        for j, (k, dils) in enumerate(zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes)):
+            for n in range(len(dils)):
+                for which in ("convs1", "convs2"):
+                    inv[f"resblocks.{i * nk + j}.{which}.{n}.weight"] = (ch, ch, k)
+                    inv[f"resblocks.{i * nk + j}.{which}.{n}.bias"] = (ch,)
+    inv["conv_post.weight"] = (1, ch, 7)
+    inv["conv_post.bias"] = (1,)
+    return inv
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic weights
+
+
+def _rng(name: str, seed: int) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64([zlib.crc32(name.encode()), seed]))
+
+
+def synth_tensor(name: str, shape, seed: int = 0) -> np.ndarray:
+    """Deterministic f32 tensor for a state-dict entry, chosen so that every term
+    of the computation is exercised (non-trivial LayerNorm affine, non-zero biases)
+    while activations keep O(1) scale through 20+ layers."""
+    r = _rng(name, seed)
+    shape = tuple(shape)
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "alpha":                              # embedding.py:62 (frozen, =1)
+        return np.ones(shape, np.float32)
+    if leaf == "inited":                             # core_vq.py:135; must be 1
+        return np.ones(shape, np.float32)
+    if leaf == "cluster_size":
+        return np.ones(shape, np.float32)
+    if leaf in ("embed", "embed_avg"):               # codebook; tests overwrite with a ze-matched one
+        return _rng(name.replace("embed_avg", "embed"), seed).standard_normal(shape).astype(np.float32)
+    if ".norm" in name and leaf == "weight":         # LayerNorm gamma
+        return (1.0 + 0.2 * r.uniform(-1, 1, shape)).astype(np.float32)
+    if ".norm" in name and leaf == "bias":
+        return (0.2 * r.uniform(-1, 1, shape)).astype(np.float32)
+    if "embedding" in name and leaf == "weight":     # nn.Embedding default N(0,1)
+        return r.standard_normal(shape).astype(np.float32)
+    if leaf == "weight":
+        if name.startswith("upsampler."):            # ConvTranspose1d [Cin, Cout, k]
+            fan_in = shape[0] * shape[2] / 1.0
+        else:
+            fan_in = int(np.prod(shape[1:]))
+        a = (3.0 / fan_in) ** 0.5                    # unit-gain uniform
+        if name.endswith("adm.dt_linear_emb.weight"):
+            a *= 0.1                                 # keep the ADM's float feedback loop contractive
+        return r.uniform(-a, a, shape).astype(np.float32)
+    if leaf == "bias":
+        return (0.1 * r.uniform(-1, 1, shape)).astype(np.float32)
+    raise KeyError(name)
+
+
+def synth_state_dict(inv, seed: int = 0, prefix: str = "") -> Dict[str, np.ndarray]:
+    """name -> f32 ndarray for every inventory entry.  `prefix` salts the generator so
+    that equally-named tensors of different models (`predict_layer.weight`) differ."""
+    sd = OrderedDict()
+    for name, shape in inv.items():
+        if name.endswith(".middle_layer.weight") or name.endswith(".middle_layer.bias"):
+            # shared storage in the reference (mrte.py:101-115): same values under every alias
+            alias = "mrte.mel_encoder_middle_layer." + name.rsplit(".", 1)[-1]
+            sd[name] = synth_tensor(prefix + alias, shape, seed)
+        else:
+            sd[name] = synth_tensor(prefix + name, shape, seed)
+    return sd
+
+
+def load_lightning_state_dict(ckpt_path: str, prefix: str) -> Dict[str, np.ndarray]:
+    """`torch.load(ckpt)['state_dict']`, keep keys under `prefix`, strip it
+    (reference models/megatts2.py:111-116,192-197,287-291)."""
+    import torch
+
+    raw = torch.load(ckpt_path, map_location="cpu", weights_only=False)["state_dict"]
+    out = OrderedDict()
+    for k, v in raw.items():
+        if k.startswith(prefix):
+            out[k[len(prefix):]] = v.detach().to(torch.float32).cpu().numpy()
+    return out
+
+
+def check_strict(sd: Dict[str, np.ndarray], inv) -> None:
+    """`load_state_dict(strict=True)` semantics: same key set, same shapes."""
+    missing = [k for k in inv if k not in sd]
+    unexpected = [k for k in sd if k not in inv]
+    if missing or unexpected:
+        raise KeyError(f"state_dict mismatch: missing={missing[:5]} unexpected={unexpected[:5]}")
+    for k, shape in inv.items():
+        if tuple(sd[k].shape) != tuple(shape):
+            raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != expected {tuple(shape)}")

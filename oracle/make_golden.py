@@ -1,0 +1,211 @@
+"""Generate the committed golden fixtures in tests/golden/ from the LIVE reference modules.
+
+TEST INFRASTRUCTURE.  Run in the build container only (needs /root/reference):
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz, *.npy
+
+The reference (LSimon95/megatts2) ships no checkpoints, no tests and no golden vectors
+(SURVEY.md section 4), so the fixtures are produced by instantiating the reference's own
+`MegaG` / `MegaPLM` / `MegaADM` (through oracle/ref_shim.py), loading the name-seeded synthetic
+weights of megatts2_amd/weights.py into them with `load_state_dict(strict=True)`, and running
+the stages of `Megatts.forward` (models/megatts2.py:353-368) one by one on seeded synthetic
+inputs.  The vocoder leg uses `transformers.SpeechT5HifiGan` (stand-in; parity unpinned).
+
+Each .npz holds the inputs AND every intermediate so that the oracle and the HIP path can be
+checked stage-wise with teacher forcing.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_shim  # noqa: E402
+from megatts2_amd import config as C  # noqa: E402
+from megatts2_amd import synth, weights  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+WEIGHT_SEED = 0
+
+
+def cfgs(kind: str):
+    if kind == "prod":
+        return C.production_g(), C.production_plm(), C.production_adm(), C.production_hifigan()
+    return C.tiny_g(), C.tiny_plm(), C.tiny_adm(), C.tiny_hifigan()
+
+
+def build_reference(kind: str):
+    """Reference modules (eval) carrying the synthetic weights; returns (G, plm, adm, state dicts)."""
+    ref = ref_shim.load()
+    from modules.mrte import MRTE
+    from modules.vqpe import VQProsodyEncoder
+
+    g, p, a, _ = cfgs(kind)
+    m, v = g.mrte, g.vqpe
+    mrte = MRTE(mel_bins=m.mel_bins, mel_kernel_size=m.mel_kernel_size, mel_stride=m.mel_stride,
+                mel_n_layer=m.mel_n_layer, mel_n_stack=m.mel_n_stack, mel_n_block=m.mel_n_block,
+                content_ff_dim=m.content_ff_dim, content_n_heads=m.content_n_heads,
+                content_n_layers=m.content_n_layers, hidden_size=m.hidden_size,
+                duration_token_ms=16.0, phone_vocab_size=m.phone_vocab_size)
+    vqpe = VQProsodyEncoder(mel_bins=v.mel_bins, stride=v.stride, hidden_size=v.hidden_size,
+                            kernel_size=v.kernel_size, n_layers=v.n_layers, n_stacks=v.n_stacks,
+                            n_blocks=v.n_blocks, vq_bins=v.vq_bins, vq_dim=v.vq_dim)
+    G = ref.MegaG(mrte, vqpe, kernel_size=g.kernel_size, hidden_size=g.hidden_size,
+                  decoder_n_stack=g.decoder_n_stack, decoder_n_block=g.decoder_n_block)
+    plm = ref.MegaPLM(n_layers=p.n_layers, n_heads=p.n_heads, vq_dim=p.vq_dim,
+                      tc_latent_dim=p.tc_latent_dim, vq_bins=p.vq_bins)
+    adm = ref.MegaADM(n_layers=a.n_layers, n_heads=a.n_heads, emb_dim=a.emb_dim,
+                      tc_latent_dim=a.tc_latent_dim, tc_emb_dim=a.tc_emb_dim)
+    sd_g = weights.synth_state_dict(weights.inventory_g(g), WEIGHT_SEED, "G.")
+    sd_p = weights.synth_state_dict(weights.inventory_plm(p), WEIGHT_SEED, "plm.")
+    sd_a = weights.synth_state_dict(weights.inventory_adm(a), WEIGHT_SEED, "adm.")
+    for mod, sd in ((G, sd_g), (plm, sd_p), (adm, sd_a)):
+        mod.load_state_dict({k: torch.from_numpy(x) for k, x in sd.items()}, strict=True)
+        mod.eval()
+    return G, plm, adm, sd_g, sd_p, sd_a
+
+
+def make_codebook(kind: str, G, sd_g) -> np.ndarray:
+    """Codebook matched to the encoder output (what k-means init does, core_vq.py:74-96,141-149):
+    sampled `ze` rows + small noise, so that indices are diverse and near-ties occur."""
+    g = cfgs(kind)[0]
+    bins, dim = g.vqpe.vq_bins, g.vqpe.vq_dim
+    rng = np.random.Generator(np.random.PCG64(4242))
+    rows = []
+    need = bins
+    with torch.no_grad():
+        while sum(r.shape[0] for r in rows) < need:
+            mel = synth.make_utterance(rng, 4, 400, 400).prompt_mel
+            x = torch.from_numpy(mel[None, :, :g.vqpe.mel_bins]).transpose(1, 2)
+            ze = G.vqpe.convnet(x)[0].transpose(0, 1).numpy()
+            rows.append(ze)
+    ze = np.concatenate(rows)[rng.permutation(sum(r.shape[0] for r in rows))[:bins]]
+    emb = (ze + 0.02 * ze.std() * rng.standard_normal(ze.shape)).astype(np.float32)
+    assert emb.shape == (bins, dim)
+    return emb
+
+
+def install_codebook(G, sd_g, emb: np.ndarray) -> None:
+    cb = G.vqpe.vq.vq.layers[0]._codebook
+    cb.embed.copy_(torch.from_numpy(emb))
+    cb.embed_avg.copy_(torch.from_numpy(emb))
+    cb.inited.fill_(1)
+    sd_g["vqpe.vq.vq.layers.0._codebook.embed"] = emb
+    sd_g["vqpe.vq.vq.layers.0._codebook.embed_avg"] = emb.copy()
+
+
+def run_utterance(ref, G, plm, adm, utt: synth.Utterance, target_mel: np.ndarray) -> dict:
+    """Stages of Megatts.forward (models/megatts2.py:353-368) on one utterance, everything kept."""
+    from modules.mrte import LengthRegulator
+
+    out = {"phone": utt.phone, "prompt_mel": utt.prompt_mel, "forced_dur": utt.durations,
+           "target_mel": target_mel}
+    adm_float, plm_logits = [], []
+    h1 = adm.predict_layer.register_forward_hook(lambda m, i, o: adm_float.append(o[0, -1, 0].item()))
+    h2 = plm.predict_layer.register_forward_hook(lambda m, i, o: plm_logits.append(o[0, -1].numpy().copy()))
+    with torch.no_grad():
+        phone = torch.from_numpy(utt.phone)[None]
+        mel = torch.from_numpy(utt.prompt_mel)[None]
+        out["mel_context"] = G.mrte.mel_encoder(mel.transpose(1, 2))[0].transpose(0, 1).numpy()
+        tc = G.mrte.tc_latent(phone, mel)                                   # :354
+        out["tc_latent"] = tc[0].numpy()
+        dt = adm.infer(tc)[..., 0]                                          # :355
+        out["adm_dur"] = dt[0].numpy().astype(np.int32)
+        out["adm_float"] = np.asarray(adm_float, np.float32)
+        lr = LengthRegulator(256, 16000, 16.0)
+        forced = torch.from_numpy(utt.durations)[None]
+        tc_expand = lr(tc, forced)                                          # :356
+        out["tc_expand_adm_len"] = np.asarray(int(dt.sum()), np.int64)
+        cond = F.max_pool1d(tc_expand.transpose(1, 2), 8, ceil_mode=True).transpose(1, 2)   # :357-358
+        out["plm_cond"] = cond[0].numpy()
+        codes = plm.infer(cond)                                             # :359
+        out["p_codes"] = codes[0].numpy()
+        out["plm_logits"] = np.stack(plm_logits).astype(np.float32)
+        zq = G.vqpe.vq.decode(codes.unsqueeze(0))                           # :361
+        zq = zq.transpose(1, 2).unsqueeze(2).contiguous().expand(-1, -1, 8, -1)
+        zq = zq.reshape(zq.shape[0], -1, zq.shape[-1])
+        x = torch.cat([tc_expand, zq[:, :tc_expand.shape[1], :]], dim=-1)   # :365-366
+        out["decoder_in"] = x[0].numpy()
+        out["mel"] = G.decoder(x.transpose(1, 2))[0].transpose(0, 1).numpy()  # :368
+        # VQ prosody encoder on a target mel (modules/vqpe.py:50-62; used by MegaG.forward/s2_latent)
+        tm = torch.from_numpy(target_mel)[None]
+        ze = G.vqpe.convnet(tm[..., :G.vqpe.mel_bins].transpose(1, 2))
+        out["vqpe_ze"] = ze[0].transpose(0, 1).numpy()
+        zq2, _, _, codes2 = G.vqpe(tm)
+        out["vqpe_zq"] = zq2[0].numpy()
+        out["vqpe_codes"] = codes2[0, 0].numpy()
+    h1.remove()
+    h2.remove()
+    return out
+
+
+def make_hifigan(kind: str) -> dict:
+    from transformers import SpeechT5HifiGan, SpeechT5HifiGanConfig
+
+    hc = cfgs(kind)[3]
+    tcfg = SpeechT5HifiGanConfig(model_in_dim=hc.in_dim, upsample_initial_channel=hc.upsample_initial_channel,
+                                 upsample_rates=hc.upsample_rates, upsample_kernel_sizes=hc.upsample_kernel_sizes,
+                                 resblock_kernel_sizes=hc.resblock_kernel_sizes,
+                                 resblock_dilation_sizes=hc.resblock_dilation_sizes,
+                                 leaky_relu_slope=hc.leaky_relu_slope, normalize_before=False)
+    model = SpeechT5HifiGan(tcfg).eval()
+    sd = weights.synth_state_dict(weights.inventory_hifigan(hc), WEIGHT_SEED, "hifigan.")
+    full = {k: torch.from_numpy(v) for k, v in sd.items()}
+    full["mean"] = torch.zeros(hc.in_dim)
+    full["scale"] = torch.ones(hc.in_dim)
+    model.load_state_dict(full, strict=True)
+    rng = np.random.Generator(np.random.PCG64(77))
+    out = {}
+    for i, T in enumerate((37, 12) if kind == "tiny" else (24,)):
+        mel = synth.make_utterance(rng, 2, T, T).prompt_mel
+        with torch.no_grad():
+            wav = model(torch.from_numpy(mel)).numpy()
+        out[f"mel{i}"] = mel
+        out[f"wav{i}"] = wav.astype(np.float32)
+    return out
+
+
+def main() -> None:
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.manual_seed(0)
+    # vocoder fixtures FIRST: transformers must be imported before ref_shim puts its torchaudio /
+    # librosa stand-ins into sys.modules (its availability probes trip over them otherwise)
+    for kind in ("tiny", "prod"):
+        hg = make_hifigan(kind)
+        np.savez_compressed(os.path.join(GOLDEN, f"{kind}_hifigan.npz"), **hg)
+        print(kind, "hifigan", {k: v.shape for k, v in hg.items()})
+    ref = ref_shim.load()
+    for kind in ("tiny", "prod"):
+        G, plm, adm, sd_g, sd_p, sd_a = build_reference(kind)
+        g = cfgs(kind)[0]
+        emb = make_codebook(kind, G, sd_g)
+        install_codebook(G, sd_g, emb)
+        np.save(os.path.join(GOLDEN, f"codebook_{kind}.npy"), emb)
+        rng = np.random.Generator(np.random.PCG64(1001 if kind == "prod" else 2002))
+        if kind == "prod":
+            shapes = [(42, 260, 260)]                      # config C1
+        else:
+            shapes = [(9, 50, 61), (5, 33, 17), (1, 16, 8), (12, 97, 40)]   # ragged, incl. Np=1
+        for i, (n_ph, n_pr, n_fr) in enumerate(shapes):
+            utt = synth.make_utterance(rng, n_ph, n_pr, n_fr, g.mrte.phone_vocab_size, g.mrte.mel_bins,
+                                       g.vqpe.vq_bins)
+            target = synth.make_utterance(rng, 1, n_fr, n_fr).prompt_mel
+            res = run_utterance(ref, G, plm, adm, utt, target)
+            path = os.path.join(GOLDEN, f"{kind}_utt{i}.npz")
+            np.savez_compressed(path, **res)
+            print(kind, i, {k: (v.shape, str(v.dtype)) for k, v in res.items()})
+            print("   adm_float", res["adm_float"][:8], "dur", res["adm_dur"][:12],
+                  "codes", res["p_codes"][:12], "vq", res["vqpe_codes"][:12],
+                  "n_distinct_vq", len(set(res["vqpe_codes"].tolist())))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,459 @@
+"""CPU oracle for the Mega-TTS 2 synthesis hot path (numpy, fp32).
+
+TEST INFRASTRUCTURE ONLY.  Nothing under megatts2_amd/ imports this file; it is
+used by tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg as the
+*checker*, never as the thing measured or shipped.
+
+It restates, function by function, what the reference (LSimon95/megatts2,
+mounted at /root/reference in the build container) computes on the path
+`models/megatts2.py:325-375 Megatts.forward`, with *batch-1 semantics*: every
+function takes ONE utterance (the reference's AR loops hard-code batch 1,
+`models/megatts2.py:170-171,262-263`).  Citations are `file:line` relative to
+the reference root.
+
+Parity is pinned: tests/test_oracle_golden.py checks every function here against
+fixtures in tests/golden/ that were produced by running the reference's own
+modules (oracle/make_golden.py, through oracle/ref_shim.py) on the same
+name-seeded synthetic weights (megatts2_amd/weights.py).  The HiFi-GAN vocoder
+is the exception: the reference takes it from speechbrain's hub model, which is
+neither vendored nor reachable offline -> **parity unpinned** for `hifigan()`;
+it restates the published HiFi-GAN V1 generator and is pinned only against
+`transformers.SpeechT5HifiGan` carrying the same synthetic weights.
+
+Weights are passed as a dict keyed exactly like the reference state_dicts.
+Layout convention inside the oracle: time-major `[T, C]` float32 arrays.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+F32 = np.float32
+SD = Dict[str, np.ndarray]
+
+
+# ------------------------------------------------------------------------------------------------
+# ATen primitives the reference dispatches to, restated on [T, C] arrays
+
+
+def linear(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
+    """F.linear: y = x @ w.T + b, w is [out, in]."""
+    y = x.astype(F32) @ w.T.astype(F32)
+    if b is not None:
+        y = y + b
+    return y.astype(F32)
+
+
+def conv1d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], stride: int = 1,
+           padding: int = 0, dilation: int = 1) -> np.ndarray:
+    """nn.Conv1d (cross-correlation, zero padding) on x[T, Cin]; w[Cout, Cin, k] -> [T_out, Cout]."""
+    T, cin = x.shape
+    cout, cin_w, k = w.shape
+    assert cin == cin_w
+    t_out = (T + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    if t_out <= 0:
+        return np.zeros((0, cout), F32)
+    xp = np.zeros((T + 2 * padding, cin), F32)
+    xp[padding:padding + T] = x
+    y = np.zeros((t_out, cout), F32)
+    for tap in range(k):
+        rows = xp[tap * dilation: tap * dilation + (t_out - 1) * stride + 1: stride]
+        y += rows @ w[:, :, tap].T
+    if b is not None:
+        y += b
+    return y.astype(F32)
+
+
+def conv_transpose1d(x: np.ndarray, w: np.ndarray, b: Optional[np.ndarray], stride: int,
+                     padding: int) -> np.ndarray:
+    """nn.ConvTranspose1d on x[T, Cin]; w[Cin, Cout, k] -> [(T-1)*stride - 2*padding + k, Cout]."""
+    T, cin = x.shape
+    cin_w, cout, k = w.shape
+    assert cin == cin_w
+    full = np.zeros(((T - 1) * stride + k, cout), F32)
+    for tap in range(k):
+        full[tap: tap + (T - 1) * stride + 1: stride] += x @ w[:, :, tap]
+    y = full[padding: full.shape[0] - padding]
+    if b is not None:
+        y = y + b
+    return y.astype(F32)
+
+
+def layer_norm(x: np.ndarray, g: np.ndarray, b: np.ndarray, eps: float = 1e-5) -> np.ndarray:
+    """F.layer_norm over the last dim, biased variance, eps inside the sqrt."""
+    x = x.astype(F32)
+    mu = x.mean(axis=-1, keepdims=True, dtype=F32)
+    xc = x - mu
+    var = (xc * xc).mean(axis=-1, keepdims=True, dtype=F32)
+    return (xc / np.sqrt(var + F32(eps)) * g + b).astype(F32)
+
+
+def relu(x: np.ndarray) -> np.ndarray:
+    return np.maximum(x, F32(0))
+
+
+def leaky_relu(x: np.ndarray, slope: float) -> np.ndarray:
+    return np.where(x >= 0, x, x * F32(slope)).astype(F32)
+
+
+def softmax_rows(s: np.ndarray) -> np.ndarray:
+    m = s.max(axis=-1, keepdims=True)
+    e = np.exp(s - m)
+    return (e / e.sum(axis=-1, keepdims=True)).astype(F32)
+
+
+def max_pool1d_ceil(x: np.ndarray, k: int) -> np.ndarray:
+    """F.max_pool1d(kernel=k, stride=k, ceil_mode=True) along time of x[T, C]
+    (models/megatts2.py:357-358, modules/vqpe.py:38): the last window may be partial."""
+    T, c = x.shape
+    tq = -(-T // k)
+    out = np.empty((tq, c), F32)
+    for q in range(tq):
+        out[q] = x[q * k: min(T, (q + 1) * k)].max(axis=0)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# modules/embedding.py
+
+
+def sine_pe(length: int, dim: int) -> np.ndarray:
+    """SinePositionalEmbedding.extend_pe (modules/embedding.py:68-92): sin on even columns,
+    cos on odd, div_term = exp(2i * -(ln 1e4 / dim)), all in fp32."""
+    pos = np.arange(0, length, dtype=F32)[:, None]
+    div = np.exp(np.arange(0, dim, 2, dtype=F32) * F32(-(math.log(10000.0) / dim))).astype(F32)
+    pe = np.zeros((length, dim), F32)
+    ang = (pos * div).astype(F32)
+    pe[:, 0::2] = np.sin(ang)
+    pe[:, 1::2] = np.cos(ang)
+    return pe
+
+
+def add_pe(x: np.ndarray, alpha: np.ndarray) -> np.ndarray:
+    """SinePositionalEmbedding.forward (modules/embedding.py:94-98) with x_scale = 1
+    (scale=False, :60) and dropout = identity in eval: x * 1 + alpha * pe[:T]."""
+    T, d = x.shape
+    return (x * F32(1.0) + alpha.astype(F32) * sine_pe(T, d)).astype(F32)
+
+
+# ------------------------------------------------------------------------------------------------
+# modules/transformer.py
+
+
+def mha(sd: SD, p: str, q_in: np.ndarray, kv_in: Optional[np.ndarray], n_heads: int) -> np.ndarray:
+    """MultiHeadAttention.forward (modules/transformer.py:35-57): separate w_q/w_k/w_v Linear
+    (+bias), SDPA with mask None, dropout 0, scale 1/sqrt(head_dim), then out_proj[0]."""
+    src = q_in if kv_in is None else kv_in
+    q = linear(q_in, sd[f"{p}.w_q.weight"], sd[f"{p}.w_q.bias"])
+    k = linear(src, sd[f"{p}.w_k.weight"], sd[f"{p}.w_k.bias"])
+    v = linear(src, sd[f"{p}.w_v.weight"], sd[f"{p}.w_v.bias"])
+    d = q.shape[1]
+    hd = d // n_heads
+    out = np.empty_like(q)
+    scale = F32(1.0 / math.sqrt(hd))
+    for h in range(n_heads):
+        sl = slice(h * hd, (h + 1) * hd)
+        s = (q[:, sl] @ k[:, sl].T) * scale
+        out[:, sl] = softmax_rows(s.astype(F32)) @ v[:, sl]
+    return linear(out, sd[f"{p}.out_proj.0.weight"], sd[f"{p}.out_proj.0.bias"])
+
+
+def encoder_layer(sd: SD, p: str, x: np.ndarray, n_heads: int, conv_ff: bool) -> np.ndarray:
+    """TransformerEncoderLayer.forward (modules/transformer.py:88-102).  Note the conv-FF
+    asymmetry (:95-99): x is REPLACED by norm2(x) before the residual."""
+    x = x + mha(sd, f"{p}.attn", layer_norm(x, sd[f"{p}.norm1.weight"], sd[f"{p}.norm1.bias"]), None, n_heads)
+    if conv_ff:
+        x = layer_norm(x, sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"])
+        h = relu(conv1d(x, sd[f"{p}.ff.0.weight"], sd[f"{p}.ff.0.bias"], padding=2))
+        x = x + conv1d(h, sd[f"{p}.ff.2.weight"], sd[f"{p}.ff.2.bias"], padding=2)
+    else:
+        y = layer_norm(x, sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"])
+        h = relu(linear(y, sd[f"{p}.ff.0.weight"], sd[f"{p}.ff.0.bias"]))
+        x = x + linear(h, sd[f"{p}.ff.3.weight"], sd[f"{p}.ff.3.bias"])
+    return x.astype(F32)
+
+
+def encoder(sd: SD, p: str, x: np.ndarray, n_layers: int, n_heads: int, conv_ff: bool) -> np.ndarray:
+    """TransformerEncoder.forward with x_lens=None -> mask None, norm None
+    (modules/transformer.py:118-133; inference call sites models/megatts2.py:177,271)."""
+    for l in range(n_layers):
+        x = encoder_layer(sd, f"{p}.{l}", x, n_heads, conv_ff)
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# modules/convnet.py
+
+
+def conv_block(sd: SD, p: str, x: np.ndarray, k: int) -> np.ndarray:
+    """ConvBlock.forward (modules/convnet.py:23-31): ReLU -> (dropout) -> Conv1d(pad (k-1)//2)
+    -> LayerNorm over channels."""
+    y = conv1d(relu(x), sd[f"{p}.conv.weight"], sd[f"{p}.conv.bias"], padding=(k - 1) // 2)
+    return layer_norm(y, sd[f"{p}.norm.weight"], sd[f"{p}.norm.bias"])
+
+
+def residual_stack(sd: SD, p: str, x: np.ndarray, k: int, n_stacks: int, n_blocks: int) -> np.ndarray:
+    """ResidualBlockStack.forward (modules/convnet.py:69-72): x = x + ConvStack(x)."""
+    for s in range(n_stacks):
+        y = x
+        for b in range(n_blocks):
+            y = conv_block(sd, f"{p}.conv_stacks.{s}.blocks.{b}", y, k)
+        x = (x + y).astype(F32)
+    return x
+
+
+def convnet(sd: SD, p: str, x: np.ndarray, k: int, n_stacks: int, n_blocks: int) -> np.ndarray:
+    """ConvNet.forward (modules/convnet.py:115-119): first conv, residual stack, last conv."""
+    pad = (k - 1) // 2
+    x = conv1d(x, sd[f"{p}.first_layer.weight"], sd[f"{p}.first_layer.bias"], padding=pad)
+    x = residual_stack(sd, f"{p}.conv_stack", x, k, n_stacks, n_blocks)
+    return conv1d(x, sd[f"{p}.last_layer.weight"], sd[f"{p}.last_layer.bias"], padding=pad)
+
+
+def convnet_double(sd: SD, p: str, x: np.ndarray, k: int, n_layers: int, n_stacks: int, n_blocks: int,
+                   middle) -> np.ndarray:
+    """ConvNetDouble.forward (modules/convnet.py:202-210): first conv; N parallel branches
+    (ConvNetDoubleLayer.forward :150-154 = stack1 -> middle -> stack2) summed; last conv."""
+    pad = (k - 1) // 2
+    x = conv1d(x, sd[f"{p}.first_layer.weight"], sd[f"{p}.first_layer.bias"], padding=pad)
+    acc = None
+    for l in range(n_layers):
+        y = residual_stack(sd, f"{p}.layers.{l}.conv_stack1", x, k, n_stacks, n_blocks)
+        y = middle(y, l)
+        y = residual_stack(sd, f"{p}.layers.{l}.conv_stack2", y, k, n_stacks, n_blocks)
+        acc = y if acc is None else (acc + y).astype(F32)
+    return conv1d(acc, sd[f"{p}.last_layer.weight"], sd[f"{p}.last_layer.bias"], padding=pad)
+
+
+# ------------------------------------------------------------------------------------------------
+# modules/mrte.py
+
+
+def mrte_mel_context(sd: SD, cfg, mel: np.ndarray) -> np.ndarray:
+    """mel_encoder of MRTE (modules/mrte.py:101-117): ConvNetDouble whose middle layer is ONE
+    shared Conv1d(h, h, k=stride+1, stride, pad=stride//2)."""
+    m = cfg.mrte
+    w, b = sd["mrte.mel_encoder_middle_layer.weight"], sd["mrte.mel_encoder_middle_layer.bias"]
+
+    def middle(y, l):
+        return conv1d(y, w, b, stride=m.mel_stride, padding=m.mel_stride // 2)
+
+    return convnet_double(sd, "mrte.mel_encoder", mel, m.mel_kernel_size, m.mel_n_layer,
+                          m.mel_n_stack, m.mel_n_block, middle)
+
+
+def mrte_phone_encoder(sd: SD, cfg, phone: np.ndarray) -> np.ndarray:
+    """Phone embedding + PE + conv-FF transformer (modules/mrte.py:159-160,165)."""
+    m = cfg.mrte
+    emb = sd["mrte.phone_embedding.word_embeddings.weight"][phone.astype(np.int64)]
+    x = add_pe(emb.astype(F32), sd["mrte.phone_pos_embedding.alpha"])
+    return encoder(sd, "mrte.phone_encoder.layers", x, m.content_n_layers, m.content_n_heads, True)
+
+
+def mrte_tc_latent(sd: SD, cfg, phone: np.ndarray, mel: np.ndarray) -> np.ndarray:
+    """MRTE.tc_latent (modules/mrte.py:154-171): phone[Np] int, mel[Tp, mel_bins] -> [Np, hidden].
+    Cross-attention is ONE head of width hidden (mrte.py:131-135), then LayerNorm, ReLU."""
+    ctx = mrte_mel_context(sd, cfg, mel)
+    px = mrte_phone_encoder(sd, cfg, phone)
+    y = mha(sd, "mrte.mha", px, ctx, 1)
+    return relu(layer_norm(y, sd["mrte.norm.weight"], sd["mrte.norm.bias"]))
+
+
+def create_alignment(durations: Sequence[int]) -> np.ndarray:
+    """create_alignment (modules/mrte.py:23-31) for one utterance: dense 0/1 [sum(d), Np]."""
+    durations = [int(d) for d in durations]
+    a = np.zeros((sum(durations), len(durations)), F32)
+    count = 0
+    for j, d in enumerate(durations):
+        for k in range(d):
+            a[count + k, j] = 1
+        count += d
+    return a
+
+
+def length_regulate(x: np.ndarray, durations: Sequence[int]) -> np.ndarray:
+    """LengthRegulator.forward (modules/mrte.py:42-60) for one utterance: alignment @ x
+    (== repeat_interleave; zero durations are skipped)."""
+    return (create_alignment(durations) @ x.astype(F32)).astype(F32)
+
+
+# ------------------------------------------------------------------------------------------------
+# models/megatts2.py: ADM / PLM autoregressive inference
+
+
+def adm_infer(sd: SD, cfg, tc_latent: np.ndarray, return_float: bool = False):
+    """MegaADM.infer (models/megatts2.py:257-275): for t in range(Np) re-encode ALL t+1 positions
+    NON-causally (mask None), append the un-rounded float prediction of the last
+    position (N3), finally trunc(x + 0.5).clamp(1, 128) as int32."""
+    n = tc_latent.shape[0]
+    p_code = np.zeros((1, 1), F32)                              # :262-263
+    tc_emb_all = linear(tc_latent, sd["tc_linear_emb.weight"])  # row-wise; slicing commutes
+    for t in range(n):
+        dt_emb = linear(p_code, sd["dt_linear_emb.weight"])     # [t+1, emb]
+        x = np.concatenate([tc_emb_all[:t + 1], dt_emb], axis=-1)
+        x = add_pe(x, sd["pos_emb.alpha"])
+        x = encoder(sd, "adm.layers", x, cfg.n_layers, cfg.n_heads, False)
+        pred = linear(x, sd["predict_layer.weight"])[-1:, :]    # :272
+        p_code = np.concatenate([p_code, pred], axis=0)
+    flt = p_code[1:, 0].astype(F32)
+    dur = np.clip(np.trunc(flt + F32(0.5)).astype(np.int32), 1, 128)   # :275 (.to(int32) truncates)
+    return (dur, flt) if return_float else dur
+
+
+def plm_infer(sd: SD, cfg, cond: np.ndarray, return_logits: bool = False):
+    """MegaPLM.infer (models/megatts2.py:165-181): BOS = 1024 (hard-coded literal at :170, equal to
+    vq_bins in the shipped config), greedy argmax over vq_bins logits of the LAST position after a
+    NON-causal re-encode of all t+1 positions."""
+    tq = cond.shape[0]
+    codes: List[int] = [PLM_BOS]
+    logits_all = []
+    for t in range(tq):
+        pc = sd["pc_embedding.weight"][np.asarray(codes, np.int64)]
+        x = np.concatenate([cond[:t + 1], pc], axis=-1).astype(F32)
+        x = add_pe(x, sd["pos.alpha"])
+        x = encoder(sd, "plm.layers", x, cfg.n_layers, cfg.n_heads, False)
+        logits = linear(x[-1:], sd["predict_layer.weight"])[0]
+        logits_all.append(logits)
+        codes.append(int(np.argmax(logits)))                    # first index on ties (torch.argmax)
+    out = np.asarray(codes[1:], np.int64)
+    return (out, np.stack(logits_all)) if return_logits else out
+
+
+# ------------------------------------------------------------------------------------------------
+# modules/quantization/core_vq.py and modules/vqpe.py
+
+CODEBOOK = "vqpe.vq.vq.layers.0._codebook.embed"
+PLM_BOS = 1024   # models/megatts2.py:170
+
+
+def vq_quantize(embed: np.ndarray, x: np.ndarray) -> np.ndarray:
+    """EuclideanCodebook.quantize (core_vq.py:175-183): argmax_j -(|x|^2 - 2 x.e_j + |e_j|^2)
+    evaluated in that operand order ((xx - (2x)@E) + ee), ties -> lowest index."""
+    x = x.astype(F32)
+    e_t = embed.astype(F32).T
+    xx = (x * x).sum(axis=1, keepdims=True, dtype=F32)
+    ee = (e_t * e_t).sum(axis=0, keepdims=True, dtype=F32)
+    dist = -((xx - (F32(2) * x) @ e_t) + ee)
+    return np.argmax(dist, axis=-1).astype(np.int64)
+
+
+def vq_distances(embed: np.ndarray, x: np.ndarray) -> np.ndarray:
+    """The score matrix of `vq_quantize` in float64 (for decision-margin reporting only)."""
+    x = x.astype(np.float64)
+    e = embed.astype(np.float64)
+    return -((x * x).sum(1, keepdims=True) - 2 * x @ e.T + (e * e).sum(1)[None])
+
+
+def vq_decode(embed: np.ndarray, codes: np.ndarray) -> np.ndarray:
+    """EuclideanCodebook.dequantize (core_vq.py:188-190): embedding gather -> [T, dim]."""
+    return embed[codes.astype(np.int64)].astype(F32)
+
+
+def vqpe_encode(sd: SD, cfg, mel: np.ndarray) -> np.ndarray:
+    """VQProsodyEncoder convnet (modules/vqpe.py:54-57): first `mel_bins` (20) mel bins ->
+    ConvNetDouble with MaxPool1d(stride, ceil_mode=True) middle (vqpe.py:38) -> ze [ceil(T/8), vq_dim]."""
+    v = cfg.vqpe
+
+    def middle(y, l):
+        return max_pool1d_ceil(y, v.stride)
+
+    return convnet_double(sd, "vqpe.convnet", mel[:, :v.mel_bins].astype(F32), v.kernel_size,
+                          v.n_layers, v.n_stacks, v.n_blocks, middle)
+
+
+def vqpe_forward(sd: SD, cfg, mel: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """VQProsodyEncoder.forward (modules/vqpe.py:50-62) in eval: returns
+    (zq [T, vq_dim] = codebook rows repeated x stride and cropped to T, codes [ceil(T/8)], ze)."""
+    v = cfg.vqpe
+    ze = vqpe_encode(sd, cfg, mel)
+    codes = vq_quantize(sd[CODEBOOK], ze)
+    zq = np.repeat(vq_decode(sd[CODEBOOK], codes), v.stride, axis=0)[: mel.shape[0]]
+    return zq.astype(F32), codes, ze
+
+
+def decoder_input(sd: SD, cfg, tc_expand: np.ndarray, p_codes: np.ndarray) -> np.ndarray:
+    """models/megatts2.py:361-366: zq = codebook[p_codes] repeated x8, cropped to Tm, concatenated
+    AFTER tc_latent_expand -> [Tm, hidden + vq_dim]."""
+    zq = np.repeat(vq_decode(sd[CODEBOOK], p_codes), cfg.vqpe.stride, axis=0)[: tc_expand.shape[0]]
+    return np.concatenate([tc_expand, zq], axis=-1).astype(F32)
+
+
+def mel_decoder(sd: SD, cfg, x: np.ndarray) -> np.ndarray:
+    """MegaG.decoder = ConvNet (models/megatts2.py:46-54,368): x[Tm, 768] -> mel[Tm, 80]."""
+    return convnet(sd, "decoder", x, cfg.kernel_size, cfg.decoder_n_stack, cfg.decoder_n_block)
+
+
+# ------------------------------------------------------------------------------------------------
+# HiFi-GAN V1 generator (NOT in the reference tree; parity unpinned - see module docstring)
+
+
+def hifigan(sd: SD, cfg, mel: np.ndarray) -> np.ndarray:
+    """mel[T, 80] -> waveform[T * hop].  conv_pre k7; per stage: leaky_relu(0.1) ->
+    ConvTranspose1d(k, stride, pad (k-stride)//2) -> mean of ResBlock1(k in {3,7,11}, dil {1,3,5});
+    then leaky_relu(0.01 default slope) -> conv_post k7 -> tanh.  Call site in the reference:
+    models/megatts2.py:370 `hifi_gan.decode_batch(x)`."""
+    slope = cfg.leaky_relu_slope
+    x = conv1d(mel.astype(F32), sd["conv_pre.weight"], sd["conv_pre.bias"], padding=3)
+    nk = len(cfg.resblock_kernel_sizes)
+    for i, (r, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+        x = leaky_relu(x, slope)
+        x = conv_transpose1d(x, sd[f"upsampler.{i}.weight"], sd[f"upsampler.{i}.bias"], r, (k - r) // 2)
+        acc = None
+        for j, (rk, dils) in enumerate(zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes)):
+            p = f"resblocks.{i * nk + j}"
+            h = x
+            for n, d in enumerate(dils):
+                res = h
+                y = conv1d(leaky_relu(h, slope), sd[f"{p}.convs1.{n}.weight"], sd[f"{p}.convs1.{n}.bias"],
+                           padding=(rk * d - d) // 2, dilation=d)
+                y = conv1d(leaky_relu(y, slope), sd[f"{p}.convs2.{n}.weight"], sd[f"{p}.convs2.{n}.bias"],
+                           padding=(rk - 1) // 2)
+                h = (y + res).astype(F32)
+            acc = h if acc is None else (acc + h).astype(F32)
+        x = (acc / F32(nk)).astype(F32)
+    x = leaky_relu(x, 0.01)
+    x = conv1d(x, sd["conv_post.weight"], sd["conv_post.bias"], padding=3)
+    return np.tanh(x[:, 0]).astype(F32)
+
+
+# ------------------------------------------------------------------------------------------------
+# the pipeline of Megatts.forward (models/megatts2.py:353-368), one utterance
+
+
+def synthesize(sd_g: SD, sd_plm: SD, sd_adm: SD, g_cfg, plm_cfg, adm_cfg, phone: np.ndarray,
+               prompt_mel: np.ndarray, forced_durations: Optional[Sequence[int]] = None,
+               forced_codes: Optional[np.ndarray] = None, run_plm: bool = True) -> Dict[str, np.ndarray]:
+    """tc_latent -> ADM durations -> length regulate -> max-pool(8, ceil) -> PLM codes -> VQ decode
+    + concat -> mel decoder.  `forced_durations` replaces the ADM's integer durations after the ADM
+    has run (benchmarks: random weights predict duration 1 everywhere); `forced_codes`
+    replaces the PLM (config C2: "MRTE+ADM mel decode only")."""
+    out: Dict[str, np.ndarray] = {}
+    tc = mrte_tc_latent(sd_g, g_cfg, phone, prompt_mel)
+    out["tc_latent"] = tc
+    dur, flt = adm_infer(sd_adm, adm_cfg, tc, return_float=True)
+    out["adm_float"], out["adm_dur"] = flt, dur
+    if forced_durations is not None:
+        dur = np.asarray(forced_durations, np.int32)
+    out["dur"] = dur
+    tc_expand = length_regulate(tc, dur)
+    out["tc_expand"] = tc_expand
+    cond = max_pool1d_ceil(tc_expand, g_cfg.vqpe.stride)
+    out["plm_cond"] = cond
+    if forced_codes is not None:
+        codes = np.asarray(forced_codes, np.int64)
+    elif run_plm:
+        codes = plm_infer(sd_plm, plm_cfg, cond)
+    else:
+        raise ValueError("need forced_codes when run_plm is False")
+    out["p_codes"] = codes
+    x = decoder_input(sd_g, g_cfg, tc_expand, codes)
+    out["mel"] = mel_decoder(sd_g, g_cfg, x)
+    return out
+
+
+def rel_l2(a: np.ndarray, b: np.ndarray) -> float:
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))

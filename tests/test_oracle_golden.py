@@ -1,0 +1,92 @@
+"""Pins the CPU oracle (oracle/megatts2_oracle.py) against fixtures produced by the LIVE reference
+modules (oracle/make_golden.py).  Stage-wise with teacher forcing: every stage gets the golden
+input of that stage, so one stage's round-off cannot hide in another's."""
+import numpy as np
+import pytest
+
+import megatts2_oracle as O
+from conftest import load_golden
+
+TOL = 2e-5          # fp32 round-off class (numpy BLAS vs ATen/oneDNN accumulation order)
+TINY = [f"tiny_utt{i}.npz" for i in range(4)]
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_tiny_stages(tiny, name):
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = tiny
+    z = load_golden(name)
+    ctx = O.mrte_mel_context(sd_g, g, z["prompt_mel"])
+    assert O.rel_l2(ctx, z["mel_context"]) < TOL
+    tc = O.mrte_tc_latent(sd_g, g, z["phone"], z["prompt_mel"])
+    assert O.rel_l2(tc, z["tc_latent"]) < TOL
+    dur, flt = O.adm_infer(sd_a, a, z["tc_latent"], return_float=True)
+    assert np.allclose(flt, z["adm_float"], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(dur, z["adm_dur"])
+    tce = O.length_regulate(z["tc_latent"], z["forced_dur"])
+    cond = O.max_pool1d_ceil(tce, 8)
+    assert np.array_equal(cond, z["plm_cond"])          # gather + max: exact
+    codes, logits = O.plm_infer(sd_p, p, z["plm_cond"], return_logits=True)
+    assert np.array_equal(codes, z["p_codes"])
+    assert O.rel_l2(logits, z["plm_logits"]) < 1e-4
+    x = O.decoder_input(sd_g, g, tce, z["p_codes"])
+    assert np.array_equal(x, z["decoder_in"])
+    assert O.rel_l2(O.mel_decoder(sd_g, g, x), z["mel"]) < TOL
+    zq, vcodes, ze = O.vqpe_forward(sd_g, g, z["target_mel"])
+    assert O.rel_l2(ze, z["vqpe_ze"]) < TOL
+    assert np.array_equal(vcodes, z["vqpe_codes"])
+    assert np.array_equal(zq, z["vqpe_zq"])
+    # L2-argmin on the golden encoder output itself: bit-exact indices
+    assert np.array_equal(O.vq_quantize(sd_g[O.CODEBOOK], z["vqpe_ze"]), z["vqpe_codes"])
+
+
+def test_tiny_pipeline_end_to_end(tiny):
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = tiny
+    z = load_golden("tiny_utt0.npz")
+    out = O.synthesize(sd_g, sd_p, sd_a, g, p, a, z["phone"], z["prompt_mel"], forced_durations=z["forced_dur"])
+    assert np.array_equal(out["adm_dur"], z["adm_dur"])
+    assert np.array_equal(out["p_codes"], z["p_codes"])
+    assert O.rel_l2(out["mel"], z["mel"]) < 1e-4
+
+
+def test_prod_c1(prod):
+    """Config C1 (BASELINE.json configs[0]): single ~260-frame utterance, production shapes."""
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = prod
+    z = load_golden("prod_utt0.npz")
+    tc = O.mrte_tc_latent(sd_g, g, z["phone"], z["prompt_mel"])
+    assert O.rel_l2(tc, z["tc_latent"]) < TOL
+    dur, flt = O.adm_infer(sd_a, a, z["tc_latent"], return_float=True)
+    assert np.allclose(flt, z["adm_float"], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(dur, z["adm_dur"])
+    codes = O.plm_infer(sd_p, p, z["plm_cond"])
+    assert np.array_equal(codes, z["p_codes"])
+    assert O.rel_l2(O.mel_decoder(sd_g, g, z["decoder_in"]), z["mel"]) < TOL
+    zq, vcodes, ze = O.vqpe_forward(sd_g, g, z["target_mel"])
+    assert O.rel_l2(ze, z["vqpe_ze"]) < TOL
+    assert np.array_equal(vcodes, z["vqpe_codes"])
+    assert len(set(vcodes.tolist())) > 16       # the ze-matched codebook gives diverse indices
+
+
+@pytest.mark.parametrize("kind", ["tiny", "prod"])
+def test_hifigan_stand_in(kind, tiny, prod):
+    """Vocoder: parity UNPINNED w.r.t. the reference (speechbrain hub model absent); pinned only
+    against transformers.SpeechT5HifiGan with the same synthetic weights."""
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = tiny if kind == "tiny" else prod
+    z = load_golden(f"{kind}_hifigan.npz")
+    i = 0
+    while f"mel{i}" in z:
+        wav = O.hifigan(sd_h, h, z[f"mel{i}"])
+        assert wav.shape == z[f"wav{i}"].shape
+        assert O.rel_l2(wav, z[f"wav{i}"]) < 1e-4
+        i += 1
+
+
+def test_known_answers():
+    """Hand-verified KATs from SURVEY.md 8c: LengthRegulator rows and the reference's only shape
+    assertion (modules/mrte.py:186-194)."""
+    x = np.arange(8, dtype=np.float32).reshape(4, 2)
+    y = O.length_regulate(x, [1, 2, 0, 3])
+    assert y.tolist() == [[0, 1], [2, 3], [2, 3], [6, 7], [6, 7], [6, 7]]
+    assert O.length_regulate(np.zeros((4, 128), np.float32), [1, 2, 3, 5]).shape == (11, 128)
+    # all-zero codebook -> every distance ties -> index 0 (lowest index)
+    assert O.vq_quantize(np.zeros((16, 4), np.float32), np.ones((3, 4), np.float32)).tolist() == [0, 0, 0]
+    assert O.max_pool1d_ceil(np.arange(10, dtype=np.float32)[:, None], 8)[:, 0].tolist() == [7, 9]

@@ -1,0 +1,248 @@
+"""Benchmark of the MI355X Mega-TTS 2 synthesis hot path (contract: see the task's bench.py section).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic utterances, inputs already resident
+in HBM.  Default workload = BASELINE.json configs[1] (C2): per GPU 32 utterances of 70 phones, a
+431-frame prompt and 431 target frames through MRTE -> ADM (autoregressive, runs in full) -> length
+regulation -> VQ decode + concat -> mel decoder, with durations and prosody codes forced so that
+the frame count is exact (random weights predict arbitrary durations).  C3 adds the
+PLM (free-running) and the vocoder.  Weights are synthetic (no checkpoint ships with the
+reference), fp32 throughout (`dtype: "f32"`: exact-f32 MFMA).
+
+N > 1: one process per GPU, utterances sharded by rank (weak scaling: 32 per GPU, C4 = 8 x 32), the
+only exchange is an RCCL all-gather of the generated mels + lengths at the end of each step.
+
+Output: ONE JSON line on rank 0 with the whole-job mel-frames/s, plus
+  roofline      - the GEMM/conv engine (dominant kernel family) against the f32 MFMA peak, from a
+                  traced step: HIP events around every launch on the launch stream;
+  cpu_baseline  - the numpy oracle (a port of the reference's path) timed on this box's host cores
+                  on ONE utterance of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def gemm_flops_model(g, adm, plm, hg, utts, stages):
+    """Algorithmic FLOPs (2*MAC) of the conv/linear GEMMs in REFERENCE semantics (non-causal
+    recompute-all AR steps), and of attention separately, for a list of utterances."""
+    gemm = 0.0
+    attn = 0.0
+    m, v = g.mrte, g.vqpe
+    H = m.hidden_size
+    for u in utts:
+        Np, Tp, Tm = u.phone.size, u.prompt_mel.shape[0], int(u.durations.sum())
+        Tc = (Tp - 1) // m.mel_stride + 1
+        Tq = -(-Tm // v.stride)
+        if "mrte" in stages:
+            k = m.mel_kernel_size
+            blocks = m.mel_n_stack * m.mel_n_block
+            mac = Tp * k * m.mel_bins * H
+            mac += m.mel_n_layer * blocks * Tp * k * H * H
+            mac += m.mel_n_layer * Tc * (m.mel_stride + 1) * H * H
+            mac += m.mel_n_layer * blocks * Tc * k * H * H + Tc * k * H * H
+            mac += m.content_n_layers * Np * (4 * H * H + 2 * 5 * H * m.content_ff_dim)
+            mac += 2 * Np * H * H + 2 * Tc * H * H
+            gemm += 2.0 * mac
+            attn += m.content_n_layers * 4.0 * Np * Np * H + 4.0 * Np * Tc * H
+        if "adm" in stages:
+            d, ff = adm.d_model, adm.ff_dim
+            per_tok = adm.n_layers * (4 * d * d + 2 * d * ff)
+            passes = Np * (Np + 1) // 2
+            gemm += 2.0 * (Np * adm.tc_latent_dim * adm.tc_emb_dim + passes * per_tok)
+            attn += adm.n_layers * 4.0 * d * sum(n * n for n in range(1, Np + 1))
+        if "plm" in stages:
+            d, ff = plm.d_model, plm.ff_dim
+            per_tok = plm.n_layers * (4 * d * d + 2 * d * ff)
+            passes = Tq * (Tq + 1) // 2
+            gemm += 2.0 * (passes * per_tok + Tq * Tq * d * plm.vq_bins)     # predict_layer on ALL rows (:178)
+            attn += plm.n_layers * 4.0 * d * sum(n * n for n in range(1, Tq + 1))
+        if "decoder" in stages:
+            k, D = g.kernel_size, g.hidden_size
+            mac = Tm * k * (g.decoder_in * D + g.decoder_n_stack * g.decoder_n_block * D * D + D * m.mel_bins)
+            gemm += 2.0 * mac
+        if "vocoder" in stages:
+            ch = hg.upsample_initial_channel
+            T = Tm
+            mac = T * 7 * hg.in_dim * ch
+            for r, kk in zip(hg.upsample_rates, hg.upsample_kernel_sizes):
+                mac += T * kk * ch * (ch // 2)            # transposed conv: k/r taps per output sample
+                T *= r
+                ch //= 2
+                for rk, dils in zip(hg.resblock_kernel_sizes, hg.resblock_dilation_sizes):
+                    mac += T * len(dils) * 2 * rk * ch * ch
+            mac += T * 7 * ch
+            gemm += 2.0 * mac
+    return gemm, attn
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3"])
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import megatts2_oracle as O
+    from megatts2_amd import config as C
+    from megatts2_amd import synth, weights
+    from megatts2_amd.dist import gather_mels
+    from megatts2_amd.runtime import NativeModel, gemm_trace_begin, gemm_trace_end
+
+    g, p, a, h = C.production_g(), C.production_plm(), C.production_adm(), C.production_hifigan()
+    sd_g = weights.synth_state_dict(weights.inventory_g(g), 0, "G.")
+    emb = np.load(os.path.join(ROOT, "tests", "golden", "codebook_prod.npy"))
+    sd_g[O.CODEBOOK] = emb
+    sd_g[O.CODEBOOK.replace("embed", "embed_avg")] = emb.copy()
+    sd_a = weights.synth_state_dict(weights.inventory_adm(a), 0, "adm.")
+    full = args.workload == "C3"
+    sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.") if full else None
+    sd_h = weights.synth_state_dict(weights.inventory_hifigan(h), 0, "hifigan.") if full else None
+    model = NativeModel(g, p, a, h, sd_g, sd_p, sd_a, sd_h)
+
+    shape = {"C1": synth.C1, "C2": synth.C2, "C3": synth.C3}[args.workload]
+    B = args.batch or shape.B
+    utts = synth.make_batch(shape, seed=1000 + int(args.workload[1]) + 17 * rank, batch=B)
+    Np, Tp = shape.Np, shape.Tp
+    phone = torch.from_numpy(np.stack([u.phone for u in utts])).to(dev)
+    mel_in = torch.from_numpy(np.stack([u.prompt_mel for u in utts])).to(dev)
+    dur = np.stack([u.durations for u in utts]).astype(np.int32)
+    codes = None if full else torch.from_numpy(np.stack([u.p_codes for u in utts])).to(dev)
+    pl = np.full(B, Np, np.int32)
+    ml = np.full(B, Tp, np.int32)
+    frames_per_step = int(dur.sum())
+    stages = ["mrte", "adm", "decoder"] + (["plm", "vocoder"] if full else [])
+
+    def step():
+        out = model.synthesize_batch(phone, pl, mel_in, ml, forced_dur=dur, forced_codes=codes, run_plm=full,
+                                     vocoder=full, tm_cap=shape.Tm)
+        mel, lens = out[0], out[1]
+        if world > 1:
+            mel, lens = gather_mels(mel, lens)       # RCCL all-gather over xGMI (the path's only exchange)
+        return mel, lens
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        f = torch.tensor([frames_per_step], device=dev, dtype=torch.float64)
+        dist.all_reduce(f, op=dist.ReduceOp.SUM)
+        total_frames = float(f.item())
+    else:
+        total_frames = float(frames_per_step)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_frames * args.steps / elapsed
+
+    result = {
+        "metric": "mel-frames/sec (whole node)", "value": round(value, 1), "unit": "mel-frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: B={B}/GPU x {world} GPU, Np={Np}, Tp={Tp}, Tm={shape.Tm}; stages "
+                               + "+".join(stages) + "; forced durations" + ("" if full else " and prosody codes"),
+                   "frames_per_step": int(total_frames), "weights": "synthetic (name-seeded)", "parallelism":
+                   f"dp{world} (utterance shards, RCCL all-gather of mels)"},
+        "rtf": {"sr16000": round(elapsed / args.steps / (total_frames * 256 / 16000), 6),
+                "sr22050": round(elapsed / args.steps / (total_frames * 256 / 22050), 6)},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # one traced step: HIP events around every GEMM/conv launch on the launch stream
+        model.set_profiling(True)
+        gemm_trace_begin()
+        step()
+        torch.cuda.synchronize()
+        tr = gemm_trace_end()
+        result["stage_ms"] = {k: round(v, 3) for k, v in model.last_stage_ms().items()}
+        model.set_profiling(False)
+        alg_gemm, alg_attn = gemm_flops_model(g, a, p, h, utts, stages)
+        t_ms = sum(r["ms"] for r in tr)
+        n_launch = sum(r["launches"] for r in tr)
+        exe = sum(r["flops"] for r in tr)
+        achieved = alg_gemm / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "gemm_f32_kernel<*> (implicit-GEMM conv/linear engine, f32 MFMA)",
+            "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / max(n_launch, 1), 2),
+            "algorithmic_gflop_per_step": round(alg_gemm / 1e9, 1), "executed_gflop_per_step": round(exe / 1e9, 1),
+            "attention_gflop_per_step": round(alg_attn / 1e9, 1), "gemm_ms_per_step": round(t_ms, 3),
+            "per_config": [{"config": r["config"], "launches": r["launches"], "ms": round(r["ms"], 3),
+                            "tflops": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2)} for r in tr],
+        }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the oracle (numpy port of the reference path) on ONE utterance of the same workload
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+        except Exception:
+            threads = os.cpu_count() or 1
+        u = utts[0]
+        if sd_p is None and full:
+            sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.")
+        t0 = time.perf_counter()
+        ref = O.synthesize(sd_g, sd_p, sd_a, g, p, a, u.phone, u.prompt_mel, forced_durations=u.durations,
+                           forced_codes=None if full else u.p_codes, run_plm=full)
+        if full:
+            O.hifigan(sd_h, h, ref["mel"])
+        cpu_s = time.perf_counter() - t0
+        result["cpu_baseline"] = {"value": round(ref["mel"].shape[0] / cpu_s, 2), "unit": "mel-frames/s",
+                                  "cores": int(threads), "kind": "port",
+                                  "sample": f"1 of the {B} utterances of {args.workload} (Np={Np}, Tp={Tp}, "
+                                            f"Tm={ref['mel'].shape[0]}), numpy oracle, {cpu_s:.1f} s"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,182 @@
+/* libmegatts2_hip - C ABI of the MI355X (gfx950) Mega-TTS 2 synthesis path.
+ *
+ * The reference (LSimon95/megatts2) has no plugin / FFI layer: its drop-in boundary is the Python
+ * object surface of `models/megatts2.py`.  Each entry point below replaces one
+ * method of that surface; the Python mirror in megatts2_amd/ binds them with ctypes and keeps the
+ * reference's class / method names and tensor layouts.
+ *
+ * Conventions
+ *  - Every `const float*` / `float*` / `int64_t*` / `int32_t*` NOT marked (host) is a DEVICE pointer
+ *    (PyTorch-ROCm `tensor.data_ptr()`), f32 / int64 / int32, contiguous, 16-byte aligned.
+ *  - Batched tensors use the reference's padded batch-first layouts; per-utterance true lengths are
+ *    passed as (host) int32 arrays.  Padding positions of outputs are written as zeros.
+ *  - `stream` is a hipStream_t (pass `torch.cuda.current_stream().cuda_stream`); all work is
+ *    enqueued on it.  Calls that must size their output (mt2_adm_infer -> durations) document
+ *    their host synchronisation.
+ *  - Return value: 0 = ok, < 0 = error; `mt2_last_error()` gives the message (thread-local).
+ *    Nothing throws across the boundary.
+ *  - A model handle is immutable after `mt2_model_finalize`; one call at a time per handle (it owns
+ *    the activation workspace).  Batch semantics: every utterance is computed exactly as if it were
+ *    alone (the reference is batch-1).
+ */
+#ifndef MEGATTS2_HIP_H
+#define MEGATTS2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mt2_model mt2_model;
+
+/* Hyper-parameters = the `model:` sub-trees of the reference's configs/config_{gan,plm,adm}.yaml
+ * (reference models/megatts2.py:87-104,184-191,278-286) + the HiFi-GAN V1 generator topology. */
+typedef struct mt2_config {
+    /* MRTE (modules/mrte.py:64-84) */
+    int32_t mel_bins, mrte_hidden, mrte_kernel, mrte_stride, mrte_n_layer, mrte_n_stack, mrte_n_block;
+    int32_t content_ff_dim, content_n_heads, content_n_layers, phone_vocab;
+    /* VQ prosody encoder (modules/vqpe.py:14-26) */
+    int32_t vq_mel_bins, vq_stride, vq_hidden, vq_kernel, vq_n_layers, vq_n_stacks, vq_n_blocks, vq_bins, vq_dim;
+    /* mel decoder (models/megatts2.py:31-54) */
+    int32_t dec_kernel, dec_hidden, dec_n_stack, dec_n_block;
+    /* PLM (models/megatts2.py:121-146) */
+    int32_t plm_layers, plm_heads, plm_vq_dim, plm_tc_dim, plm_bins;
+    /* ADM (models/megatts2.py:202-231) */
+    int32_t adm_layers, adm_heads, adm_emb_dim, adm_tc_dim, adm_tc_emb_dim;
+    /* HiFi-GAN V1 generator (speechbrain hub model in the reference, models/megatts2.py:321-323) */
+    int32_t hg_in_dim, hg_init_channels, hg_n_up, hg_up_rates[8], hg_up_kernels[8];
+    int32_t hg_n_res, hg_res_kernels[4], hg_res_dilations[4][3];
+    float hg_slope;
+    int32_t max_positions;   /* rows of the sine positional tables (embedding.py:66 builds 4000) */
+} mt2_config;
+
+const char* mt2_last_error(void);
+const char* mt2_version(void);
+/* 0 when a gfx950 device is visible and usable, < 0 otherwise (never falls back to a CPU path). */
+int mt2_device_check(void);
+
+/* ---- model lifetime (replaces MegaG/MegaPLM/MegaADM.from_pretrained, models/megatts2.py:107-117,
+ * 184-198, 278-292).  Tensors are pushed one by one under their reference state_dict names, prefixed
+ * by "G." / "plm." / "adm." / "hifigan."; `data` is a HOST pointer to `numel` f32 values (copied).
+ * Additional tensors "pe.mrte" [max_positions, hidden], "pe.adm", "pe.plm": the sine tables of
+ * modules/embedding.py:68-92 already multiplied by `alpha` (computed by the host mirror exactly
+ * as the reference does).  finalize() checks the inventory strictly (load_state_dict(strict=True)),
+ * repacks weights into GEMM-ready layouts and uploads them. */
+mt2_model* mt2_model_create(const mt2_config* cfg);
+int mt2_model_load_tensor(mt2_model* m, const char* name, const float* data /*host*/, const int64_t* shape /*host*/,
+                          int ndim);
+int mt2_model_finalize(mt2_model* m);
+void mt2_model_destroy(mt2_model* m);
+/* bytes of device memory held (weights, workspace) */
+int mt2_model_memory(const mt2_model* m, size_t* weight_bytes, size_t* workspace_bytes);
+
+/* ---- MRTE.tc_latent(phone, mel) (modules/mrte.py:154-171)
+ * phone int64 [B, Np_max], mel f32 [B, Tp_max, mel_bins] -> out f32 [B, Np_max, hidden]. */
+int mt2_mrte_tc_latent(mt2_model* m, void* stream, const int64_t* phone, const int32_t* phone_lens /*host*/,
+                       int Np_max, const float* mel, const int32_t* mel_lens /*host*/, int Tp_max, int B,
+                       float* out);
+/* the mel-encoder part alone (mrte.mel_encoder, modules/convnet.py:202-210): -> [B, Tc_max, hidden],
+ * Tc = (T-1)/stride + 1 */
+int mt2_mrte_mel_context(mt2_model* m, void* stream, const float* mel, const int32_t* mel_lens /*host*/,
+                         int Tp_max, int B, float* out, int Tc_max);
+
+/* ---- MegaADM.infer(tc_latents) (models/megatts2.py:257-275)
+ * tc_latent f32 [B, Np_max, tc_dim] -> dur int32 [B, Np_max] (0 in padding); `dur_float` (optional, may
+ * be NULL) receives the un-rounded predictions.  Asynchronous on `stream`. */
+int mt2_adm_infer(mt2_model* m, void* stream, const float* tc_latent, const int32_t* lens /*host*/, int Np_max,
+                  int B, int32_t* dur, float* dur_float);
+
+/* ---- LengthRegulator.forward(x, duration_tokens) (modules/mrte.py:42-60)
+ * x f32 [B, Np_max, D], dur int32 (HOST) [B, Np_max] -> out f32 [B, Tm_max, D] (zero rows beyond sum(dur_b)).
+ * Durations are taken from the host because the output size depends on them (the reference also
+ * moves them to the CPU, mrte.py:53). */
+int mt2_length_regulate(mt2_model* m, void* stream, const float* x, const int32_t* dur /*host*/,
+                        const int32_t* lens /*host*/, int Np_max, int D, int B, float* out, int Tm_max);
+
+/* ---- F.max_pool1d(x.transpose(1,2), k, ceil_mode=True).transpose(1,2) (models/megatts2.py:357-358)
+ * x f32 [B, T_max, D] -> out f32 [B, Tq_max, D], Tq = ceil(T/k). */
+int mt2_max_pool_ceil(mt2_model* m, void* stream, const float* x, const int32_t* lens /*host*/, int T_max, int D,
+                      int B, int k, float* out, int Tq_max);
+
+/* ---- MegaPLM.infer(tc_latent) (models/megatts2.py:165-181)
+ * cond f32 [B, Tq_max, tc_dim] -> codes int64 [B, Tq_max] (0 in padding); `last_logits` optional
+ * f32 [B, Tq_max, bins] receives the logits of every step's last position. */
+int mt2_plm_infer(mt2_model* m, void* stream, const float* cond, const int32_t* lens /*host*/, int Tq_max, int B,
+                  int64_t* codes, float* last_logits);
+
+/* ---- generator.vqpe.vq.decode(codes) (modules/quantization/vq.py:109-113)
+ * codes int64 [n_q=1, B, Tq_max] -> out f32 [B, vq_dim, Tq_max]. */
+int mt2_vq_decode(mt2_model* m, void* stream, const int64_t* codes, int B, int Tq_max, float* out);
+
+/* ---- EuclideanCodebook.quantize (modules/quantization/core_vq.py:175-183): L2-argmin
+ * x f32 [M, vq_dim] -> idx int64 [M] (lowest index on ties). */
+int mt2_vq_quantize(mt2_model* m, void* stream, const float* x, int M, int64_t* idx);
+
+/* ---- VQProsodyEncoder.forward(mel) (modules/vqpe.py:50-62), eval mode
+ * mel f32 [B, T_max, mel_bins_full] (only the first vq_mel_bins are read) ->
+ * zq f32 [B, T_max, vq_dim], codes int64 [1, B, Tq_max], ze (optional) f32 [B, Tq_max, vq_dim]. */
+int mt2_vqpe_forward(mt2_model* m, void* stream, const float* mel, const int32_t* lens /*host*/, int T_max,
+                     int mel_ld, int B, float* zq, int64_t* codes, int Tq_max, float* ze);
+
+/* ---- generator.decoder(x) = ConvNet.forward (modules/convnet.py:115-119)
+ * x f32 [B, decoder_in, T_max] ("B D T") -> mel f32 [B, mel_bins, T_max]. */
+int mt2_mel_decoder(mt2_model* m, void* stream, const float* x, const int32_t* lens /*host*/, int T_max, int B,
+                    float* mel);
+
+/* ---- hifi_gan.decode_batch(mel) (speechbrain; models/megatts2.py:370): HiFi-GAN V1 generator
+ * mel f32 [B, in_dim, T_max] -> wav f32 [B, 1, hop*T_max]. */
+int mt2_hifigan(mt2_model* m, void* stream, const float* mel, const int32_t* lens /*host*/, int T_max, int B,
+                float* wav);
+
+/* ---- the whole of Megatts.forward's no_grad block (models/megatts2.py:353-368 [+370]) for a batch,
+ * activations staying in the packed internal layout between stages.
+ *   forced_dur   (host, optional) int32 [B, Np_max]: replaces the ADM's integer durations AFTER the ADM
+ *                has run (benchmarks on synthetic weights).  NULL: the ADM's own
+ *                durations are copied to the host (one stream synchronisation, as in the reference).
+ *   forced_codes (device, optional) int64 [B, Tq_cap]: replaces the PLM (config C2).
+ *   flags: bit0 run the PLM (ignored when forced_codes given), bit1 run the vocoder, bit2 skip the ADM.
+ * Outputs: mel f32 [B, Tm_cap, mel_bins] (time-major), mel_lens (host) int32 [B], optional
+ * dur_out int32 [B, Np_max] (device), codes_out int64 [B, Tq_cap] (device), wav f32 [B, hop*Tm_cap].
+ * Tm_cap / Tq_cap are capacities; an utterance longer than Tm_cap is an error. */
+#define MT2_RUN_PLM 1
+#define MT2_RUN_VOCODER 2
+#define MT2_SKIP_ADM 4
+int mt2_synthesize_batch(mt2_model* m, void* stream, const int64_t* phone, const int32_t* phone_lens /*host*/,
+                         int Np_max, const float* prompt_mel, const int32_t* prompt_lens /*host*/, int Tp_max,
+                         int B, const int32_t* forced_dur /*host*/, const int64_t* forced_codes, int Tq_cap,
+                         int flags, float* mel, int Tm_cap, int32_t* mel_lens /*host*/, int32_t* dur_out,
+                         int64_t* codes_out, float* wav);
+
+/* ---- measurement support: time (ms, HIP events on `stream`) spent in each stage of the last
+ * mt2_synthesize_batch when profiling was enabled with mt2_set_profiling(m, 1).
+ * names: "mrte", "adm", "regulate", "plm", "decoder", "vocoder".  Returns the number of stages. */
+int mt2_set_profiling(mt2_model* m, int enable);
+int mt2_last_stage_ms(mt2_model* m, const char** names, float* ms, int cap);
+
+/* ---- kernel-level entry points (parity tests and micro-benchmarks call the engine directly)
+ * C[M,N] = act(conv/linear(X) + bias) * scale + R, see megatts2_amd/csrc/mt2_kernels.h GemmP. */
+int mt2_op_gemm(void* stream, const float* X, int ldx, int Rx, const int32_t* rowbase, int a_mul, int shift0,
+                int taps, int dil, int Cin, const float* W, int ldw, const float* bias, const float* R, int ldr,
+                const int32_t* valid, float* C, int ldc, int M, int N, int pro_act, float pro_slope, int epi_act,
+                float out_scale, int force_cfg);
+int mt2_op_layernorm(void* stream, const float* x, int ldx, const float* gamma, const float* beta, const float* R1,
+                     int ldr1, const int32_t* valid, float* out, int ldo, int M, int C, float eps, int act);
+int mt2_op_attention(void* stream, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                     float* O, int ldo, const int32_t* q_start, const int32_t* q_len, const int32_t* kv_start,
+                     const int32_t* kv_len, int B, int H, int D, int max_qlen, float scale);
+/* Launch trace of the GEMM/conv engine (measurement only): between begin and end every launch is
+ * bracketed by HIP events on its own stream.  end() reports, per tile configuration, the number of
+ * launches, the executed FLOPs (2*M*N*K*groups) and the summed kernel time in ms; returns the
+ * number of configurations written (<= cap). */
+int mt2_gemm_trace_begin(void);
+int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches, double* flops, double* ms);
+/* time `iters` back-to-back launches of one GEMM with HIP events on `stream`; returns average ms */
+int mt2_bench_gemm(void* stream, int M, int N, int K, int taps, int force_cfg, int iters, float* avg_ms,
+                   char* cfg_name, int cfg_name_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEGATTS2_HIP_H */

@@ -1,0 +1,134 @@
+// Non-causal multi-head attention over per-utterance row ranges, f32, flash-style, gfx950.
+// Replaces F.scaled_dot_product_attention at reference modules/transformer.py:52-53 for the four
+// shapes on the synthesis path (2x256, 1x512, 8x96, 16x64) with mask=None:
+// every query of an utterance attends to every key of the SAME utterance (the reference's AR
+// inference is non-causal) and to nothing else (batch-1 semantics, N1).
+//
+// One wave64 owns a 32-query tile of one (utterance, head) and walks the keys 32 at a time, with the
+// whole online-softmax state in registers and no LDS:
+//   S^T = K . Q^T   on v_mfma_f32_32x32x2_f32 (A = K rows, B = Q rows; both operands are read as one
+//                   float4 per lane along the head dim, the MFMA k index being a free permutation)
+//          -> lane (q = lane&31) holds 16 of the 32 scores of ITS query; the other 16 live in lane^32,
+//             so row max / row sum need one 32-lane-apart shuffle each and nothing else;
+//   O^T += V^T . P^T  (A = V[kv(e), d0 + lane&31] - a coalesced 128-B row segment, B = p[e] straight
+//                   from the score registers) -> lane holds O^T[:, q] and the softmax rescale factor
+//                   alpha[q] is lane-local.
+// Wide heads are split across the waves of a workgroup along d (<= 128 columns = 64 accumulator
+// VGPRs per wave); each wave recomputes S (cheap: these heads only occur in the tiny cross-attention).
+#include "mt2_kernels.h"
+#include <math.h>
+
+namespace mt2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int DT>   // DT 32-column tiles of the head dim per wave
+__global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+    int qs, ql, ks, kl;
+    if (p.q_start) {
+        qs = p.q_start[b]; ql = p.q_len[b]; ks = p.kv_start[b]; kl = p.kv_len[b];
+    } else {
+        qs = b * p.u_qstride; ql = p.u_qlen; ks = b * p.u_kvstride; kl = p.u_kvlen;
+    }
+    if (qt * 32 >= ql || kl <= 0) return;
+    const int D = p.D;
+    const int qrow = qt * 32 + l31;
+    const bool qok = qrow < ql;
+    const float* __restrict__ qptr =
+        p.Q + (long long)(qs + (qok ? qrow : qt * 32)) * p.ldq + h * D + 4 * half;
+    const int d0 = wave * DT * 32;
+    const float scale = p.scale;
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.0f;
+
+    for (int kv0 = 0; kv0 < kl; kv0 += 32) {
+        const int kvrow = kv0 + l31;
+        const float* __restrict__ kptr =
+            p.K + (long long)(ks + (kvrow < kl ? kvrow : kv0)) * p.ldk + h * D + 4 * half;
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.0f;
+        for (int d8 = 0; d8 < D; d8 += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(kptr + d8);
+            const float4 bq = *reinterpret_cast<const float4*>(qptr + d8);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq.w, s, 0, 0, 0);
+        }
+        // s[e] = S^T[kv0 + (e&3) + 8*(e>>2) + 4*half][q = l31]
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            s[e] = kvr < kl ? s[e] * scale : -INFINITY;
+            mloc = fmaxf(mloc, s[e]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);          // finite: key kv0 is always in range
+        const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
+        float lsum = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[e] = expf(s[e] - m_new);
+            lsum += s[e];
+        }
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+            const float* __restrict__ vcol = p.V + h * D + d0 + t * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                const float v = kvr < kl ? vcol[(long long)(ks + kvr) * p.ldv] : 0.0f;
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[e], o[t], 0, 0, 0);
+            }
+        }
+    }
+    if (!qok) return;
+    const float inv = 1.0f / l_run;
+    float* __restrict__ orow = p.O + (long long)(qs + qrow) * p.ldo + h * D + d0 + 4 * half;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            float4 v;
+            v.x = o[t][4 * e4 + 0] * inv;
+            v.y = o[t][4 * e4 + 1] * inv;
+            v.z = o[t][4 * e4 + 2] * inv;
+            v.w = o[t][4 * e4 + 3] * inv;
+            *reinterpret_cast<float4*>(orow + t * 32 + 8 * e4) = v;
+        }
+}
+
+hipError_t launch_attention(const AttnP& p, hipStream_t s) {
+    if (p.B <= 0 || p.H <= 0 || p.max_qlen <= 0) return hipSuccess;
+    if (p.D % 32 != 0 || (p.ldq & 3) || (p.ldk & 3) || (p.ldo & 3)) return hipErrorInvalidValue;
+    const int tiles = p.D / 32;
+    int nw = (p.D + 127) / 128;
+    while (nw <= 4 && tiles % nw != 0) ++nw;
+    if (nw > 4 || tiles / nw > 4) return hipErrorInvalidValue;
+    const int dt = tiles / nw;
+    dim3 grid((p.max_qlen + 31) / 32, p.H, p.B), block(64 * nw);
+    switch (dt) {
+        case 1: hipLaunchKernelGGL(attn_f32_kernel<1>, grid, block, 0, s, p); break;
+        case 2: hipLaunchKernelGGL(attn_f32_kernel<2>, grid, block, 0, s, p); break;
+        case 3: hipLaunchKernelGGL(attn_f32_kernel<3>, grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL(attn_f32_kernel<4>, grid, block, 0, s, p); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mt2

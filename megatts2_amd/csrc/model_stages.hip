@@ -1,0 +1,650 @@
+// Stage drivers of libmegatts2_hip: they plan row sets on the host, upload the (small) integer plans
+// with one copy per call and enqueue the gfx950 kernels of mt2_kernels.h on the caller's stream.
+// Each driver cites the reference function it replaces; batch semantics are "B independent batch-1
+// runs" (SURVEY.md N1): per-utterance zero gaps for convolutions, per-utterance attention ranges,
+// positional indices restarting at 0.
+#include "mt2_model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace mt2 {
+
+// ---------------------------------------------------------------------------------------------------
+// planning helpers
+
+static RowSet make_rows(const int* lens, int B, int G) {
+    RowSet rs;
+    rs.B = B; rs.G = G;
+    rs.len.assign(lens, lens + B);
+    rs.off.resize(B);
+    int r = G;
+    for (int b = 0; b < B; ++b) {
+        MT2_REQUIRE(lens[b] >= 0, "negative utterance length");
+        rs.off[b] = r;
+        r += lens[b] + G;
+        rs.maxlen = std::max(rs.maxlen, lens[b]);
+    }
+    rs.R = r;
+    return rs;
+}
+
+struct RowPlanOffsets { int valid, start, len; };
+static RowPlanOffsets plan_rows(IntPlan& ip, const RowSet& rs) {
+    std::vector<int> valid(rs.R, 0);
+    for (int b = 0; b < rs.B; ++b) std::fill(valid.begin() + rs.off[b], valid.begin() + rs.off[b] + rs.len[b], 1);
+    RowPlanOffsets o;
+    o.valid = ip.add(valid);
+    o.start = ip.add(rs.off);
+    o.len = ip.add(rs.len);
+    return o;
+}
+static void bind_rows(const IntPlan& ip, const RowPlanOffsets& o, RowSet& rs) {
+    rs.d_valid = ip.dev(o.valid);
+    rs.d_start = ip.dev(o.start);
+    rs.d_len = ip.dev(o.len);
+}
+// rowmap[r] = b * stride + t for real rows, -1 for gap rows (pack / unpack of padded tensors)
+static int plan_rowmap(IntPlan& ip, const RowSet& rs, int stride) {
+    std::vector<int> map(rs.R, -1);
+    for (int b = 0; b < rs.B; ++b)
+        for (int t = 0; t < rs.len[b]; ++t) map[rs.off[b] + t] = b * stride + t;
+    return ip.add(map);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernel-call helpers
+
+struct Ctx {
+    mt2_model& m;
+    hipStream_t s;
+    Arena& ws;
+};
+
+static void gemm(const Ctx& c, GemmP p) {
+    if (p.taps <= 0) p.taps = 1;
+    if (p.dil <= 0) p.dil = 1;
+    if (p.a_mul == 0) p.a_mul = 1;
+    if (p.groups <= 0) p.groups = 1;
+    if (p.out_scale == 0.0f) p.out_scale = 1.0f;
+    p.K = p.taps * p.Cin;
+    if (p.ldw == 0) p.ldw = p.K;
+    MT2_HIP(launch_gemm(p, c.s));
+}
+
+// y[M, N] = x[M, K] @ W^T + b  (F.linear)
+static void linear(const Ctx& c, const float* x, int ldx, int M, const float* W, const float* b, int N, int K,
+                   float* y, int ldy, const float* R = nullptr, int ldr = 0, const int* valid = nullptr,
+                   int epi_act = ACT_NONE) {
+    GemmP p{};
+    p.X = x; p.ldx = ldx; p.Rx = M; p.Cin = K; p.W = W; p.bias = b; p.R = R; p.ldr = ldr; p.valid = valid;
+    p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.epi_act = epi_act;
+    gemm(c, p);
+}
+
+// nn.Conv1d(k, stride 1, padding (k-1)/2 * dil, dilation dil) over gap-padded rows
+static void conv_same(const Ctx& c, const float* x, int ldx, int R, const ConvW& w, float* y, int ldy,
+                      const int* valid, int pro_act = ACT_NONE, float slope = 0.f, int epi_act = ACT_NONE,
+                      const float* Rsd = nullptr, int ldr = 0, int dil = 1) {
+    GemmP p{};
+    p.X = x; p.ldx = ldx; p.Rx = R; p.taps = w.k; p.dil = dil; p.shift0 = -((w.k - 1) / 2) * dil; p.Cin = w.cin;
+    p.W = w.w; p.bias = w.b; p.R = Rsd; p.ldr = ldr; p.valid = valid; p.C = y; p.ldc = ldy; p.M = R; p.N = w.cout;
+    p.pro_act = pro_act; p.pro_slope = slope; p.epi_act = epi_act;
+    gemm(c, p);
+}
+
+static void layernorm(const Ctx& c, const float* x, int ldx, const float* g, const float* b, int M, int C,
+                      float* out, int ldo, const int* valid = nullptr, int valid_rows = 0,
+                      const float* R1 = nullptr, int ldr1 = 0, int r1_rows = 0, int rows_per_group = 0,
+                      int act = ACT_NONE) {
+    LnP p{};
+    p.x = x; p.ldx = ldx; p.gamma = g; p.beta = b; p.rows_per_group = rows_per_group;
+    p.R1 = R1; p.ldr1 = ldr1; p.r1_rows = r1_rows; p.valid = valid; p.valid_rows = valid_rows;
+    p.out = out; p.ldo = ldo; p.M = M; p.C = C; p.eps = 1e-5f; p.act = act;
+    MT2_HIP(launch_layernorm(p, c.s));
+}
+
+// ResidualBlockStack.forward (modules/convnet.py:69-72) for `groups` parallel branches at once:
+// x = x + ConvStack(x), ConvBlock = ReLU -> Conv1d -> LayerNorm(C) (convnet.py:23-31).
+// x_in: [R, C] shared by all groups (shared_in) or [groups][R, C].  Returns [groups][R, C].
+static float* run_stack(const Ctx& c, const StackW& w, const float* x_in, bool shared_in, int R,
+                        const int* valid) {
+    const int C = w.C, G = w.groups;
+    const size_t per = (size_t)R * C;
+    float* T = c.ws.get<float>(per * G);
+    float* Y = c.ws.get<float>(per * G);
+    float* XA = c.ws.get<float>(per * G);
+    float* XB = c.ws.get<float>(per * G);
+    const float* cur = x_in;
+    bool cur_shared = shared_in;
+    float* nxt = XA;
+    const size_t wsz = (size_t)C * w.k * C;
+    for (int st = 0; st < w.nstack; ++st) {
+        const float* bin = cur;
+        bool bin_shared = cur_shared;
+        for (int blk = 0; blk < w.nblock; ++blk) {
+            const size_t e = w.idx(st, blk);
+            GemmP p{};
+            p.X = bin; p.strideX = bin_shared ? 0 : (long long)per; p.ldx = C; p.Rx = R;
+            p.taps = w.k; p.shift0 = -((w.k - 1) / 2); p.Cin = C;
+            p.W = w.w + e * wsz; p.strideW = (long long)wsz;
+            p.bias = w.b + e * C; p.strideB = C;
+            p.valid = valid; p.C = T; p.strideC = (long long)per; p.ldc = C; p.M = R; p.N = C; p.groups = G;
+            p.pro_act = ACT_RELU;
+            gemm(c, p);
+            const bool last = blk == w.nblock - 1;
+            if (last)
+                layernorm(c, T, C, w.g + e * C, w.be + e * C, R * G, C, nxt, C, valid, R, cur, C,
+                          cur_shared ? R : 0, R);
+            else
+                layernorm(c, T, C, w.g + e * C, w.be + e * C, R * G, C, Y, C, valid, R, nullptr, 0, 0, R);
+            bin = Y;
+            bin_shared = false;
+        }
+        cur = nxt;
+        cur_shared = false;
+        nxt = (nxt == XA) ? XB : XA;
+    }
+    return const_cast<float*>(cur);
+}
+
+// TransformerEncoderLayer.forward (modules/transformer.py:88-102) over packed rows, in place on x.
+//   attention geometry: per-utterance (starts/lens arrays) or uniform (AR steps).
+struct AttnGeom {
+    const int* start = nullptr; const int* len = nullptr;
+    int u_stride = 0, u_len = 0, B = 0, max_len = 0;
+};
+struct EncScratch { float *h, *qkv, *att, *f; };
+static EncScratch enc_scratch(const Ctx& c, const EncW& e, int M) {
+    EncScratch s;
+    s.h = c.ws.get<float>((size_t)M * e.d);
+    s.qkv = c.ws.get<float>((size_t)M * 3 * e.d);
+    s.att = c.ws.get<float>((size_t)M * e.d);
+    s.f = c.ws.get<float>((size_t)M * e.ff);
+    return s;
+}
+static void attention_self(const Ctx& c, const EncW& e, const AttnGeom& g, const float* qkv, float* att) {
+    AttnP a{};
+    const int d = e.d, D = d / e.heads;
+    a.Q = qkv; a.ldq = 3 * d; a.K = qkv + d; a.ldk = 3 * d; a.V = qkv + 2 * d; a.ldv = 3 * d;
+    a.O = att; a.ldo = d;
+    a.q_start = g.start; a.q_len = g.len; a.kv_start = g.start; a.kv_len = g.len;
+    a.u_qstride = g.u_stride; a.u_qlen = g.u_len; a.u_kvstride = g.u_stride; a.u_kvlen = g.u_len;
+    a.B = g.B; a.H = e.heads; a.D = D; a.max_qlen = g.max_len; a.scale = 1.0f / std::sqrt((float)D);
+    MT2_HIP(launch_attention(a, c.s));
+}
+static void encoder_layer(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int M, const AttnGeom& g,
+                          const int* valid, const EncScratch& s) {
+    const int d = e.d;
+    layernorm(c, x, d, w.ln1g, w.ln1b, M, d, s.h, d, valid);
+    linear(c, s.h, d, M, w.wqkv, w.bqkv, 3 * d, d, s.qkv, 3 * d);
+    attention_self(c, e, g, s.qkv, s.att);
+    linear(c, s.att, d, M, w.wo, w.bo, d, d, x, d, x, d, valid);            // x = x + out_proj(att)
+    if (e.conv_ff) {
+        // x = norm2(x); x = x + conv2(relu(conv1(x)))   (transformer.py:95-99; residual from the NORMED x)
+        layernorm(c, x, d, w.ln2g, w.ln2b, M, d, s.h, d, valid);
+        ConvW c1{w.ff0w, w.ff0b, e.ff, d, 5}, c2{w.ff1w, w.ff1b, d, e.ff, 5};
+        conv_same(c, s.h, d, M, c1, s.f, e.ff, valid, ACT_NONE, 0.f, ACT_RELU);
+        conv_same(c, s.f, e.ff, M, c2, x, d, valid, ACT_NONE, 0.f, ACT_NONE, s.h, d);
+    } else {
+        layernorm(c, x, d, w.ln2g, w.ln2b, M, d, s.h, d, valid);
+        linear(c, s.h, d, M, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, nullptr, 0, nullptr, ACT_RELU);
+        linear(c, s.f, e.ff, M, w.ff1w, w.ff1b, d, e.ff, x, d, x, d, valid);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage timers (HIP events on the caller's stream)
+
+struct Stages {
+    mt2_model& m;
+    hipStream_t s;
+    std::vector<hipEvent_t> ev;
+    std::vector<std::string> names;
+    explicit Stages(mt2_model& mm, hipStream_t ss) : m(mm), s(ss) {}
+    void mark(const char* name) {
+        if (!m.profiling) return;
+        hipEvent_t e;
+        MT2_HIP(hipEventCreate(&e));
+        MT2_HIP(hipEventRecord(e, s));
+        ev.push_back(e);
+        names.push_back(name);
+    }
+    void finish() {
+        if (!m.profiling || ev.empty()) return;
+        MT2_HIP(hipEventSynchronize(ev.back()));
+        m.stage_names.clear();
+        m.stage_ms.clear();
+        for (size_t i = 1; i < ev.size(); ++i) {
+            float ms = 0.f;
+            MT2_HIP(hipEventElapsedTime(&ms, ev[i - 1], ev[i]));
+            m.stage_names.push_back(names[i]);
+            m.stage_ms.push_back(ms);
+        }
+        for (auto e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// ConvNetDouble (modules/convnet.py:156-210): first conv, N parallel branches (stack1 -> middle ->
+// stack2) summed, last conv.  `middle` turns [G][Rin, C] into [G][Rout, C].
+
+// MRTE mel encoder: middle = ONE shared Conv1d(C, C, stride+1, stride, pad stride/2) (mrte.py:101-107)
+static float* mel_context_rows(const Ctx& c, const float* xmel, int ld_mel, RowSet& F, RowSet& X,
+                               const int* d_rowbase) {
+    mt2_model& m = c.m;
+    const int C = m.cfg.mrte_hidden, G = m.mel_s1.groups;
+    float* h0 = c.ws.get<float>((size_t)F.R * C);
+    {
+        GemmP p{};
+        p.X = xmel; p.ldx = ld_mel; p.Rx = F.R; p.taps = m.mel_first.k; p.shift0 = -((m.mel_first.k - 1) / 2);
+        p.Cin = m.mel_first.cin; p.W = m.mel_first.w; p.bias = m.mel_first.b; p.valid = F.d_valid;
+        p.C = h0; p.ldc = C; p.M = F.R; p.N = C;
+        gemm(c, p);
+    }
+    float* s1 = run_stack(c, m.mel_s1, h0, true, F.R, F.d_valid);
+    float* mid = c.ws.get<float>((size_t)G * X.R * C);
+    {
+        GemmP p{};
+        p.X = s1; p.strideX = (long long)F.R * C; p.ldx = C; p.Rx = F.R; p.rowbase = d_rowbase;
+        p.taps = m.mel_mid.k; p.Cin = C; p.W = m.mel_mid.w; p.strideW = 0; p.bias = m.mel_mid.b; p.strideB = 0;
+        p.valid = X.d_valid; p.C = mid; p.strideC = (long long)X.R * C; p.ldc = C; p.M = X.R; p.N = C; p.groups = G;
+        gemm(c, p);
+    }
+    float* s2 = run_stack(c, m.mel_s2, mid, false, X.R, X.d_valid);
+    float* sum = c.ws.get<float>((size_t)X.R * C);
+    MT2_HIP(launch_sum_groups(s2, (long long)X.R * C, G, C, sum, C, C, X.R, c.s));
+    float* ctx = c.ws.get<float>((size_t)X.R * C);
+    conv_same(c, sum, C, X.R, m.mel_last, ctx, C, X.d_valid);
+    return ctx;
+}
+
+struct MelPlan {
+    RowSet F, X;
+    int o_rowmapF, o_rowbase, o_rowmapX;
+    RowPlanOffsets oF, oX;
+};
+static MelPlan plan_mel(IntPlan& ip, const mt2_config& cfg, const int* mel_lens, int B, int Tp_max, int Tc_max) {
+    MelPlan mp;
+    const int s = cfg.mrte_stride;
+    mp.F = make_rows(mel_lens, B, std::max(s / 2, 2));
+    std::vector<int> xl(B);
+    for (int b = 0; b < B; ++b) {
+        MT2_REQUIRE(mel_lens[b] >= 1 && mel_lens[b] <= Tp_max, "prompt mel length out of range");
+        xl[b] = (mel_lens[b] - 1) / s + 1;      // Conv1d(k = s+1, stride s, pad s/2) output length
+    }
+    mp.X = make_rows(xl.data(), B, 2);
+    mp.oF = plan_rows(ip, mp.F);
+    mp.oX = plan_rows(ip, mp.X);
+    mp.o_rowmapF = plan_rowmap(ip, mp.F, Tp_max);
+    mp.o_rowmapX = plan_rowmap(ip, mp.X, Tc_max > 0 ? Tc_max : 1);
+    std::vector<int> base(mp.X.R, kInvalidRow);
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < xl[b]; ++j) base[mp.X.off[b] + j] = mp.F.off[b] + j * s - s / 2;
+    mp.o_rowbase = ip.add(base);
+    return mp;
+}
+
+// MRTE.tc_latent (modules/mrte.py:154-171) -> packed rows [P.R, hidden] (gap rows zero)
+struct TcResult { float* rows; RowSet P; };
+static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* phone_lens, int Np_max,
+                               const float* mel, const int* mel_lens, int Tp_max, int B) {
+    mt2_model& m = c.m;
+    const mt2_config& cfg = m.cfg;
+    const int H = cfg.mrte_hidden;
+    IntPlan ip;
+    MelPlan mp = plan_mel(ip, cfg, mel_lens, B, Tp_max, 0);
+    RowSet P = make_rows(phone_lens, B, 2);
+    MT2_REQUIRE(P.maxlen <= cfg.max_positions, "phone sequence longer than the positional table");
+    RowPlanOffsets oP = plan_rows(ip, P);
+    const int o_idmap = plan_rowmap(ip, P, Np_max);
+    std::vector<int> pos(P.R, 0);
+    for (int b = 0; b < B; ++b) {
+        MT2_REQUIRE(phone_lens[b] >= 1 && phone_lens[b] <= Np_max, "phone length out of range");
+        for (int t = 0; t < P.len[b]; ++t) pos[P.off[b] + t] = t;
+    }
+    const int o_pos = ip.add(pos);
+    ip.upload(c.ws, c.s);
+    bind_rows(ip, mp.oF, mp.F);
+    bind_rows(ip, mp.oX, mp.X);
+    bind_rows(ip, oP, P);
+
+    // prompt mel -> rows, mel encoder
+    float* xmel = c.ws.get<float>((size_t)mp.F.R * cfg.mel_bins);
+    MT2_HIP(launch_pack_rows(mel, cfg.mel_bins, Tp_max, 0, ip.dev(mp.o_rowmapF), xmel, cfg.mel_bins, mp.F.R, c.s));
+    float* ctx = mel_context_rows(c, xmel, cfg.mel_bins, mp.F, mp.X, ip.dev(mp.o_rowbase));
+
+    // phone embedding + PE, conv-FF transformer (mrte.py:159-160,165)
+    float* x = c.ws.get<float>((size_t)P.R * H);
+    MT2_HIP(launch_embed_pe(m.phone_emb, H, phone, ip.dev(o_idmap), ip.dev(o_pos), m.pe_mrte, x, H, P.R, c.s));
+    EncScratch sc = enc_scratch(c, m.phone_enc, P.R);
+    AttnGeom g;
+    g.start = P.d_start; g.len = P.d_len; g.B = B; g.max_len = P.maxlen;
+    for (auto& lw : m.phone_enc.layers) encoder_layer(c, m.phone_enc, lw, x, P.R, g, P.d_valid, sc);
+
+    // cross attention, ONE head of width H (mrte.py:131-135,167), LayerNorm, ReLU (:168-169)
+    float* q = sc.h;
+    linear(c, x, H, P.R, m.x_wq, m.x_bq, H, H, q, H);
+    float* kv = c.ws.get<float>((size_t)mp.X.R * 2 * H);
+    linear(c, ctx, H, mp.X.R, m.x_wkv, m.x_bkv, 2 * H, H, kv, 2 * H);
+    AttnP a{};
+    a.Q = q; a.ldq = H; a.K = kv; a.ldk = 2 * H; a.V = kv + H; a.ldv = 2 * H; a.O = sc.att; a.ldo = H;
+    a.q_start = P.d_start; a.q_len = P.d_len; a.kv_start = mp.X.d_start; a.kv_len = mp.X.d_len;
+    a.B = B; a.H = 1; a.D = H; a.max_qlen = P.maxlen; a.scale = 1.0f / std::sqrt((float)H);
+    MT2_HIP(launch_attention(a, c.s));
+    float* o = c.ws.get<float>((size_t)P.R * H);
+    linear(c, sc.att, H, P.R, m.x_wo, m.x_bo, H, H, o, H);
+    float* tc = c.ws.get<float>((size_t)P.R * H);
+    layernorm(c, o, H, m.x_ng, m.x_nb, P.R, H, tc, H, P.d_valid, 0, nullptr, 0, 0, 0, ACT_RELU);
+    return {tc, P};
+}
+
+// ---------------------------------------------------------------------------------------------------
+// autoregressive models.  Utterances are visited in order of decreasing length so that the sequences
+// still active at step t are always slots [0, A_t); at step t every active sequence has exactly
+// n = t+1 positions, stored compactly as rows j*n + i.  ALL positions are re-encoded every step,
+// non-causally, exactly as the reference does (models/megatts2.py:172-179,264-273) -
+// a KV cache would change the result.
+
+struct ArOrder {
+    std::vector<int> slot_b, len;   // slot j -> utterance, length
+    int nmax = 0;
+};
+static ArOrder ar_order(const int* lens, int B) {
+    ArOrder o;
+    o.slot_b.resize(B);
+    std::iota(o.slot_b.begin(), o.slot_b.end(), 0);
+    std::stable_sort(o.slot_b.begin(), o.slot_b.end(), [&](int a, int b) { return lens[a] > lens[b]; });
+    o.len.resize(B);
+    for (int j = 0; j < B; ++j) o.len[j] = lens[o.slot_b[j]];
+    o.nmax = B ? o.len[0] : 0;
+    return o;
+}
+
+// MegaADM.infer (models/megatts2.py:257-275).  tc: rows buffer (ld), utterance b's first row row0[b].
+static void adm_run(const Ctx& c, const float* tc, int ld_tc, int tc_rows, const std::vector<int>& row0,
+                    const int* lens, int B, int32_t* dur_out, float* flt_out, int dstride) {
+    mt2_model& m = c.m;
+    const mt2_config& cfg = m.cfg;
+    const EncW& e = m.adm_enc;
+    const int d = e.d, Dc = cfg.adm_tc_emb_dim, De = cfg.adm_emb_dim;
+    ArOrder ord = ar_order(lens, B);
+    MT2_REQUIRE(ord.nmax <= cfg.max_positions, "ADM sequence longer than the positional table");
+    IntPlan ip;
+    std::vector<int> tcrow(B);
+    for (int j = 0; j < B; ++j) tcrow[j] = row0[ord.slot_b[j]];
+    const int o_tcrow = ip.add(tcrow), o_len = ip.add(ord.len), o_slot = ip.add(ord.slot_b);
+    ip.upload(c.ws, c.s);
+
+    float* tcemb = c.ws.get<float>((size_t)tc_rows * Dc);
+    linear(c, tc, ld_tc, tc_rows, m.adm_wtc, nullptr, Dc, cfg.adm_tc_dim, tcemb, Dc);   // tc_linear_emb (no bias)
+    const int pstride = ord.nmax + 1;
+    float* p = c.ws.get<float>((size_t)B * pstride);
+    MT2_HIP(hipMemsetAsync(p, 0, sizeof(float) * B * pstride, c.s));                    // p_code starts at 0.0 (:262)
+    const int Mmax = B * ord.nmax;
+    float* x = c.ws.get<float>((size_t)Mmax * d);
+    EncScratch sc = enc_scratch(c, e, Mmax);
+    int A = B;
+    for (int t = 0; t < ord.nmax; ++t) {
+        while (A > 0 && ord.len[A - 1] <= t) --A;
+        const int n = t + 1, M = A * n;
+        MT2_HIP(launch_adm_step_input(tcemb, Dc, ip.dev(o_tcrow), m.adm_wdt, p, pstride, m.pe_adm, x, Dc, De, n, A,
+                                      c.s));
+        AttnGeom g;
+        g.u_stride = n; g.u_len = n; g.B = A; g.max_len = n;
+        for (auto& lw : e.layers) encoder_layer(c, e, lw, x, M, g, nullptr, sc);
+        MT2_HIP(launch_adm_predict(x, d, m.adm_wpred, p, pstride, n, A, c.s));
+    }
+    MT2_HIP(launch_adm_finalize(p, pstride, ip.dev(o_len), ip.dev(o_slot), dur_out, flt_out, dstride, B,
+                                dstride < ord.nmax ? dstride : ord.nmax, c.s));
+}
+
+// MegaPLM.infer (models/megatts2.py:165-181).  cond rows buffer (ld), utterance b's first row row0[b].
+static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector<int>& row0, const int* lens, int B,
+                    int64_t* codes_out, int ostride, float* last_logits, int logit_tmax) {
+    mt2_model& m = c.m;
+    const mt2_config& cfg = m.cfg;
+    const EncW& e = m.plm_enc;
+    const int d = e.d, Dc = cfg.plm_tc_dim, De = cfg.plm_vq_dim, NB = cfg.plm_bins;
+    ArOrder ord = ar_order(lens, B);
+    MT2_REQUIRE(ord.nmax <= cfg.max_positions, "PLM sequence longer than the positional table");
+    IntPlan ip;
+    std::vector<int> crow(B);
+    for (int j = 0; j < B; ++j) crow[j] = row0[ord.slot_b[j]];
+    const int o_crow = ip.add(crow), o_len = ip.add(ord.len), o_slot = ip.add(ord.slot_b);
+    ip.upload(c.ws, c.s);
+
+    const int cstride = ord.nmax + 1;
+    int64_t* codes = c.ws.get<int64_t>((size_t)B * cstride);
+    {
+        std::vector<int64_t> init((size_t)B * cstride, 0);
+        for (int j = 0; j < B; ++j) init[(size_t)j * cstride] = 1024;   // BOS literal, models/megatts2.py:170
+        MT2_HIP(hipMemcpyAsync(codes, init.data(), init.size() * sizeof(int64_t), hipMemcpyHostToDevice, c.s));
+        MT2_HIP(hipStreamSynchronize(c.s));   // `init` is a stack temporary
+    }
+    MT2_REQUIRE(1024 < cfg.plm_bins + 2, "pc_embedding too small for the BOS id 1024");
+    const int Mmax = B * ord.nmax;
+    float* x = c.ws.get<float>((size_t)Mmax * d);
+    float* logits = c.ws.get<float>((size_t)B * NB);
+    EncScratch sc = enc_scratch(c, e, Mmax);
+    int A = B;
+    for (int t = 0; t < ord.nmax; ++t) {
+        while (A > 0 && ord.len[A - 1] <= t) --A;
+        const int n = t + 1, M = A * n;
+        MT2_HIP(launch_plm_step_input(cond, ld_c, ip.dev(o_crow), m.plm_emb, codes, cstride, m.pe_plm, x, Dc, De, n,
+                                      A, c.s));
+        AttnGeom g;
+        g.u_stride = n; g.u_len = n; g.B = A; g.max_len = n;
+        for (auto& lw : e.layers) encoder_layer(c, e, lw, x, M, g, nullptr, sc);
+        // predict_layer on the last position of each sequence only (:178 takes [:, -1:]), then argmax
+        GemmP p{};
+        p.X = x; p.ldx = d; p.Rx = M; p.a_mul = n; p.shift0 = n - 1; p.Cin = d; p.W = m.plm_wpred;
+        p.C = logits; p.ldc = NB; p.M = A; p.N = NB;
+        gemm(c, p);
+        MT2_HIP(launch_argmax_rows(logits, NB, NB, codes, cstride, n, A, c.s));
+        if (last_logits)
+            for (int j = 0; j < A; ++j)
+                MT2_HIP(hipMemcpyAsync(last_logits + ((size_t)ord.slot_b[j] * logit_tmax + t) * NB,
+                                       logits + (size_t)j * NB, sizeof(float) * NB, hipMemcpyDeviceToDevice, c.s));
+    }
+    MT2_HIP(launch_plm_finalize(codes, cstride, ip.dev(o_len), ip.dev(o_slot), codes_out, ostride, B,
+                                ostride < ord.nmax ? ostride : ord.nmax, c.s));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// length regulation, PLM conditioning, decoder
+
+struct FramePlan {
+    RowSet D;                 // mel frames, gap 2
+    std::vector<int> tq;      // prosody tokens per utterance
+    std::vector<int> q_row0;  // first cond row of each utterance (compact, no gaps)
+    int Qrows = 0;
+    int o_tcmap, o_codemap, o_first, o_cnt, o_rowmapD;
+    RowPlanOffsets oD;
+};
+// dur: host [B, dstride]; tc rows of utterance b start at tc_row0[b]; codes are addressed as b*code_stride + q
+static FramePlan plan_frames(IntPlan& ip, const int* dur, int dstride, const int* lens, int B,
+                             const std::vector<int>& tc_row0, int pool, int code_stride, int out_stride) {
+    FramePlan fp;
+    std::vector<int> tm(B);
+    for (int b = 0; b < B; ++b) {
+        long long s = 0;
+        for (int i = 0; i < lens[b]; ++i) {
+            MT2_REQUIRE(dur[(size_t)b * dstride + i] >= 0, "negative duration");
+            s += dur[(size_t)b * dstride + i];
+        }
+        MT2_REQUIRE(s < (1 << 24), "utterance too long");
+        tm[b] = (int)s;
+    }
+    fp.D = make_rows(tm.data(), B, 2);
+    fp.oD = plan_rows(ip, fp.D);
+    fp.o_rowmapD = plan_rowmap(ip, fp.D, out_stride > 0 ? out_stride : 1);
+    std::vector<int> tcmap(fp.D.R, -1), codemap(fp.D.R, -1);
+    fp.tq.resize(B);
+    fp.q_row0.resize(B);
+    int qr = 0;
+    for (int b = 0; b < B; ++b) {
+        int f = 0;
+        for (int i = 0; i < lens[b]; ++i)                       // create_alignment, mrte.py:23-31
+            for (int k = 0; k < dur[(size_t)b * dstride + i]; ++k, ++f) {
+                tcmap[fp.D.off[b] + f] = tc_row0[b] + i;
+                codemap[fp.D.off[b] + f] = b * code_stride + f / pool;
+            }
+        fp.tq[b] = (tm[b] + pool - 1) / pool;
+        fp.q_row0[b] = qr;
+        qr += fp.tq[b];
+    }
+    fp.Qrows = qr;
+    std::vector<int> first(qr > 0 ? qr : 1, 0), cnt(qr > 0 ? qr : 1, 0);
+    for (int b = 0; b < B; ++b)
+        for (int q = 0; q < fp.tq[b]; ++q) {
+            first[fp.q_row0[b] + q] = fp.D.off[b] + q * pool;
+            cnt[fp.q_row0[b] + q] = std::min(pool, tm[b] - q * pool);    // ceil_mode: partial last window
+        }
+    fp.o_tcmap = ip.add(tcmap);
+    fp.o_codemap = ip.add(codemap);
+    fp.o_first = ip.add(first);
+    fp.o_cnt = ip.add(cnt);
+    return fp;
+}
+
+// ConvNet.forward (modules/convnet.py:115-119) on rows xdec [D.R, decoder_in] -> mel rows [D.R, mel_bins]
+static float* decoder_rows(const Ctx& c, const float* xdec, const RowSet& D) {
+    mt2_model& m = c.m;
+    const int H = m.cfg.dec_hidden, DIN = m.dec_first.cin;
+    float* h0 = c.ws.get<float>((size_t)D.R * H);
+    conv_same(c, xdec, DIN, D.R, m.dec_first, h0, H, D.d_valid);
+    float* s = run_stack(c, m.dec_stack, h0, true, D.R, D.d_valid);
+    float* mel = c.ws.get<float>((size_t)D.R * m.cfg.mel_bins);
+    conv_same(c, s, H, D.R, m.dec_last, mel, m.cfg.mel_bins, D.d_valid);
+    return mel;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// VQ prosody encoder (modules/vqpe.py:50-62)
+
+struct VqpeResult { float* ze; int64_t* idx; RowSet F, Q; int o_rowmapQ, o_rowmapF, o_codemapF; };
+static VqpeResult vqpe_rows(const Ctx& c, IntPlan& ip, const float* mel, int mel_ld, const int* lens, int T_max,
+                            int Tq_max, int B) {
+    mt2_model& m = c.m;
+    const mt2_config& cfg = m.cfg;
+    const int C = cfg.vq_hidden, G = m.vq_s1.groups, st = cfg.vq_stride, Dq = cfg.vq_dim;
+    VqpeResult r;
+    r.F = make_rows(lens, B, 2);
+    std::vector<int> ql(B);
+    for (int b = 0; b < B; ++b) {
+        MT2_REQUIRE(lens[b] >= 1 && lens[b] <= T_max, "mel length out of range");
+        ql[b] = (lens[b] + st - 1) / st;
+    }
+    r.Q = make_rows(ql.data(), B, 2);
+    RowPlanOffsets oF = plan_rows(ip, r.F), oQ = plan_rows(ip, r.Q);
+    r.o_rowmapF = plan_rowmap(ip, r.F, T_max);
+    r.o_rowmapQ = plan_rowmap(ip, r.Q, Tq_max);
+    std::vector<int> first(r.Q.R, 0), cnt(r.Q.R, 0), codemap(r.F.R, -1);
+    for (int b = 0; b < B; ++b) {
+        for (int q = 0; q < ql[b]; ++q) {
+            first[r.Q.off[b] + q] = r.F.off[b] + q * st;
+            cnt[r.Q.off[b] + q] = std::min(st, lens[b] - q * st);
+        }
+        for (int t = 0; t < lens[b]; ++t) codemap[r.F.off[b] + t] = r.Q.off[b] + t / st;
+    }
+    const int o_first = ip.add(first), o_cnt = ip.add(cnt);
+    r.o_codemapF = ip.add(codemap);
+    ip.upload(c.ws, c.s);
+    bind_rows(ip, oF, r.F);
+    bind_rows(ip, oQ, r.Q);
+
+    float* xmel = c.ws.get<float>((size_t)r.F.R * mel_ld);
+    MT2_HIP(launch_pack_rows(mel, mel_ld, T_max, 0, ip.dev(r.o_rowmapF), xmel, mel_ld, r.F.R, c.s));
+    float* h0 = c.ws.get<float>((size_t)r.F.R * C);
+    {   // first_layer reads only the first vq_mel_bins columns (vqpe.py:55)
+        GemmP p{};
+        p.X = xmel; p.ldx = mel_ld; p.Rx = r.F.R; p.taps = m.vq_first.k; p.shift0 = -((m.vq_first.k - 1) / 2);
+        p.Cin = m.vq_first.cin; p.W = m.vq_first.w; p.bias = m.vq_first.b; p.valid = r.F.d_valid;
+        p.C = h0; p.ldc = C; p.M = r.F.R; p.N = C;
+        gemm(c, p);
+    }
+    float* s1 = run_stack(c, m.vq_s1, h0, true, r.F.R, r.F.d_valid);
+    float* mid = c.ws.get<float>((size_t)G * r.Q.R * C);     // MaxPool1d(stride, ceil_mode=True), vqpe.py:38
+    for (int g = 0; g < G; ++g)
+        MT2_HIP(launch_pool_max(s1 + (size_t)g * r.F.R * C, C, ip.dev(o_first), ip.dev(o_cnt),
+                                mid + (size_t)g * r.Q.R * C, C, C, r.Q.R, c.s));
+    float* s2 = run_stack(c, m.vq_s2, mid, false, r.Q.R, r.Q.d_valid);
+    float* sum = c.ws.get<float>((size_t)r.Q.R * C);
+    MT2_HIP(launch_sum_groups(s2, (long long)r.Q.R * C, G, C, sum, C, C, r.Q.R, c.s));
+    r.ze = c.ws.get<float>((size_t)r.Q.R * Dq);
+    conv_same(c, sum, C, r.Q.R, m.vq_last, r.ze, Dq, r.Q.d_valid);
+    // EuclideanCodebook.quantize: distance GEMM + ordered argmax
+    float* xe = c.ws.get<float>((size_t)r.Q.R * cfg.vq_bins);
+    linear(c, r.ze, Dq, r.Q.R, m.codebook, nullptr, cfg.vq_bins, Dq, xe, cfg.vq_bins);
+    r.idx = c.ws.get<int64_t>(r.Q.R);
+    MT2_HIP(launch_vq_argmin(r.ze, Dq, Dq, xe, cfg.vq_bins, m.codebook_sq, cfg.vq_bins, r.Q.d_valid, r.idx, r.Q.R,
+                             c.s));
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// HiFi-GAN V1 generator on mel rows [M0.R, in_dim] (gap 4) -> waveform rows [M0.R * hop] (1 channel, tanh'ed)
+
+static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
+    mt2_model& m = c.m;
+    const mt2_config& cfg = m.cfg;
+    const float slope = cfg.hg_slope;
+    long long R = M0.R;
+    int ch = cfg.hg_init_channels;
+    float* x = c.ws.get<float>((size_t)R * ch);
+    conv_same(c, xmel, cfg.hg_in_dim, (int)R, m.hg_pre, x, ch, M0.d_valid);
+    const int* valid = M0.d_valid;
+    for (int i = 0; i < cfg.hg_n_up; ++i) {
+        const UpW& u = m.hg_up[i];
+        const int s = u.stride, co = u.cout, hs = s / 2;
+        MT2_REQUIRE(R * s < (1ll << 31), "waveform row count exceeds int32");
+        // ConvTranspose1d as two phase GEMMs over the input rows; output [R, s*co] IS [R*s, co] time-major
+        float* up = c.ws.get<float>((size_t)R * s * co);
+        for (int half = 0; half < 2; ++half) {
+            GemmP p{};
+            p.X = x; p.ldx = ch; p.Rx = (int)R; p.taps = 2; p.shift0 = half == 0 ? -1 : 0; p.Cin = ch;
+            p.W = half == 0 ? u.wlo : u.whi; p.bias = u.bias; p.valid = valid;
+            p.C = up + (half == 0 ? 0 : hs * co); p.ldc = s * co; p.M = (int)R; p.N = hs * co;
+            p.pro_act = ACT_LRELU; p.pro_slope = slope;
+            gemm(c, p);
+        }
+        int* v2 = c.ws.get<int>((size_t)R * s);
+        MT2_HIP(launch_expand_mask(valid, s, v2, R * s, c.s));
+        valid = v2;
+        R *= s;
+        ch = co;
+        // multi-receptive-field fusion: mean of the resblocks (ResBlock1: x += conv2(lrelu(conv1(lrelu(x)))) x3)
+        const size_t per = (size_t)R * ch;
+        float* t1 = c.ws.get<float>(per);
+        float* ha = c.ws.get<float>(per);
+        float* hb = c.ws.get<float>(per);
+        float* rb[3] = {nullptr, nullptr, nullptr};
+        MT2_REQUIRE(cfg.hg_n_res == 3, "HiFi-GAN V1 uses three resblocks per stage");
+        for (int j = 0; j < 3; ++j) {
+            const ResW& r = m.hg_res[i * 3 + j];
+            rb[j] = c.ws.get<float>(per);
+            const float* h = up;
+            for (int n = 0; n < 3; ++n) {
+                float* out = n == 2 ? rb[j] : (n == 0 ? ha : hb);
+                conv_same(c, h, ch, (int)R, r.c1[n], t1, ch, valid, ACT_LRELU, slope, ACT_NONE, nullptr, 0, r.dil[n]);
+                conv_same(c, t1, ch, (int)R, r.c2[n], out, ch, valid, ACT_LRELU, slope, ACT_NONE, h, ch, 1);
+                h = out;
+            }
+        }
+        x = c.ws.get<float>(per);
+        MT2_HIP(launch_avg3(rb[0], rb[1], rb[2], 1.0f / 3.0f, x, (long long)per, c.s));
+    }
+    // F.leaky_relu default slope 0.01, conv_post k7, tanh
+    float* wav = c.ws.get<float>((size_t)R);
+    conv_same(c, x, ch, (int)R, m.hg_post, wav, 1, valid, ACT_LRELU, 0.01f, ACT_TANH);
+    return wav;
+}
+
+}  // namespace mt2
+
+// the C ABI lives in capi.hip and includes this translation unit's helpers
+#include "capi.inc"

@@ -1,0 +1,126 @@
+// Internal kernel-launcher interface of libmegatts2_hip (gfx950 only).
+//
+// Every activation lives in HBM as a time-major row matrix [rows, channels] (f32, channels
+// contiguous).  A batch of utterances is a *row set*: utterance b owns rows [off_b, off_b+len_b),
+// separated from its neighbours by >= G all-zero "gap" rows.  Conv taps that reach over an
+// utterance edge therefore read zeros - exactly the per-utterance zero padding the reference's
+// batch-1 convolutions see - and every kernel re-zeroes gap rows in its epilogue
+// through the `valid` row mask.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mt2 {
+
+constexpr int kInvalidRow = -(1 << 30);   // rowbase sentinel: "this A row is all zeros"
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
+
+// C[g][m, n] = epi( sum_{tap, c} pro(X[g][src(m) + tap*dil, c]) * W[g][n, tap*Cin + c] )
+//   src(m)  = rowbase ? rowbase[m] : m * a_mul + shift0           (rows outside [0, Rx) read as 0)
+//   epi(v)  = mask_m * ( act(v + bias[n]) * out_scale + R[g][m, n] )
+// Linear layers: taps = 1.  Conv1d(k, dilation d, "same" padding): taps = k, shift0 = -(k-1)/2*d.
+// Strided conv / gathers: rowbase.  Groups (blockIdx.z) batch independent problems of one shape
+// (the parallel branches of ConvNetDouble) - a stride of 0 shares the operand between groups.
+struct GemmP {
+    const float* X; long long strideX; int ldx; int Rx;
+    const int* rowbase; int a_mul; int shift0; int taps; int dil; int Cin;
+    const float* W; long long strideW; int ldw;
+    const float* bias; long long strideB;
+    const float* R; long long strideR; int ldr;
+    const int* valid;
+    float* C; long long strideC; int ldc;
+    int M, N, K, groups;
+    int pro_act; float pro_slope; int epi_act; float out_scale;
+};
+hipError_t launch_gemm(const GemmP& p, hipStream_t s);
+const char* gemm_last_config();     // name of the tile configuration the last launch used
+
+// Row LayerNorm over C channels (biased variance, eps inside the sqrt), one wave per row:
+//   out[m, :] = mask_m * ( act( LN(x[m, :]) * gamma[g] + beta[g] ) + R1[m, :] + R2[m, :] )
+// rows_per_group > 0: gamma/beta of group g = m / rows_per_group start at g * C.
+// valid_rows > 0: the mask index is m % valid_rows (one mask shared by all groups);
+// r1_rows > 0: the R1 row is m % r1_rows (one residual input shared by all groups).
+struct LnP {
+    const float* x; int ldx;
+    const float* gamma; const float* beta; int rows_per_group;
+    const float* R1; int ldr1; int r1_rows; const float* R2; int ldr2;
+    const int* valid; int valid_rows;
+    float* out; int ldo;
+    int M, C; float eps; int act;
+};
+hipError_t launch_layernorm(const LnP& p, hipStream_t s);
+
+// Non-causal multi-head attention over per-utterance row ranges (flash-style, f32 MFMA).
+//   Q rows of utterance b: [q_start[b], q_start[b]+q_len[b]) in Q (ld ldq), head h at column h*D.
+//   K/V likewise with kv_start/kv_len.  If q_start == nullptr the batch is uniform:
+//   start = b * u_qstride (q) / b * u_kvstride (kv), len = u_qlen / u_kvlen.
+struct AttnP {
+    const float* Q; int ldq; const float* K; int ldk; const float* V; int ldv;
+    float* O; int ldo;
+    const int* q_start; const int* q_len; const int* kv_start; const int* kv_len;
+    int u_qstride, u_qlen, u_kvstride, u_kvlen;
+    int B, H, D, max_qlen; float scale;
+};
+hipError_t launch_attention(const AttnP& p, hipStream_t s);
+
+// ---- row utilities (rowops.hip) ------------------------------------------------------------------
+// out[r, :] = table[ids[idmap[r]], :] + pe[pos[r], :]   (idmap[r] < 0 -> zero row)
+hipError_t launch_embed_pe(const float* table, int C, const int64_t* ids, const int* idmap, const int* pos,
+                           const float* pe, float* out, int ldo, int R, hipStream_t s);
+// out[r, 0:C] = src[map[r], 0:C] (map[r] < 0 -> zeros);  generic row gather
+hipError_t launch_gather_rows(const float* src, int lds_, const int* map, float* out, int ldo, int C, int R,
+                              hipStream_t s);
+// out[r, :] = max_{i < cnt[r]} src[first[r] + i, 0:C]   (cnt[r] == 0 -> zeros): ceil-mode max-pool
+hipError_t launch_pool_max(const float* src, int lds_, const int* first, const int* cnt, float* out, int ldo,
+                           int C, int R, hipStream_t s);
+// out[r, :] = sum_g x[g*strideG + r*ld + :]
+hipError_t launch_sum_groups(const float* x, long long strideG, int groups, int ld, float* out, int ldo, int C,
+                             int R, hipStream_t s);
+// dst[r, c] = (a[r,c] + b[r,c] + d[r,c]) * scale  (HiFi-GAN MRF mean)
+hipError_t launch_avg3(const float* a, const float* b, const float* d, float scale, float* out, long long n,
+                       hipStream_t s);
+// padded [B, Tmax, C] (or channel-major [B, C, Tmax] when cmajor) <-> packed rows; rowmap[r] = b*Tmax + t or -1
+hipError_t launch_pack_rows(const float* src, int C, int Tmax, int cmajor, const int* rowmap, float* dst, int ldd,
+                            int R, hipStream_t s);
+hipError_t launch_unpack_rows(const float* src, int lds_, int C, int Tmax, int cmajor, const int* rowmap,
+                              float* dst, int R, hipStream_t s);
+// AR step input rows (models/megatts2.py:172-176,264-269): uniform length n = t+1, A active sequences
+//   ADM: x[j*n+i] = [tc_emb[tc_row[j]+i, 0:Dc] , w_dt[0:De] * p[j*pstride + i]] + pe[i]
+hipError_t launch_adm_step_input(const float* tc_emb, int ld_tc, const int* tc_row, const float* w_dt,
+                                 const float* p, int pstride, const float* pe, float* x, int Dc, int De,
+                                 int n, int A, hipStream_t s);
+//   PLM: x[j*n+i] = [cond[cond_row[j]+i, 0:Dc], emb[codes[j*cstride+i], 0:De]] + pe[i]
+hipError_t launch_plm_step_input(const float* cond, int ld_c, const int* cond_row, const float* emb,
+                                 const int64_t* codes, int cstride, const float* pe, float* x, int Dc, int De,
+                                 int n, int A, hipStream_t s);
+// ADM head: p[j*pstride + n] = dot(x[j*n + n-1, 0:D], w)      (predict_layer, last position only)
+hipError_t launch_adm_predict(const float* x, int D, const float* w, float* p, int pstride, int n, int A,
+                              hipStream_t s);
+// dur[i] = clamp(trunc(p + 0.5), 1, 128)  (models/megatts2.py:275)
+hipError_t launch_adm_finalize(const float* p, int pstride, const int* lens, const int* slot_b, int32_t* dur,
+                               float* flt, int dstride, int A, int nmax, hipStream_t s);
+hipError_t launch_plm_finalize(const int64_t* codes, int cstride, const int* lens, const int* slot_b, int64_t* out,
+                               int ostride, int A, int nmax, hipStream_t s);
+hipError_t launch_scatter_i64(const int64_t* src, const int* map, int64_t* out, int R, hipStream_t s);
+hipError_t launch_expand_mask(const int* in, int factor, int* out, long long n, hipStream_t s);
+hipError_t launch_unpack_wav(const float* src, const long long* start, const long long* len, float* out,
+                             long long out_stride, long long max_len, int B, hipStream_t s);
+// row arg-max with lowest-index ties (torch.argmax): out[j*ostride + ooff] = argmax_n x[j, 0:N]
+hipError_t launch_argmax_rows(const float* x, int ldx, int N, int64_t* out, int ostride, int ooff, int A,
+                              hipStream_t s);
+// EuclideanCodebook.quantize (core_vq.py:175-183) given xe = x @ E^T:
+//   idx[m] = argmax_j -((|x_m|^2 - 2*xe[m,j]) + ee[j]), lowest index on ties
+hipError_t launch_vq_argmin(const float* x, int ldx, int D, const float* xe, int ldxe, const float* ee, int N,
+                            const int* valid, int64_t* idx, int M, hipStream_t s);
+// ee[j] = sum_d E[j,d]^2
+hipError_t launch_row_sqnorm(const float* E, int D, float* ee, int N, hipStream_t s);
+// decoder input (models/megatts2.py:361-366): out[r] = [tc[tcmap[r]], E[codes[codemap[r]]]]
+hipError_t launch_decoder_input(const float* tc, int ld_tc, const int* tcmap, const float* E, const int64_t* codes,
+                                const int* codemap, float* out, int Dc, int Dq, int R, hipStream_t s);
+// zq rows (modules/vqpe.py:59-61): out[r] = E[codes[codemap[r]]]
+hipError_t launch_codebook_rows(const float* E, const int64_t* codes, const int* codemap, float* out, int ldo,
+                                int Dq, int R, hipStream_t s);
+hipError_t launch_tanh_col(const float* x, int ldx, float* out, long long n, hipStream_t s);
+
+}  // namespace mt2

@@ -1,0 +1,130 @@
+// Host-side model object of libmegatts2_hip: weight store (GEMM-ready layouts in HBM), activation
+// workspace, row-set planning and the stage drivers that enqueue kernels on the caller's stream.
+#pragma once
+#include "../../include/megatts2_hip.h"
+#include "mt2_kernels.h"
+
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mt2 {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+void check_hip(hipError_t e, const char* what, const char* file, int line);
+#define MT2_HIP(x) ::mt2::check_hip((x), #x, __FILE__, __LINE__)
+#define MT2_REQUIRE(cond, msg)                                                                   \
+    do {                                                                                         \
+        if (!(cond)) throw ::mt2::Error(std::string(msg) + " [" #cond "] at " __FILE__ ":" +     \
+                                        std::to_string(__LINE__));                               \
+    } while (0)
+
+// Bump allocator over hipMalloc'd chunks; reset() at the start of every API call.  Chunks persist, so
+// after the first call of a given shape no allocation happens on the hot path.
+class Arena {
+  public:
+    ~Arena();
+    void reset();
+    void* alloc(size_t bytes);
+    template <class T> T* get(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
+    size_t capacity() const;
+
+  private:
+    struct Chunk { char* p; size_t size, used; };
+    std::vector<Chunk> chunks_;
+};
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+// A batch of per-utterance row ranges with >= G zero gap rows around each (mt2_kernels.h header).
+struct RowSet {
+    int B = 0, G = 0, R = 0, maxlen = 0;
+    std::vector<int> len, off;
+    const int* d_valid = nullptr;   // [R] 1 = real row
+    const int* d_start = nullptr;   // [B]
+    const int* d_len = nullptr;     // [B]
+};
+
+// all small integer arrays of one API call, uploaded with ONE H2D copy
+class IntPlan {
+  public:
+    int add(const std::vector<int>& v);
+    int add_fill(size_t n, int value);
+    std::vector<int>& host() { return h_; }
+    void upload(Arena& a, hipStream_t s);
+    const int* dev(int offset) const { return d_ + offset; }
+
+  private:
+    std::vector<int> h_;
+    int* d_ = nullptr;
+};
+
+struct ConvW { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, k = 0; };
+// grouped residual stack: entry (s, blk) holds `groups` consecutive [C, k*C] matrices
+struct StackW {
+    float *w = nullptr, *b = nullptr, *g = nullptr, *be = nullptr;
+    int C = 0, k = 0, nstack = 0, nblock = 0, groups = 0;
+    size_t idx(int s, int blk) const { return (size_t)(s * nblock + blk) * groups; }
+};
+struct EncLayerW {
+    float *ln1g, *ln1b, *ln2g, *ln2b, *wqkv, *bqkv, *wo, *bo, *ff0w, *ff0b, *ff1w, *ff1b;
+};
+struct EncW {
+    std::vector<EncLayerW> layers;
+    int d = 0, ff = 0, heads = 0;
+    bool conv_ff = false;
+};
+struct UpW { float *wlo, *whi, *bias; int cin, cout, stride; };
+struct ResW { ConvW c1[3], c2[3]; int k; int dil[3]; };
+
+struct StageTimer {
+    std::vector<std::string> names;
+    std::vector<hipEvent_t> ev;
+};
+
+}  // namespace mt2
+
+struct mt2_model {
+    mt2_config cfg{};
+    bool finalized = false;
+    bool has_g = false, has_adm = false, has_plm = false;
+    std::map<std::string, mt2::HostTensor> host;
+    std::vector<void*> dev_allocs;
+    size_t weight_bytes = 0;
+    mt2::Arena ws;
+
+    // MRTE
+    float *phone_emb = nullptr, *pe_mrte = nullptr;
+    mt2::ConvW mel_first, mel_mid, mel_last;
+    mt2::StackW mel_s1, mel_s2;
+    mt2::EncW phone_enc;
+    float *x_wq, *x_bq, *x_wkv, *x_bkv, *x_wo, *x_bo, *x_ng, *x_nb;
+    // VQ prosody encoder
+    mt2::ConvW vq_first, vq_last;
+    mt2::StackW vq_s1, vq_s2;
+    float *codebook = nullptr, *codebook_sq = nullptr;
+    // decoder
+    mt2::ConvW dec_first, dec_last;
+    mt2::StackW dec_stack;
+    // ADM
+    mt2::EncW adm_enc;
+    float *adm_wdt, *adm_wtc, *adm_wpred, *pe_adm;
+    // PLM
+    mt2::EncW plm_enc;
+    float *plm_emb, *plm_wpred, *pe_plm;
+    // HiFi-GAN
+    bool has_vocoder = false;
+    mt2::ConvW hg_pre, hg_post;
+    std::vector<mt2::UpW> hg_up;
+    std::vector<mt2::ResW> hg_res;
+
+    bool profiling = false;
+    std::vector<std::string> stage_names;
+    std::vector<float> stage_ms;
+};

@@ -1,0 +1,593 @@
+// HBM-bound row kernels of the Mega-TTS 2 synthesis path (gfx950): LayerNorm, embedding + positional
+// table, length-regulator gather, ceil-mode max-pool, VQ L2-argmin / decode, AR step assembly and heads.
+// All of them move each byte once with float4 (16 B/lane) coalesced accesses; row reductions use wave64
+// shuffles (one wave per row), never LDS.
+#include "mt2_kernels.h"
+#include <math.h>
+
+namespace mt2 {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float act_rt2(int act, float v) {
+    switch (act) {
+        case ACT_RELU: return fmaxf(v, 0.0f);
+        case ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm: F.layer_norm(x, (C,), gamma, beta, eps=1e-5) at reference modules/convnet.py:29,
+// modules/transformer.py:94-99, modules/mrte.py:168.  Two-pass (mean, then centred variance) in
+// registers: a lane holds up to 4 float4 of its row (C <= 1024).
+__global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= p.M) return;
+    const int C = p.C;
+    float* __restrict__ out = p.out + (long long)m * p.ldo;
+    const int vm = p.valid_rows > 0 ? m % p.valid_rows : m;
+    const bool live = !(p.valid && p.valid[vm] == 0);
+    float4 x[4];
+    float s = 0.0f;
+    if (live) {
+        const float* __restrict__ xr = p.x + (long long)m * p.ldx;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            x[v] = c < C ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (x[v].x + x[v].y) + (x[v].z + x[v].w);
+        }
+    }
+    if (!live) {   // gap row: stays all-zero
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int c = (v * 64 + lane) * 4;
+            if (c < C) *reinterpret_cast<float4*>(out + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const float inv_c = 1.0f / (float)C;
+    const float mean = wave_sum(s) * inv_c;
+    float q = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < C) {
+            x[v].x -= mean; x[v].y -= mean; x[v].z -= mean; x[v].w -= mean;
+            q += (x[v].x * x[v].x + x[v].y * x[v].y) + (x[v].z * x[v].z + x[v].w * x[v].w);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_c + p.eps);
+    const int g = p.rows_per_group > 0 ? m / p.rows_per_group : 0;
+    const float* __restrict__ gam = p.gamma + (long long)g * C;
+    const float* __restrict__ bet = p.beta + (long long)g * C;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < C) {
+            const float4 gv = *reinterpret_cast<const float4*>(gam + c);
+            const float4 bv = *reinterpret_cast<const float4*>(bet + c);
+            float4 y;
+            y.x = act_rt2(p.act, x[v].x * rstd * gv.x + bv.x);
+            y.y = act_rt2(p.act, x[v].y * rstd * gv.y + bv.y);
+            y.z = act_rt2(p.act, x[v].z * rstd * gv.z + bv.z);
+            y.w = act_rt2(p.act, x[v].w * rstd * gv.w + bv.w);
+            if (p.R1) {
+                const int rm = p.r1_rows > 0 ? m % p.r1_rows : m;
+                const float4 r = *reinterpret_cast<const float4*>(p.R1 + (long long)rm * p.ldr1 + c);
+                y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+            }
+            if (p.R2) {
+                const float4 r = *reinterpret_cast<const float4*>(p.R2 + (long long)m * p.ldr2 + c);
+                y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+            }
+            *reinterpret_cast<float4*>(out + c) = y;
+        }
+    }
+}
+
+hipError_t launch_layernorm(const LnP& p, hipStream_t s) {
+    if (p.M <= 0) return hipSuccess;
+    if (p.C > 1024 || (p.C & 3) || (p.ldx & 3) || (p.ldo & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((p.M + 3) / 4), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// generic "one float4 per thread" row kernels: thread -> (row r, column chunk c4)
+
+#define MT2_ROW_LOOP(R_, C_)                                                              \
+    const long long total_ = (long long)(R_) * ((C_) >> 2);                               \
+    for (long long i_ = (long long)blockIdx.x * blockDim.x + threadIdx.x; i_ < total_;    \
+         i_ += (long long)gridDim.x * blockDim.x)
+
+static inline dim3 row_grid(long long work) {
+    long long blocks = (work + 255) / 256;
+    if (blocks > 2048 * 8) blocks = 2048 * 8;
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned)blocks);
+}
+
+// TokenEmbedding + SinePositionalEmbedding (modules/embedding.py:43-47,94-98; mrte.py:159-160)
+__global__ void embed_pe_kernel(const float* table, int C, const int64_t* ids, const int* idmap, const int* pos,
+                                const float* pe, float* out, int ldo, int R) {
+    const int c4n = C >> 2;
+    MT2_ROW_LOOP(R, C) {
+        const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int im = idmap[r];
+        if (im >= 0) {
+            const float4 e = *reinterpret_cast<const float4*>(table + (long long)ids[im] * C + c);
+            const float4 q = *reinterpret_cast<const float4*>(pe + (long long)pos[r] * C + c);
+            v.x = e.x * 1.0f + q.x; v.y = e.y * 1.0f + q.y; v.z = e.z * 1.0f + q.z; v.w = e.w * 1.0f + q.w;
+        }
+        *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = v;
+    }
+}
+hipError_t launch_embed_pe(const float* table, int C, const int64_t* ids, const int* idmap, const int* pos,
+                           const float* pe, float* out, int ldo, int R, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(embed_pe_kernel, row_grid((long long)R * (C >> 2)), dim3(256), 0, s, table, C, ids, idmap,
+                       pos, pe, out, ldo, R);
+    return hipGetLastError();
+}
+
+// LengthRegulator (modules/mrte.py:42-60) as a gather: alignment @ x with a 0/1 alignment matrix is
+// exactly "copy row map[r]" (SURVEY M4), so no matmul and no host round trip.
+__global__ void gather_rows_kernel(const float* src, int lds_, const int* map, float* out, int ldo, int C, int R) {
+    const int c4n = C >> 2;
+    MT2_ROW_LOOP(R, C) {
+        const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
+        const int sr = map[r];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sr >= 0) v = *reinterpret_cast<const float4*>(src + (long long)sr * lds_ + c);
+        *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = v;
+    }
+}
+hipError_t launch_gather_rows(const float* src, int lds_, const int* map, float* out, int ldo, int C, int R,
+                              hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, row_grid((long long)R * (C >> 2)), dim3(256), 0, s, src, lds_, map, out,
+                       ldo, C, R);
+    return hipGetLastError();
+}
+
+// F.max_pool1d(k, stride k, ceil_mode=True) along time (models/megatts2.py:357-358, vqpe.py:38):
+// window r covers source rows [first[r], first[r] + cnt[r]) - the last one of an utterance is partial.
+__global__ void pool_max_kernel(const float* src, int lds_, const int* first, const int* cnt, float* out, int ldo,
+                                int C, int R) {
+    const int c4n = C >> 2;
+    MT2_ROW_LOOP(R, C) {
+        const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
+        const int n = cnt[r];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n > 0) {
+            const float* sp = src + (long long)first[r] * lds_ + c;
+            v = *reinterpret_cast<const float4*>(sp);
+            for (int i = 1; i < n; ++i) {
+                const float4 w = *reinterpret_cast<const float4*>(sp + (long long)i * lds_);
+                v.x = fmaxf(v.x, w.x); v.y = fmaxf(v.y, w.y); v.z = fmaxf(v.z, w.z); v.w = fmaxf(v.w, w.w);
+            }
+        }
+        *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = v;
+    }
+}
+hipError_t launch_pool_max(const float* src, int lds_, const int* first, const int* cnt, float* out, int ldo,
+                           int C, int R, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pool_max_kernel, row_grid((long long)R * (C >> 2)), dim3(256), 0, s, src, lds_, first, cnt,
+                       out, ldo, C, R);
+    return hipGetLastError();
+}
+
+// ConvNetDouble.forward branch sum (modules/convnet.py:205-207), left-to-right like the reference
+__global__ void sum_groups_kernel(const float* x, long long strideG, int groups, int ld, float* out, int ldo,
+                                  int C, int R) {
+    const int c4n = C >> 2;
+    MT2_ROW_LOOP(R, C) {
+        const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
+        const float* xp = x + (long long)r * ld + c;
+        float4 v = *reinterpret_cast<const float4*>(xp);
+        for (int g = 1; g < groups; ++g) {
+            const float4 w = *reinterpret_cast<const float4*>(xp + g * strideG);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = v;
+    }
+}
+hipError_t launch_sum_groups(const float* x, long long strideG, int groups, int ld, float* out, int ldo, int C,
+                             int R, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sum_groups_kernel, row_grid((long long)R * (C >> 2)), dim3(256), 0, s, x, strideG, groups,
+                       ld, out, ldo, C, R);
+    return hipGetLastError();
+}
+
+// HiFi-GAN multi-receptive-field fusion: (rb0 + rb1 + rb2) / 3
+__global__ void avg3_kernel(const float* a, const float* b, const float* d, float scale, float* out, long long n4) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (long long)gridDim.x * blockDim.x) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i];
+        const float4 y = reinterpret_cast<const float4*>(b)[i];
+        const float4 z = reinterpret_cast<const float4*>(d)[i];
+        float4 v;
+        v.x = ((x.x + y.x) + z.x) * scale; v.y = ((x.y + y.y) + z.y) * scale;
+        v.z = ((x.z + y.z) + z.z) * scale; v.w = ((x.w + y.w) + z.w) * scale;
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+hipError_t launch_avg3(const float* a, const float* b, const float* d, float scale, float* out, long long n,
+                       hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(avg3_kernel, row_grid(n >> 2), dim3(256), 0, s, a, b, d, scale, out, n >> 2);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// boundary layout conversion: reference tensors are padded batch-first [B, Tmax, C] (or [B, C, Tmax]
+// for the mel decoder / vocoder, "B D T"); internal rows are packed with gap rows.
+
+__global__ void pack_rows_kernel(const float* src, int C, int Tmax, int cmajor, const int* rowmap, float* dst,
+                                 int ldd, int R) {
+    const long long total = (long long)R * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / C), c = (int)(i % C);
+        const int bt = rowmap[r];
+        float v = 0.0f;
+        if (bt >= 0) {
+            if (cmajor) {
+                const int b = bt / Tmax, t = bt % Tmax;
+                v = src[((long long)b * C + c) * Tmax + t];
+            } else {
+                v = src[(long long)bt * C + c];
+            }
+        }
+        dst[(long long)r * ldd + c] = v;
+    }
+}
+hipError_t launch_pack_rows(const float* src, int C, int Tmax, int cmajor, const int* rowmap, float* dst, int ldd,
+                            int R, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_rows_kernel, row_grid((long long)R * C), dim3(256), 0, s, src, C, Tmax, cmajor, rowmap,
+                       dst, ldd, R);
+    return hipGetLastError();
+}
+
+__global__ void unpack_rows_kernel(const float* src, int lds_, int C, int Tmax, int cmajor, const int* rowmap,
+                                   float* dst, int R) {
+    const long long total = (long long)R * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int r, c;
+        if (cmajor) { c = (int)(i / R); r = (int)(i % R); }   // consecutive threads -> consecutive t
+        else { r = (int)(i / C); c = (int)(i % C); }
+        const int bt = rowmap[r];
+        if (bt < 0) continue;
+        const float v = src[(long long)r * lds_ + c];
+        if (cmajor) {
+            const int b = bt / Tmax, t = bt % Tmax;
+            dst[((long long)b * C + c) * Tmax + t] = v;
+        } else {
+            dst[(long long)bt * C + c] = v;
+        }
+    }
+}
+hipError_t launch_unpack_rows(const float* src, int lds_, int C, int Tmax, int cmajor, const int* rowmap,
+                              float* dst, int R, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(unpack_rows_kernel, row_grid((long long)R * C), dim3(256), 0, s, src, lds_, C, Tmax, cmajor,
+                       rowmap, dst, R);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// autoregressive step assembly (all active sequences have the same length n = t + 1 at step t)
+
+// MegaADM.infer step input (models/megatts2.py:265-269): cat([tc_emb, dt_linear_emb(p)]) + pe
+__global__ void adm_step_input_kernel(const float* tc_emb, int ld_tc, const int* tc_row, const float* w_dt,
+                                      const float* p, int pstride, const float* pe, float* x, int Dc, int De,
+                                      int n, int A) {
+    const int D = Dc + De, c4n = D >> 2;
+    MT2_ROW_LOOP(A * n, D) {
+        const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
+        const int j = r / n, i = r % n;
+        float4 v;
+        if (c < Dc) {
+            v = *reinterpret_cast<const float4*>(tc_emb + (long long)(tc_row[j] + i) * ld_tc + c);
+        } else {
+            const float pv = p[(long long)j * pstride + i];
+            const float4 w = *reinterpret_cast<const float4*>(w_dt + (c - Dc));
+            v.x = w.x * pv; v.y = w.y * pv; v.z = w.z * pv; v.w = w.w * pv;
+        }
+        const float4 q = *reinterpret_cast<const float4*>(pe + (long long)i * D + c);
+        v.x = v.x * 1.0f + q.x; v.y = v.y * 1.0f + q.y; v.z = v.z * 1.0f + q.z; v.w = v.w * 1.0f + q.w;
+        *reinterpret_cast<float4*>(x + (long long)r * D + c) = v;
+    }
+}
+hipError_t launch_adm_step_input(const float* tc_emb, int ld_tc, const int* tc_row, const float* w_dt,
+                                 const float* p, int pstride, const float* pe, float* x, int Dc, int De,
+                                 int n, int A, hipStream_t s) {
+    if (A <= 0) return hipSuccess;
+    hipLaunchKernelGGL(adm_step_input_kernel, row_grid((long long)A * n * ((Dc + De) >> 2)), dim3(256), 0, s,
+                       tc_emb, ld_tc, tc_row, w_dt, p, pstride, pe, x, Dc, De, n, A);
+    return hipGetLastError();
+}
+
+// MegaPLM.infer step input (models/megatts2.py:173-175): cat([cond[:t+1], pc_embedding(codes)]) + pe
+__global__ void plm_step_input_kernel(const float* cond, int ld_c, const int* cond_row, const float* emb,
+                                      const int64_t* codes, int cstride, const float* pe, float* x, int Dc, int De,
+                                      int n, int A) {
+    const int D = Dc + De, c4n = D >> 2;
+    MT2_ROW_LOOP(A * n, D) {
+        const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
+        const int j = r / n, i = r % n;
+        float4 v;
+        if (c < Dc) {
+            v = *reinterpret_cast<const float4*>(cond + (long long)(cond_row[j] + i) * ld_c + c);
+        } else {
+            v = *reinterpret_cast<const float4*>(emb + (long long)codes[(long long)j * cstride + i] * De + (c - Dc));
+        }
+        const float4 q = *reinterpret_cast<const float4*>(pe + (long long)i * D + c);
+        v.x = v.x * 1.0f + q.x; v.y = v.y * 1.0f + q.y; v.z = v.z * 1.0f + q.z; v.w = v.w * 1.0f + q.w;
+        *reinterpret_cast<float4*>(x + (long long)r * D + c) = v;
+    }
+}
+hipError_t launch_plm_step_input(const float* cond, int ld_c, const int* cond_row, const float* emb,
+                                 const int64_t* codes, int cstride, const float* pe, float* x, int Dc, int De,
+                                 int n, int A, hipStream_t s) {
+    if (A <= 0) return hipSuccess;
+    hipLaunchKernelGGL(plm_step_input_kernel, row_grid((long long)A * n * ((Dc + De) >> 2)), dim3(256), 0, s, cond,
+                       ld_c, cond_row, emb, codes, cstride, pe, x, Dc, De, n, A);
+    return hipGetLastError();
+}
+
+// MegaADM predict_layer on the last position only (models/megatts2.py:272): one wave per sequence
+__global__ __launch_bounds__(256) void adm_predict_kernel(const float* x, int D, const float* w, float* p,
+                                                          int pstride, int n, int A) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= A) return;
+    const float* xr = x + ((long long)j * n + (n - 1)) * D;
+    float s = 0.0f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + c);
+        const float4 b = *reinterpret_cast<const float4*>(w + c);
+        s += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) p[(long long)j * pstride + n] = s;
+}
+hipError_t launch_adm_predict(const float* x, int D, const float* w, float* p, int pstride, int n, int A,
+                              hipStream_t s) {
+    if (A <= 0) return hipSuccess;
+    hipLaunchKernelGGL(adm_predict_kernel, dim3((A + 3) / 4), dim3(256), 0, s, x, D, w, p, pstride, n, A);
+    return hipGetLastError();
+}
+
+// (p_code[:, 1:] + 0.5).to(int32).clamp(1, 128)  (models/megatts2.py:275); .to(int32) truncates
+// slot j (length-sorted order) is written back to utterance slot_b[j].
+__global__ void adm_finalize_kernel(const float* p, int pstride, const int* lens, const int* slot_b, int32_t* dur,
+                                    float* flt, int dstride, int A, int nmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A * nmax) return;
+    const int j = i / nmax, t = i % nmax;
+    int d = 0;
+    float f = 0.0f;
+    if (t < lens[j]) {
+        f = p[(long long)j * pstride + t + 1];
+        d = (int)(f + 0.5f);
+        d = d < 1 ? 1 : (d > 128 ? 128 : d);
+    }
+    const int b = slot_b ? slot_b[j] : j;
+    dur[(long long)b * dstride + t] = d;
+    if (flt) flt[(long long)b * dstride + t] = f;
+}
+hipError_t launch_adm_finalize(const float* p, int pstride, const int* lens, const int* slot_b, int32_t* dur,
+                               float* flt, int dstride, int A, int nmax, hipStream_t s) {
+    if (A * nmax <= 0) return hipSuccess;
+    hipLaunchKernelGGL(adm_finalize_kernel, dim3((A * nmax + 255) / 256), dim3(256), 0, s, p, pstride, lens, slot_b,
+                       dur, flt, dstride, A, nmax);
+    return hipGetLastError();
+}
+
+// codes_out[slot_b[j]*ostride + t] = codes[j*cstride + 1 + t] for t < lens[j], else 0
+__global__ void plm_finalize_kernel(const int64_t* codes, int cstride, const int* lens, const int* slot_b,
+                                    int64_t* out, int ostride, int A, int nmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A * nmax) return;
+    const int j = i / nmax, t = i % nmax;
+    const int b = slot_b ? slot_b[j] : j;
+    out[(long long)b * ostride + t] = t < lens[j] ? codes[(long long)j * cstride + 1 + t] : 0;
+}
+hipError_t launch_plm_finalize(const int64_t* codes, int cstride, const int* lens, const int* slot_b, int64_t* out,
+                               int ostride, int A, int nmax, hipStream_t s) {
+    if (A * nmax <= 0) return hipSuccess;
+    hipLaunchKernelGGL(plm_finalize_kernel, dim3((A * nmax + 255) / 256), dim3(256), 0, s, codes, cstride, lens,
+                       slot_b, out, ostride, A, nmax);
+    return hipGetLastError();
+}
+
+// out[map[r]] = src[r] for map[r] >= 0 (int64 row scatter: VQ indices back to the padded layout)
+__global__ void scatter_i64_kernel(const int64_t* src, const int* map, int64_t* out, int R) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < R && map[r] >= 0) out[map[r]] = src[r];
+}
+hipError_t launch_scatter_i64(const int64_t* src, const int* map, int64_t* out, int R, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_i64_kernel, dim3((R + 255) / 256), dim3(256), 0, s, src, map, out, R);
+    return hipGetLastError();
+}
+
+// gap-row mask of an up-sampled row set: out[r] = in[r / factor]
+__global__ void expand_mask_kernel(const int* in, int factor, int* out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        out[i] = in[i / factor];
+}
+hipError_t launch_expand_mask(const int* in, int factor, int* out, long long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(expand_mask_kernel, row_grid(n), dim3(256), 0, s, in, factor, out, n);
+    return hipGetLastError();
+}
+
+// waveform rows (1 channel, already tanh'ed) -> padded [B, hop*T_max]; utterance b = rows [start[b], start[b]+len[b])
+__global__ void unpack_wav_kernel(const float* src, const long long* start, const long long* len, float* out,
+                                  long long out_stride) {
+    const int b = blockIdx.y;
+    const long long n = len[b], s0 = start[b];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        out[b * out_stride + i] = src[s0 + i];
+}
+hipError_t launch_unpack_wav(const float* src, const long long* start, const long long* len, float* out,
+                             long long out_stride, long long max_len, int B, hipStream_t s) {
+    if (B <= 0 || max_len <= 0) return hipSuccess;
+    long long bx = (max_len + 255) / 256;
+    if (bx > 4096) bx = 4096;
+    hipLaunchKernelGGL(unpack_wav_kernel, dim3((unsigned)bx, B), dim3(256), 0, s, src, start, len, out, out_stride);
+    return hipGetLastError();
+}
+
+// torch.argmax semantics: first index of the maximum.  One wave per row, (value, index) reduction.
+__device__ __forceinline__ void argmax_combine(float& bv, int& bi, float ov, int oi) {
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+}
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, int ldx, int N, int64_t* out,
+                                                          int ostride, int ooff, int A) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wave;
+    if (j >= A) return;
+    const float* xr = x + (long long)j * ldx;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int n = lane; n < N; n += 64) argmax_combine(bv, bi, xr[n], n);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    if (lane == 0) out[(long long)j * ostride + ooff] = bi;
+}
+hipError_t launch_argmax_rows(const float* x, int ldx, int N, int64_t* out, int ostride, int ooff, int A,
+                              hipStream_t s) {
+    if (A <= 0) return hipSuccess;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((A + 3) / 4), dim3(256), 0, s, x, ldx, N, out, ostride, ooff, A);
+    return hipGetLastError();
+}
+
+// EuclideanCodebook.quantize (modules/quantization/core_vq.py:175-183):
+//   dist = -(x.pow(2).sum(1) - 2 * x @ embed + embed.pow(2).sum(0)); ind = dist.max(-1).indices
+// evaluated in that operand order, ((xx - 2*xe) + ee), lowest index on ties.  xe comes from the GEMM.
+__global__ __launch_bounds__(256) void vq_argmin_kernel(const float* x, int ldx, int D, const float* xe, int ldxe,
+                                                        const float* ee, int N, const int* valid, int64_t* idx,
+                                                        int M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    if (valid && valid[m] == 0) { if (lane == 0) idx[m] = 0; return; }
+    const float* xr = x + (long long)m * ldx;
+    float s = 0.0f;
+    for (int c = lane; c < D; c += 64) s += xr[c] * xr[c];
+    const float xx = wave_sum(s);
+    const float* er = xe + (long long)m * ldxe;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int n = lane; n < N; n += 64) {
+        const float dist = -((xx - 2.0f * er[n]) + ee[n]);
+        argmax_combine(bv, bi, dist, n);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        argmax_combine(bv, bi, ov, oi);
+    }
+    if (lane == 0) idx[m] = bi;
+}
+hipError_t launch_vq_argmin(const float* x, int ldx, int D, const float* xe, int ldxe, const float* ee, int N,
+                            const int* valid, int64_t* idx, int M, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(vq_argmin_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, D, xe, ldxe, ee, N, valid, idx,
+                       M);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* E, int D, float* ee, int N) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    float s = 0.0f;
+    for (int c = lane; c < D; c += 64) s += E[(long long)n * D + c] * E[(long long)n * D + c];
+    s = wave_sum(s);
+    if (lane == 0) ee[n] = s;
+}
+hipError_t launch_row_sqnorm(const float* E, int D, float* ee, int N, hipStream_t s) {
+    if (N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((N + 3) / 4), dim3(256), 0, s, E, D, ee, N);
+    return hipGetLastError();
+}
+
+// decoder input rows (models/megatts2.py:361-366): [tc_latent_expand (gather), zq (codebook row, x8 repeat)]
+__global__ void decoder_input_kernel(const float* tc, int ld_tc, const int* tcmap, const float* E,
+                                     const int64_t* codes, const int* codemap, float* out, int Dc, int Dq, int R) {
+    const int D = Dc + Dq, c4n = D >> 2;
+    MT2_ROW_LOOP(R, D) {
+        const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int tr = tcmap[r];
+        if (tr >= 0) {
+            if (c < Dc) v = *reinterpret_cast<const float4*>(tc + (long long)tr * ld_tc + c);
+            else v = *reinterpret_cast<const float4*>(E + (long long)codes[codemap[r]] * Dq + (c - Dc));
+        }
+        *reinterpret_cast<float4*>(out + (long long)r * D + c) = v;
+    }
+}
+hipError_t launch_decoder_input(const float* tc, int ld_tc, const int* tcmap, const float* E, const int64_t* codes,
+                                const int* codemap, float* out, int Dc, int Dq, int R, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(decoder_input_kernel, row_grid((long long)R * ((Dc + Dq) >> 2)), dim3(256), 0, s, tc, ld_tc,
+                       tcmap, E, codes, codemap, out, Dc, Dq, R);
+    return hipGetLastError();
+}
+
+// EuclideanCodebook.dequantize (core_vq.py:188-190) + the x8 repeat of vqpe.py:59-61 via codemap
+__global__ void codebook_rows_kernel(const float* E, const int64_t* codes, const int* codemap, float* out, int ldo,
+                                     int Dq, int R) {
+    const int c4n = Dq >> 2;
+    MT2_ROW_LOOP(R, Dq) {
+        const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int cm = codemap[r];
+        if (cm >= 0) v = *reinterpret_cast<const float4*>(E + (long long)codes[cm] * Dq + c);
+        *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = v;
+    }
+}
+hipError_t launch_codebook_rows(const float* E, const int64_t* codes, const int* codemap, float* out, int ldo,
+                                int Dq, int R, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(codebook_rows_kernel, row_grid((long long)R * (Dq >> 2)), dim3(256), 0, s, E, codes, codemap,
+                       out, ldo, Dq, R);
+    return hipGetLastError();
+}
+
+__global__ void tanh_col_kernel(const float* x, int ldx, float* out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        out[i] = tanhf(x[i * ldx]);
+}
+hipError_t launch_tanh_col(const float* x, int ldx, float* out, long long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tanh_col_kernel, row_grid(n), dim3(256), 0, s, x, ldx, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace mt2

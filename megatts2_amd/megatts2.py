@@ -1,0 +1,323 @@
+"""Drop-in mirror of the reference's `models/megatts2.py` object surface on the MI355X HIP engine.
+
+Same class / method names, argument order and tensor layouts as the reference
+(`MegaG`, `MegaPLM`, `MegaADM`, `Megatts`, `LengthRegulator`), so that
+`infer.py`-style code switches with an import change.  Every numeric method
+forwards to libmegatts2_hip through `runtime.NativeModel`; nothing here computes with torch ops.
+
+Extensions over the reference (which is batch-1, CPU): every method takes optional per-utterance
+length arguments and treats each utterance as an independent batch-1 run; `Megatts.synthesize`
+runs a whole batch with activations resident in HBM between stages.
+"""
+from __future__ import annotations
+
+import glob
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import config as cfgmod
+from . import weights
+from .config import HIFIGAN_HOP_LENGTH, HIFIGAN_SR
+from .runtime import NativeError, NativeModel
+
+
+def _np_sd(sd) -> Dict[str, np.ndarray]:
+    return {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
+
+
+class LengthRegulator:
+    """reference modules/mrte.py:34-60 (FastSpeech length regulator) as a device gather."""
+
+    def __init__(self, mel_frames, sample_rate, duration_token_ms, native: Optional[NativeModel] = None):
+        assert (mel_frames / sample_rate * 1000 / duration_token_ms) == 1      # mrte.py:40
+        self._native = native
+
+    def bind(self, native: NativeModel) -> "LengthRegulator":
+        self._native = native
+        return self
+
+    def __call__(self, x, duration_tokens, mel_max_length=None, lens=None):
+        if self._native is None:
+            raise NativeError("LengthRegulator is not bound to a native model")
+        return self._native.length_regulate(x, duration_tokens, lens, mel_max_length)
+
+    forward = __call__
+
+
+class _MRTE:
+    """reference modules/mrte.py:63-171 (the inference surface: `tc_latent`, `mel_encoder`)."""
+
+    def __init__(self, owner: "MegaG"):
+        self._o = owner
+        self.hidden_size = owner.cfg.mrte.hidden_size
+        self.mel_bins = owner.cfg.mrte.mel_bins
+
+    def tc_latent(self, phone, *args, phone_lens=None, mel_lens=None):
+        # the reference signature is (phone, mel) (mrte.py:154-158) but two of its own call sites pass
+        # (phone, phone_lens, mel) (mrte.py:180, models/megatts2.py:83): accept both
+        if len(args) == 1:
+            mel = args[0]
+        elif len(args) == 2:
+            phone_lens, mel = args
+        else:
+            raise TypeError("tc_latent(phone, mel) or tc_latent(phone, phone_lens, mel)")
+        return self._o.native.tc_latent(phone, mel, phone_lens, mel_lens)
+
+    def mel_encoder(self, mel_bdt, mel_lens=None):
+        """ConvNetDouble.forward on "B D T" input -> "B D T" (modules/convnet.py:202-210)."""
+        return self._o.native.mel_context(mel_bdt.transpose(1, 2), mel_lens).transpose(1, 2)
+
+
+class _RVQ:
+    """reference modules/quantization/vq.py:100-113 (n_q = 1)."""
+
+    def __init__(self, owner: "MegaG"):
+        self._o = owner
+        self.dimension = owner.cfg.vqpe.vq_dim
+        self.n_q = 1
+        self.bins = owner.cfg.vqpe.vq_bins
+
+    def decode(self, codes):
+        return self._o.native.vq_decode(codes)
+
+    def encode(self, x, frame_rate=None, bandwidth=None):
+        """x "b d n" -> codes [n_q, b, n] (EuclideanCodebook.encode, core_vq.py:192-200)."""
+        b, d, n = x.shape
+        idx = self._o.native.vq_quantize(x.transpose(1, 2).reshape(b * n, d))
+        return idx.view(1, b, n)
+
+
+class _VQPE:
+    """reference modules/vqpe.py:13-62."""
+
+    def __init__(self, owner: "MegaG"):
+        self._o = owner
+        self.stride = owner.cfg.vqpe.stride
+        self.mel_bins = owner.cfg.vqpe.mel_bins
+        self.vq = _RVQ(owner)
+
+    def __call__(self, mel, lens=None):
+        import torch
+        zq, codes = self._o.native.vqpe_forward(mel, lens)
+        zero = torch.zeros(1, 1, device=mel.device)       # losses are training-only (vqpe.py:57-58)
+        return zq, zero, zero[0, 0], codes
+
+    forward = __call__
+
+
+class MegaG:
+    """reference models/megatts2.py:30-117."""
+
+    def __init__(self, cfg: cfgmod.GConfig, state_dict: Dict[str, np.ndarray], native: Optional[NativeModel] = None):
+        self.cfg = cfg
+        self.state = _np_sd(state_dict)
+        weights.check_strict(self.state, weights.inventory_g(cfg))
+        self._native = native
+        self.mrte = _MRTE(self)
+        self.vqpe = _VQPE(self)
+
+    @property
+    def native(self) -> NativeModel:
+        if self._native is None:
+            self._native = NativeModel(g_cfg=self.cfg, sd_g=self.state)
+        return self._native
+
+    def decoder(self, x, lens=None):
+        """ConvNet.forward, "B D T" -> "B D T" (modules/convnet.py:115-119)."""
+        return self.native.mel_decoder(x, lens)
+
+    def s2_latent(self, phone, phone_lens, mel_mrte, mel_vqpe):
+        """models/megatts2.py:75-84 (stage-2 latent extraction, prepare_ds.py:224-258)."""
+        _, codes = self.native.vqpe_forward(mel_vqpe)
+        return self.native.tc_latent(phone, mel_mrte, phone_lens), codes
+
+    def eval(self):
+        return self
+
+    def cuda(self):
+        return self
+
+    @classmethod
+    def from_hparams(cls, config_path: str, seed: int = 0) -> "MegaG":
+        """models/megatts2.py:87-104.  The reference returns randomly initialised modules; here the
+        synthetic name-seeded weights are used."""
+        cfg = cfgmod.g_config_from_yaml(config_path)
+        return cls(cfg, weights.synth_state_dict(weights.inventory_g(cfg), seed, "G."))
+
+    @classmethod
+    def from_pretrained(cls, ckpt: str, config: str) -> "MegaG":
+        cfg = cfgmod.g_config_from_yaml(config)
+        return cls(cfg, weights.load_lightning_state_dict(ckpt, "G."))
+
+
+class MegaPLM:
+    """reference models/megatts2.py:120-198."""
+
+    def __init__(self, cfg: cfgmod.PLMConfig, state_dict, native: Optional[NativeModel] = None):
+        self.cfg = cfg
+        self.state = _np_sd(state_dict)
+        weights.check_strict(self.state, weights.inventory_plm(cfg))
+        self._native = native
+
+    @property
+    def native(self) -> NativeModel:
+        if self._native is None:
+            self._native = NativeModel(plm_cfg=self.cfg, sd_plm=self.state)
+        return self._native
+
+    def infer(self, tc_latent, lens=None):
+        return self.native.plm_infer(tc_latent, lens)
+
+    def eval(self):
+        return self
+
+    @classmethod
+    def from_pretrained(cls, ckpt: str, config: str) -> "MegaPLM":
+        return cls(cfgmod.plm_config_from_yaml(config), weights.load_lightning_state_dict(ckpt, "plm."))
+
+
+class MegaADM:
+    """reference models/megatts2.py:201-292."""
+
+    def __init__(self, cfg: cfgmod.ADMConfig, state_dict, native: Optional[NativeModel] = None):
+        self.cfg = cfg
+        self.state = _np_sd(state_dict)
+        weights.check_strict(self.state, weights.inventory_adm(cfg))
+        self._native = native
+
+    @property
+    def native(self) -> NativeModel:
+        if self._native is None:
+            self._native = NativeModel(adm_cfg=self.cfg, sd_adm=self.state)
+        return self._native
+
+    def infer(self, tc_latents, lens=None):
+        """-> int32 [B, Np, 1] like the reference (models/megatts2.py:275)."""
+        return self.native.adm_infer(tc_latents, lens).unsqueeze(-1)
+
+    def eval(self):
+        return self
+
+    @classmethod
+    def from_pretrained(cls, ckpt: str, config: str) -> "MegaADM":
+        return cls(cfgmod.adm_config_from_yaml(config), weights.load_lightning_state_dict(ckpt, "adm."))
+
+
+class HIFIGAN:
+    """Stand-in for `speechbrain.pretrained.HIFIGAN` (models/megatts2.py:25,321-323): HiFi-GAN V1
+    generator on the HIP engine.  `from_hparams(source=...)` cannot download the hub weights offline;
+    pass a state dict named like transformers.SpeechT5HifiGan (weights.inventory_hifigan)."""
+
+    def __init__(self, cfg: cfgmod.HifiGanConfig, state_dict, native: Optional[NativeModel] = None):
+        self.cfg = cfg
+        self.state = _np_sd(state_dict)
+        weights.check_strict(self.state, weights.inventory_hifigan(cfg))
+        self._native = native
+
+    @property
+    def native(self) -> NativeModel:
+        if self._native is None:
+            self._native = NativeModel(hg_cfg=self.cfg, sd_hifigan=self.state)
+        return self._native
+
+    def decode_batch(self, spectrogram, mel_lens=None, hop_len=None):
+        """mel [B, 80, T] -> waveform [B, 1, hop*T]."""
+        return self.native.hifigan(spectrogram, mel_lens)
+
+    def eval(self):
+        return self
+
+
+class Megatts:
+    """reference models/megatts2.py:295-375.  One native handle carries G + PLM + ADM (+ vocoder)."""
+
+    def __init__(self, g_ckpt: str = None, g_config: str = None, plm_ckpt: str = None, plm_config: str = None,
+                 adm_ckpt: str = None, adm_config: str = None, symbol_table: str = None, *,
+                 models: Optional[tuple] = None, hifi_gan: Optional[HIFIGAN] = None):
+        if models is not None:
+            self.generator, self.plm, self.adm = models
+        else:
+            self.generator = MegaG.from_pretrained(g_ckpt, g_config)
+            self.plm = MegaPLM.from_pretrained(plm_ckpt, plm_config)
+            self.adm = MegaADM.from_pretrained(adm_ckpt, adm_config)
+        self.hifi_gan = hifi_gan
+        self.native = NativeModel(self.generator.cfg, self.plm.cfg, self.adm.cfg,
+                                  hifi_gan.cfg if hifi_gan else None, self.generator.state, self.plm.state,
+                                  self.adm.state, hifi_gan.state if hifi_gan else None)
+        for part in (self.generator, self.plm, self.adm) + ((hifi_gan,) if hifi_gan else ()):
+            part._native = self.native
+        self.lr = LengthRegulator(HIFIGAN_HOP_LENGTH, 16000, (HIFIGAN_HOP_LENGTH / HIFIGAN_SR * 1000), self.native)
+        self.symbol_table = symbol_table
+        self.tt = None
+        self.ttc = None
+
+    def eval(self):
+        return self
+
+    # -- batched tensor-level pipeline (the measured hot path)
+    def synthesize(self, phone_tokens, mels, phone_lens=None, mel_lens=None, forced_durations=None,
+                   forced_codes=None, vocoder: bool = False, return_aux: bool = False):
+        """phone_tokens int64 [B, Np], mels f32 [B, Tp, 80] -> (mel [B, Tm, 80], mel_lens) - the
+        no_grad block of Megatts.forward (models/megatts2.py:353-368) for every utterance of the batch."""
+        return self.native.synthesize_batch(phone_tokens, phone_lens, mels, mel_lens, forced_durations, forced_codes,
+                                            run_plm=forced_codes is None, vocoder=vocoder, return_aux=return_aux)
+
+    def synthesize_list(self, utterances: Sequence, vocoder: bool = False):
+        """List of utterance records (`.phone` int64 [Np], `.prompt_mel` f32 [Tp, 80], optional
+        `.durations`, `.p_codes`) -> (mel [B, Tm_max, 80] device tensor, lens); pads to the batch
+        maxima and forwards per-utterance lengths, so every utterance is computed as if alone."""
+        import torch
+        B = len(utterances)
+        Np = max(u.phone.size for u in utterances)
+        Tp = max(u.prompt_mel.shape[0] for u in utterances)
+        phone = np.zeros((B, Np), np.int64)
+        mel = np.zeros((B, Tp, utterances[0].prompt_mel.shape[1]), np.float32)
+        pl, ml = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        have_d = all(getattr(u, "durations", None) is not None for u in utterances)
+        have_c = all(getattr(u, "p_codes", None) is not None for u in utterances)
+        dur = np.zeros((B, Np), np.int32) if have_d else None
+        tq = max(u.p_codes.size for u in utterances) if have_c else 0
+        codes = np.zeros((B, tq), np.int64) if have_c else None
+        for i, u in enumerate(utterances):
+            pl[i], ml[i] = u.phone.size, u.prompt_mel.shape[0]
+            phone[i, :pl[i]] = u.phone
+            mel[i, :ml[i]] = u.prompt_mel
+            if have_d:
+                dur[i, :pl[i]] = u.durations
+            if have_c:
+                codes[i, :u.p_codes.size] = u.p_codes
+        dev = self.native.device
+        out = self.native.synthesize_batch(torch.from_numpy(phone).to(dev), pl, torch.from_numpy(mel).to(dev), ml,
+                                           forced_dur=dur,
+                                           forced_codes=torch.from_numpy(codes).to(dev) if have_c else None,
+                                           run_plm=not have_c, vocoder=vocoder)
+        return out[0], out[1]
+
+    # -- the reference's entry point (models/megatts2.py:325-375).  The audio / text front-end
+    # (librosa, speechbrain mel, pypinyin G2P) is host pre-processing outside the hot path
+    # (SURVEY.md 2.1 rows 12-13); it is used when importable.
+    def forward(self, wavs_dir: str, text: str):
+        import torch
+        try:
+            import librosa  # noqa: F401
+            from modules.tokenizer import TextTokenizer, extract_mel_spec   # reference front-end, if on sys.path
+            from modules.datamodule import TokensCollector
+        except Exception as e:  # pragma: no cover - front-end absent in this image
+            raise NativeError("Megatts.forward(wavs_dir, text) needs the reference's audio/text front-end "
+                              "(librosa, speechbrain, pypinyin); call synthesize(phone_tokens, mels) instead") from e
+        mels, mels_prompt = [], None
+        for wav in glob.glob(f"{wavs_dir}/*.wav"):
+            y = librosa.util.normalize(librosa.load(wav, sr=HIFIGAN_SR)[0])
+            mel_spec = extract_mel_spec(torch.from_numpy(y)).transpose(0, 1)
+            mels.append(mel_spec)
+            if mels_prompt is None:
+                mels_prompt = mel_spec
+        mels = torch.cat(mels, dim=0).unsqueeze(0).cuda()
+        if self.tt is None:
+            self.tt, self.ttc = TextTokenizer(), TokensCollector(self.symbol_table)
+        phone_tokens = self.ttc.phone2token(self.tt.tokenize_lty(self.tt.tokenize(text))).unsqueeze(0).cuda()
+        mel, mel_lens, aux = self.synthesize(phone_tokens, mels, vocoder=self.hifi_gan is not None, return_aux=True)
+        return mel, mel_lens, aux
+
+    __call__ = forward

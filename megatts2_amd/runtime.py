@@ -1,0 +1,467 @@
+"""ctypes binding of libmegatts2_hip.so (C ABI: include/megatts2_hip.h).
+
+PyTorch-ROCm is used for plumbing only: device memory (`torch.empty(..., device='cuda')`), the
+current HIP stream and `torch.distributed`.  Every numeric stage runs in the hand-written gfx950
+kernels behind the C ABI; there is NO PyTorch / CPU fallback - if the shared library or a gfx950
+device is missing, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import config as cfgmod
+
+_LIB = None
+MAX_POSITIONS = 8192       # rows of the sine tables (the reference builds 4000 and extends on demand)
+
+MT2_RUN_PLM, MT2_RUN_VOCODER, MT2_SKIP_ADM = 1, 2, 4
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class MT2Config(C.Structure):
+    _fields_ = [
+        ("mel_bins", C.c_int32), ("mrte_hidden", C.c_int32), ("mrte_kernel", C.c_int32), ("mrte_stride", C.c_int32),
+        ("mrte_n_layer", C.c_int32), ("mrte_n_stack", C.c_int32), ("mrte_n_block", C.c_int32),
+        ("content_ff_dim", C.c_int32), ("content_n_heads", C.c_int32), ("content_n_layers", C.c_int32),
+        ("phone_vocab", C.c_int32),
+        ("vq_mel_bins", C.c_int32), ("vq_stride", C.c_int32), ("vq_hidden", C.c_int32), ("vq_kernel", C.c_int32),
+        ("vq_n_layers", C.c_int32), ("vq_n_stacks", C.c_int32), ("vq_n_blocks", C.c_int32), ("vq_bins", C.c_int32),
+        ("vq_dim", C.c_int32),
+        ("dec_kernel", C.c_int32), ("dec_hidden", C.c_int32), ("dec_n_stack", C.c_int32), ("dec_n_block", C.c_int32),
+        ("plm_layers", C.c_int32), ("plm_heads", C.c_int32), ("plm_vq_dim", C.c_int32), ("plm_tc_dim", C.c_int32),
+        ("plm_bins", C.c_int32),
+        ("adm_layers", C.c_int32), ("adm_heads", C.c_int32), ("adm_emb_dim", C.c_int32), ("adm_tc_dim", C.c_int32),
+        ("adm_tc_emb_dim", C.c_int32),
+        ("hg_in_dim", C.c_int32), ("hg_init_channels", C.c_int32), ("hg_n_up", C.c_int32),
+        ("hg_up_rates", C.c_int32 * 8), ("hg_up_kernels", C.c_int32 * 8),
+        ("hg_n_res", C.c_int32), ("hg_res_kernels", C.c_int32 * 4), ("hg_res_dilations", (C.c_int32 * 3) * 4),
+        ("hg_slope", C.c_float),
+        ("max_positions", C.c_int32),
+    ]
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmegatts2_hip.so")
+
+
+def load_library():
+    """dlopen the HIP library (building it with hipcc first if the .so is absent)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        from .build import build
+        build(verbose=False)
+    if not os.path.exists(path):
+        raise NativeError(f"{path} is missing: run `python -m megatts2_amd.build` (needs hipcc)")
+    lib = C.CDLL(path)
+    lib.mt2_last_error.restype = C.c_char_p
+    lib.mt2_version.restype = C.c_char_p
+    lib.mt2_model_create.restype = C.c_void_p
+    lib.mt2_model_create.argtypes = [C.POINTER(MT2Config)]
+    lib.mt2_model_destroy.argtypes = [C.c_void_p]
+    lib.mt2_model_destroy.restype = None
+    _LIB = lib
+    return lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise NativeError(load_library().mt2_last_error().decode(errors="replace"))
+
+
+def device_check() -> None:
+    _check(load_library().mt2_device_check())
+
+
+def make_config(g: Optional[cfgmod.GConfig], plm: Optional[cfgmod.PLMConfig], adm: Optional[cfgmod.ADMConfig],
+                hg: Optional[cfgmod.HifiGanConfig], max_positions: int = MAX_POSITIONS) -> MT2Config:
+    g = g or cfgmod.production_g()
+    plm = plm or cfgmod.production_plm()
+    adm = adm or cfgmod.production_adm()
+    hg = hg or cfgmod.production_hifigan()
+    c = MT2Config()
+    m, v = g.mrte, g.vqpe
+    c.mel_bins, c.mrte_hidden, c.mrte_kernel, c.mrte_stride = m.mel_bins, m.hidden_size, m.mel_kernel_size, m.mel_stride
+    c.mrte_n_layer, c.mrte_n_stack, c.mrte_n_block = m.mel_n_layer, m.mel_n_stack, m.mel_n_block
+    c.content_ff_dim, c.content_n_heads, c.content_n_layers = m.content_ff_dim, m.content_n_heads, m.content_n_layers
+    c.phone_vocab = m.phone_vocab_size
+    c.vq_mel_bins, c.vq_stride, c.vq_hidden, c.vq_kernel = v.mel_bins, v.stride, v.hidden_size, v.kernel_size
+    c.vq_n_layers, c.vq_n_stacks, c.vq_n_blocks, c.vq_bins, c.vq_dim = v.n_layers, v.n_stacks, v.n_blocks, v.vq_bins, v.vq_dim
+    c.dec_kernel, c.dec_hidden, c.dec_n_stack, c.dec_n_block = g.kernel_size, g.hidden_size, g.decoder_n_stack, g.decoder_n_block
+    c.plm_layers, c.plm_heads, c.plm_vq_dim, c.plm_tc_dim, c.plm_bins = plm.n_layers, plm.n_heads, plm.vq_dim, plm.tc_latent_dim, plm.vq_bins
+    c.adm_layers, c.adm_heads, c.adm_emb_dim, c.adm_tc_dim, c.adm_tc_emb_dim = adm.n_layers, adm.n_heads, adm.emb_dim, adm.tc_latent_dim, adm.tc_emb_dim
+    c.hg_in_dim, c.hg_init_channels, c.hg_n_up = hg.in_dim, hg.upsample_initial_channel, len(hg.upsample_rates)
+    for i, (r, k) in enumerate(zip(hg.upsample_rates, hg.upsample_kernel_sizes)):
+        c.hg_up_rates[i], c.hg_up_kernels[i] = r, k
+    c.hg_n_res = len(hg.resblock_kernel_sizes)
+    for j, (k, dils) in enumerate(zip(hg.resblock_kernel_sizes, hg.resblock_dilation_sizes)):
+        c.hg_res_kernels[j] = k
+        for n, d in enumerate(dils):
+            c.hg_res_dilations[j][n] = d
+    c.hg_slope = hg.leaky_relu_slope
+    c.max_positions = max_positions
+    return c
+
+
+def sine_table(n: int, dim: int, alpha: float) -> np.ndarray:
+    """alpha * pe[:n] of SinePositionalEmbedding (reference modules/embedding.py:68-98), computed with
+    the same torch fp32 ops the reference uses so that the table is bit-identical to its `self.pe`."""
+    import torch
+
+    position = torch.arange(0, n, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * -(math.log(10000.0) / dim))
+    pe = torch.zeros(n, dim)
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return (float(alpha) * pe).numpy()
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _iptr(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else C.c_void_p(0)
+
+
+def _stream() -> C.c_void_p:
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class NativeModel:
+    """Owns one `mt2_model*`: packed weights in HBM + the activation workspace."""
+
+    def __init__(self, g_cfg=None, plm_cfg=None, adm_cfg=None, hg_cfg=None,
+                 sd_g: Optional[Dict[str, np.ndarray]] = None, sd_plm: Optional[Dict[str, np.ndarray]] = None,
+                 sd_adm: Optional[Dict[str, np.ndarray]] = None, sd_hifigan: Optional[Dict[str, np.ndarray]] = None,
+                 max_positions: int = MAX_POSITIONS):
+        import torch
+
+        self.lib = load_library()
+        device_check()
+        if not torch.cuda.is_available():
+            raise NativeError("PyTorch-ROCm sees no GPU")
+        self.g_cfg = g_cfg or cfgmod.production_g()
+        self.plm_cfg = plm_cfg or cfgmod.production_plm()
+        self.adm_cfg = adm_cfg or cfgmod.production_adm()
+        self.hg_cfg = hg_cfg or cfgmod.production_hifigan()
+        self.max_positions = max_positions
+        self.ccfg = make_config(self.g_cfg, self.plm_cfg, self.adm_cfg, self.hg_cfg, max_positions)
+        self.h = C.c_void_p(self.lib.mt2_model_create(C.byref(self.ccfg)))
+        if not self.h:
+            raise NativeError(self.lib.mt2_last_error().decode())
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        try:
+            if sd_g is not None:
+                self._push(sd_g, "G.")
+                self._push_one("pe.mrte", sine_table(max_positions, self.g_cfg.mrte.hidden_size,
+                                                     float(np.asarray(sd_g["mrte.phone_pos_embedding.alpha"]).reshape(-1)[0])))
+            if sd_plm is not None:
+                self._push(sd_plm, "plm.")
+                self._push_one("pe.plm", sine_table(max_positions, self.plm_cfg.d_model,
+                                                    float(np.asarray(sd_plm["pos.alpha"]).reshape(-1)[0])))
+            if sd_adm is not None:
+                self._push(sd_adm, "adm.")
+                self._push_one("pe.adm", sine_table(max_positions, self.adm_cfg.d_model,
+                                                    float(np.asarray(sd_adm["pos_emb.alpha"]).reshape(-1)[0])))
+            if sd_hifigan is not None:
+                self._push(sd_hifigan, "hifigan.")
+            _check(self.lib.mt2_model_finalize(self.h))
+        except Exception:
+            self.close()
+            raise
+        self.has_g, self.has_plm, self.has_adm = sd_g is not None, sd_plm is not None, sd_adm is not None
+        self.has_vocoder = sd_hifigan is not None
+
+    # ---- lifetime
+    def _push_one(self, name: str, arr) -> None:
+        a = np.ascontiguousarray(np.asarray(arr, dtype=np.float32))
+        shape = (C.c_int64 * max(a.ndim, 1))(*(a.shape if a.ndim else (1,)))
+        _check(self.lib.mt2_model_load_tensor(self.h, name.encode(), a.ctypes.data_as(C.c_void_p), shape,
+                                              max(a.ndim, 1)))
+
+    def _push(self, sd: Dict[str, np.ndarray], prefix: str) -> None:
+        for k, v in sd.items():
+            if hasattr(v, "detach"):
+                v = v.detach().cpu().numpy()
+            self._push_one(prefix + k, v)
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.mt2_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def memory(self):
+        w, s = C.c_size_t(0), C.c_size_t(0)
+        _check(self.lib.mt2_model_memory(self.h, C.byref(w), C.byref(s)))
+        return w.value, s.value
+
+    # ---- helpers
+    def _f32(self, t):
+        import torch
+        assert t.is_cuda, "device tensor expected"
+        return t.contiguous().to(torch.float32)
+
+    def _lens(self, lens, B: int, full: int) -> np.ndarray:
+        if lens is None:
+            return np.full(B, full, np.int32)
+        if hasattr(lens, "detach"):
+            lens = lens.detach().cpu().numpy()
+        a = _i32(lens)
+        assert a.shape == (B,)
+        return a
+
+    # ---- stages (C ABI one-to-one)
+    def tc_latent(self, phone, mel, phone_lens=None, mel_lens=None):
+        import torch
+        B, Np = phone.shape
+        Tp = mel.shape[1]
+        phone = phone.contiguous().to(torch.int64)
+        mel = self._f32(mel)
+        pl, ml = self._lens(phone_lens, B, Np), self._lens(mel_lens, B, Tp)
+        out = torch.empty(B, Np, self.g_cfg.mrte.hidden_size, device=mel.device, dtype=torch.float32)
+        _check(self.lib.mt2_mrte_tc_latent(self.h, _stream(), _ptr(phone), _iptr(pl), Np, _ptr(mel), _iptr(ml), Tp, B,
+                                           _ptr(out)))
+        return out
+
+    def mel_context(self, mel, mel_lens=None):
+        import torch
+        B, Tp = mel.shape[0], mel.shape[1]
+        mel = self._f32(mel)
+        ml = self._lens(mel_lens, B, Tp)
+        s = self.g_cfg.mrte.mel_stride
+        Tc = (int(ml.max()) - 1) // s + 1
+        out = torch.empty(B, Tc, self.g_cfg.mrte.hidden_size, device=mel.device, dtype=torch.float32)
+        _check(self.lib.mt2_mrte_mel_context(self.h, _stream(), _ptr(mel), _iptr(ml), Tp, B, _ptr(out), Tc))
+        return out
+
+    def adm_infer(self, tc_latent, lens=None, return_float=False):
+        import torch
+        B, Np = tc_latent.shape[0], tc_latent.shape[1]
+        tc = self._f32(tc_latent)
+        ln = self._lens(lens, B, Np)
+        dur = torch.empty(B, Np, device=tc.device, dtype=torch.int32)
+        flt = torch.empty(B, Np, device=tc.device, dtype=torch.float32) if return_float else None
+        _check(self.lib.mt2_adm_infer(self.h, _stream(), _ptr(tc), _iptr(ln), Np, B, _ptr(dur), _ptr(flt)))
+        return (dur, flt) if return_float else dur
+
+    def length_regulate(self, x, dur, lens=None, mel_max_length=None):
+        import torch
+        B, Np, D = x.shape
+        x = self._f32(x)
+        d = _i32(dur.detach().cpu().numpy() if hasattr(dur, "detach") else dur).reshape(B, Np)
+        ln = self._lens(lens, B, Np)
+        tm = int(max(int(d[b, :ln[b]].sum()) for b in range(B)))
+        cap = max(tm, int(mel_max_length)) if mel_max_length else tm
+        out = torch.empty(B, cap, D, device=x.device, dtype=torch.float32)
+        _check(self.lib.mt2_length_regulate(self.h, _stream(), _ptr(x), _iptr(d), _iptr(ln), Np, D, B, _ptr(out), cap))
+        return out
+
+    def max_pool_ceil(self, x, k: int = 8, lens=None):
+        import torch
+        B, T, D = x.shape
+        x = self._f32(x)
+        ln = self._lens(lens, B, T)
+        Tq = -(-T // k)
+        out = torch.zeros(B, Tq, D, device=x.device, dtype=torch.float32)
+        _check(self.lib.mt2_max_pool_ceil(self.h, _stream(), _ptr(x), _iptr(ln), T, D, B, k, _ptr(out), Tq))
+        return out
+
+    def plm_infer(self, cond, lens=None, return_logits=False):
+        import torch
+        B, Tq = cond.shape[0], cond.shape[1]
+        cond = self._f32(cond)
+        ln = self._lens(lens, B, Tq)
+        codes = torch.empty(B, Tq, device=cond.device, dtype=torch.int64)
+        logits = torch.zeros(B, Tq, self.plm_cfg.vq_bins, device=cond.device, dtype=torch.float32) if return_logits else None
+        _check(self.lib.mt2_plm_infer(self.h, _stream(), _ptr(cond), _iptr(ln), Tq, B, _ptr(codes), _ptr(logits)))
+        return (codes, logits) if return_logits else codes
+
+    def vq_decode(self, codes):
+        import torch
+        nq, B, Tq = codes.shape
+        assert nq == 1, "n_q = 1 (reference modules/vqpe.py:45)"
+        codes = codes.contiguous().to(torch.int64)
+        out = torch.empty(B, self.g_cfg.vqpe.vq_dim, Tq, device=codes.device, dtype=torch.float32)
+        _check(self.lib.mt2_vq_decode(self.h, _stream(), _ptr(codes), B, Tq, _ptr(out)))
+        return out
+
+    def vq_quantize(self, x):
+        import torch
+        x = self._f32(x)
+        M = x.shape[0]
+        idx = torch.empty(M, device=x.device, dtype=torch.int64)
+        _check(self.lib.mt2_vq_quantize(self.h, _stream(), _ptr(x), M, _ptr(idx)))
+        return idx
+
+    def vqpe_forward(self, mel, lens=None, return_ze=False):
+        import torch
+        B, T, ld = mel.shape
+        mel = self._f32(mel)
+        ln = self._lens(lens, B, T)
+        st = self.g_cfg.vqpe.stride
+        Tq = -(-T // st)
+        zq = torch.empty(B, T, self.g_cfg.vqpe.vq_dim, device=mel.device, dtype=torch.float32)
+        codes = torch.empty(1, B, Tq, device=mel.device, dtype=torch.int64)
+        ze = torch.empty(B, Tq, self.g_cfg.vqpe.vq_dim, device=mel.device, dtype=torch.float32) if return_ze else None
+        _check(self.lib.mt2_vqpe_forward(self.h, _stream(), _ptr(mel), _iptr(ln), T, ld, B, _ptr(zq), _ptr(codes), Tq,
+                                         _ptr(ze)))
+        return (zq, codes, ze) if return_ze else (zq, codes)
+
+    def mel_decoder(self, x, lens=None):
+        import torch
+        B, D, T = x.shape
+        x = self._f32(x)
+        ln = self._lens(lens, B, T)
+        mel = torch.empty(B, self.g_cfg.mrte.mel_bins, T, device=x.device, dtype=torch.float32)
+        _check(self.lib.mt2_mel_decoder(self.h, _stream(), _ptr(x), _iptr(ln), T, B, _ptr(mel)))
+        return mel
+
+    def hifigan(self, mel, lens=None):
+        import torch
+        B, D, T = mel.shape
+        mel = self._f32(mel)
+        ln = self._lens(lens, B, T)
+        wav = torch.empty(B, 1, self.hg_cfg.hop * T, device=mel.device, dtype=torch.float32)
+        _check(self.lib.mt2_hifigan(self.h, _stream(), _ptr(mel), _iptr(ln), T, B, _ptr(wav)))
+        return wav
+
+    def synthesize_batch(self, phone, phone_lens, prompt_mel, prompt_lens, forced_dur=None, forced_codes=None,
+                         run_plm=True, vocoder=False, skip_adm=False, tm_cap: Optional[int] = None,
+                         return_aux=False):
+        """Megatts.forward's no_grad block for a batch; returns (mel [B, Tm_cap, 80], mel_lens[, aux])."""
+        import torch
+        B, Np = phone.shape
+        Tp = prompt_mel.shape[1]
+        phone = phone.contiguous().to(torch.int64)
+        prompt_mel = self._f32(prompt_mel)
+        pl, ml = self._lens(phone_lens, B, Np), self._lens(prompt_lens, B, Tp)
+        fd = None
+        if forced_dur is not None:
+            fd = _i32(forced_dur.detach().cpu().numpy() if hasattr(forced_dur, "detach") else forced_dur).reshape(B, Np)
+            need = int(max(int(fd[b, :pl[b]].sum()) for b in range(B)))
+            tm_cap = max(tm_cap or 0, need)
+        if tm_cap is None:
+            tm_cap = 128 * Np          # clamp(1, 128) bounds every duration (models/megatts2.py:275)
+        st = self.g_cfg.vqpe.stride
+        tq_cap = -(-tm_cap // st)
+        if forced_codes is not None:
+            forced_codes = forced_codes.contiguous().to(torch.int64)
+            assert forced_codes.shape[0] == B
+            if forced_codes.shape[1] != tq_cap:
+                fc = torch.zeros(B, tq_cap, device=phone.device, dtype=torch.int64)
+                n = min(tq_cap, forced_codes.shape[1])
+                fc[:, :n] = forced_codes[:, :n]
+                forced_codes = fc
+        dev = prompt_mel.device
+        mel = torch.empty(B, tm_cap, self.g_cfg.mrte.mel_bins, device=dev, dtype=torch.float32)
+        mel_lens = np.zeros(B, np.int32)
+        dur_out = torch.empty(B, Np, device=dev, dtype=torch.int32)
+        codes_out = torch.empty(B, tq_cap, device=dev, dtype=torch.int64)
+        wav = torch.empty(B, self.hg_cfg.hop * tm_cap, device=dev, dtype=torch.float32) if vocoder else None
+        flags = (MT2_RUN_PLM if run_plm else 0) | (MT2_RUN_VOCODER if vocoder else 0) | (MT2_SKIP_ADM if skip_adm else 0)
+        _check(self.lib.mt2_synthesize_batch(self.h, _stream(), _ptr(phone), _iptr(pl), Np, _ptr(prompt_mel), _iptr(ml),
+                                             Tp, B, _iptr(fd), _ptr(forced_codes), tq_cap, flags, _ptr(mel), tm_cap,
+                                             _iptr(mel_lens), _ptr(dur_out), _ptr(codes_out), _ptr(wav)))
+        if return_aux:
+            return mel, mel_lens, {"dur": dur_out, "codes": codes_out, "wav": wav}
+        return mel, mel_lens
+
+    # ---- measurement
+    def set_profiling(self, on: bool) -> None:
+        _check(self.lib.mt2_set_profiling(self.h, 1 if on else 0))
+
+    def last_stage_ms(self) -> Dict[str, float]:
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = self.lib.mt2_last_stage_ms(self.h, names, ms, 16)
+        return {names[i].decode(): float(ms[i]) for i in range(max(n, 0))}
+
+
+# ---- kernel-level entry points -------------------------------------------------------------------------
+
+def op_gemm(X, W, bias=None, R=None, valid=None, rowbase=None, a_mul=1, shift0=0, taps=1, dil=1, Cin=None,
+            M=None, N=None, pro_act=ACT_NONE, pro_slope=0.0, epi_act=ACT_NONE, out_scale=1.0, force_cfg=-1,
+            out=None, ldx=None):
+    import torch
+    lib = load_library()
+    ldx = ldx or X.shape[1]
+    Cin = Cin or ldx
+    N = N or W.shape[0]
+    M = M or X.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=X.device, dtype=torch.float32)
+    _check(lib.mt2_op_gemm(_stream(), _ptr(X), ldx, X.shape[0], _ptr(rowbase), a_mul, shift0, taps, dil, Cin, _ptr(W),
+                           W.shape[1], _ptr(bias), _ptr(R), R.shape[1] if R is not None else 0, _ptr(valid), _ptr(out),
+                           out.shape[1], M, N, pro_act, C.c_float(pro_slope), epi_act, C.c_float(out_scale), force_cfg))
+    return out
+
+
+def op_layernorm(x, gamma, beta, R1=None, valid=None, eps=1e-5, act=ACT_NONE):
+    import torch
+    lib = load_library()
+    M, Cc = x.shape
+    out = torch.empty_like(x)
+    _check(lib.mt2_op_layernorm(_stream(), _ptr(x), Cc, _ptr(gamma), _ptr(beta), _ptr(R1), Cc, _ptr(valid), _ptr(out),
+                                Cc, M, Cc, C.c_float(eps), act))
+    return out
+
+
+def op_attention(Q, K, V, q_start, q_len, kv_start, kv_len, H, D, scale):
+    import torch
+    lib = load_library()
+    O = torch.zeros(Q.shape[0], H * D, device=Q.device, dtype=torch.float32)
+    B = q_start.shape[0]
+    _check(lib.mt2_op_attention(_stream(), _ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(V), V.stride(0), _ptr(O),
+                                O.stride(0), _ptr(q_start), _ptr(q_len), _ptr(kv_start), _ptr(kv_len), B, H, D,
+                                int(q_len.max().item()), C.c_float(scale)))
+    return O
+
+
+def gemm_trace_begin() -> None:
+    _check(load_library().mt2_gemm_trace_begin())
+
+
+def gemm_trace_end():
+    """-> list of dicts {config, launches, flops, ms} for the launches since gemm_trace_begin()."""
+    lib = load_library()
+    cap = 16
+    names = (C.c_char_p * cap)()
+    launches = (C.c_int64 * cap)()
+    flops = (C.c_double * cap)()
+    ms = (C.c_double * cap)()
+    n = lib.mt2_gemm_trace_end(cap, names, launches, flops, ms)
+    if n < 0:
+        raise NativeError("gemm trace failed")
+    return [{"config": names[i].decode(), "launches": int(launches[i]), "flops": float(flops[i]), "ms": float(ms[i])}
+            for i in range(n)]
+
+
+def bench_gemm(M, N, K, taps=1, force_cfg=-1, iters=20):
+    lib = load_library()
+    ms = C.c_float(0)
+    name = C.create_string_buffer(64)
+    _check(lib.mt2_bench_gemm(_stream(), M, N, K, taps, force_cfg, iters, C.byref(ms), name, 64))
+    return ms.value, name.value.decode()

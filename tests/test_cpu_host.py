@@ -1,0 +1,146 @@
+"""CPU-side checks (no GPU): the C-ABI library builds, loads and exports every declared symbol; the
+product path fails loudly without a device; host logic (inventory, sharding, synthetic inputs)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from megatts2_amd.build import build
+    path = build(verbose=False)
+    lib = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "megatts2_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(mt2_[a-z_0-9]+)\s*\(", header)))
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/megatts2_hip.h but not exported"
+    lib.mt2_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.mt2_version()
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from megatts2_amd import config as C
+    from megatts2_amd import runtime, weights
+    with pytest.raises(runtime.NativeError):
+        runtime.device_check()
+    a = C.tiny_adm()
+    with pytest.raises(runtime.NativeError):       # no CPU fallback: constructing the model raises
+        runtime.NativeModel(adm_cfg=a, sd_adm=weights.synth_state_dict(weights.inventory_adm(a), 0, "adm."))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "megatts2_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".inc")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "megatts2_oracle" not in src and "ref_shim" not in src, f
+
+
+def test_config_struct_matches_header():
+    """ctypes mirror of mt2_config: same field order/count as include/megatts2_hip.h."""
+    from megatts2_amd.runtime import MT2Config
+    header = open(os.path.join(ROOT, "include", "megatts2_hip.h")).read()
+    body = header[header.index("typedef struct mt2_config {"):header.index("} mt2_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields, words = [], 0
+    for decl in re.findall(r"(?:int32_t|float)\s+([^;]+);", body):
+        for f in decl.split(","):
+            f = f.strip()
+            fields.append(re.sub(r"\[.*", "", f))
+            n = 1
+            for d in re.findall(r"\[(\d+)\]", f):
+                n *= int(d)
+            words += n
+    assert fields == [f[0] for f in MT2Config._fields_]
+    assert ctypes.sizeof(MT2Config) == 4 * words == 288
+
+
+def test_production_yaml_equals_builtin_configs():
+    ref = "/root/reference/configs"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not mounted")
+    from megatts2_amd import config as C
+    assert C.g_config_from_yaml(f"{ref}/config_gan.yaml") == C.production_g()
+    assert C.plm_config_from_yaml(f"{ref}/config_plm.yaml") == C.production_plm()
+    assert C.adm_config_from_yaml(f"{ref}/config_adm.yaml") == C.production_adm()
+
+
+def test_inventory_counts():
+    """G 840 tensors / 216.1 M elements, PLM 195 / 152.7 M, ADM 132 / 31.8 M."""
+    from megatts2_amd import config as C
+    from megatts2_amd import weights
+    for inv, n, elems in ((weights.inventory_g(C.production_g()), 840, 216072402),
+                          (weights.inventory_plm(C.production_plm()), 195, 152728577),
+                          (weights.inventory_adm(C.production_adm()), 132, 31783937)):
+        assert len(inv) == n
+        assert sum(int(np.prod(s)) for s in inv.values()) == elems
+    hg = weights.inventory_hifigan(C.production_hifigan())
+    assert sum(int(np.prod(s)) for s in hg.values()) == 13926017      # HiFi-GAN V1
+
+
+def test_strict_state_dict_check():
+    from megatts2_amd import config as C
+    from megatts2_amd import weights
+    inv = weights.inventory_adm(C.tiny_adm())
+    sd = weights.synth_state_dict(inv, 0, "adm.")
+    weights.check_strict(sd, inv)
+    bad = dict(sd)
+    bad.pop("predict_layer.weight")
+    with pytest.raises(KeyError):
+        weights.check_strict(bad, inv)
+    bad = dict(sd)
+    bad["extra"] = np.zeros(1, np.float32)
+    with pytest.raises(KeyError):
+        weights.check_strict(bad, inv)
+
+
+def test_synthetic_inputs_are_deterministic_and_exact():
+    from megatts2_amd import synth
+    a = synth.make_batch(synth.C2, 1002, jitter=0.3)
+    b = synth.make_batch(synth.C2, 1002, jitter=0.3)
+    assert all(np.array_equal(x.prompt_mel, y.prompt_mel) and np.array_equal(x.phone, y.phone) for x, y in zip(a, b))
+    d = synth.forced_durations(70, 431)
+    assert d.sum() == 431 and d.min() >= 1 and d.max() - d.min() <= 1
+    assert all(u.durations.sum() >= u.phone.size for u in a)
+    assert float(a[0].prompt_mel.min()) >= synth.MEL_FLOOR - 1e-6 and float(a[0].prompt_mel.max()) <= 5.0
+
+
+def test_shard_utterances_balanced_and_complete():
+    from megatts2_amd import dist as D
+    rng = np.random.default_rng(0)
+    costs = rng.uniform(1, 100, 37).tolist()
+    for world in (1, 2, 4, 8):
+        shards = D.shard_utterances(costs, world)
+        flat = sorted(i for s in shards for i in s)
+        assert flat == list(range(37))
+        sizes = [len(s) for s in shards]
+        assert max(sizes) - min(sizes) <= 1 or max(sizes) == -(-37 // world)
+        loads = [sum(costs[i] for i in s) for s in shards]
+        assert max(loads) <= 1.35 * (sum(costs) / world) + max(costs)
+
+
+def test_flop_model_matches_survey():
+    """bench.py's algorithmic FLOP model reproduces SURVEY.md 8d's per-utterance C2 figures."""
+    import bench
+    from megatts2_amd import config as C
+    from megatts2_amd import synth
+    u = synth.make_batch(synth.C2, 1002, batch=1)
+    g, p, a, h = C.production_g(), C.production_plm(), C.production_adm(), C.production_hifigan()
+    tot = {}
+    for st in ("mrte", "adm", "plm", "decoder", "vocoder"):
+        gm, at = bench.gemm_flops_model(g, a, p, h, u, [st])
+        tot[st] = (gm + at) / 1e9
+    assert abs(tot["mrte"] - 44.6) < 1.0
+    assert abs(tot["adm"] - 160.5) < 3.0
+    assert abs(tot["plm"] - 454.2) < 8.0
+    assert abs(tot["decoder"] - 10.9) < 0.3
+    assert abs(tot["vocoder"] - 264.7) < 6.0

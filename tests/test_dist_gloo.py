@@ -1,0 +1,62 @@
+"""N > 1 path on CPU: world_size-2 gloo process group, utterance sharding + all-gather of mels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.multiprocessing as mp  # noqa: E402
+
+
+class FakeTTS:
+    """Deterministic stand-in for the HIP engine (no GPU here): 'mel' of an utterance = a function of
+    its own inputs only, so the test checks sharding, ordering, padding and the collective."""
+
+    def synthesize_list(self, utts, vocoder=False):
+        lens = np.asarray([int(u.durations.sum()) for u in utts], np.int32)
+        out = torch.zeros(len(utts), int(lens.max()), 80)
+        for i, u in enumerate(utts):
+            out[i, :lens[i]] = fake_mel(u)
+        return out, lens
+
+
+def fake_mel(u):
+    n = int(u.durations.sum())
+    base = float(u.phone.sum() % 97) + float(u.prompt_mel[0, 0])
+    return torch.arange(n * 80, dtype=torch.float32).reshape(n, 80) * 1e-3 + base
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from megatts2_amd import dist as D
+    from megatts2_amd import synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    utts = synth.make_batch(synth.Shape("t", 7, 9, 30, 40), seed=5, jitter=0.5)
+    outs = D.synthesize_sharded(FakeTTS(), utts)
+    ok = all(torch.equal(o, fake_mel(u)) for o, u in zip(outs, utts))
+    # unequal local batch sizes / capacities through gather_mels
+    local = torch.full((rank + 1, 5 + rank, 80), float(rank))
+    mel_all, lens_all = D.gather_mels(local, np.arange(1, rank + 2, dtype=np.int32))
+    ok = ok and mel_all.shape == (3, 6, 80) and lens_all.tolist() == [1, 1, 2]
+    ok = ok and float(mel_all[0].max()) == 0.0 and float(mel_all[1, :6].min()) == 1.0
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharded_synthesis_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

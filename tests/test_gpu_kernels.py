@@ -1,0 +1,177 @@
+"""Kernel-level parity (GPU): the gfx950 GEMM/conv engine, LayerNorm and attention, called through the
+C ABI (mt2_op_*), against float64 numpy restatements and the oracle's ATen-primitive restatements."""
+import math
+
+import numpy as np
+import pytest
+
+import megatts2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def rt():
+    from megatts2_amd import runtime
+    runtime.device_check()
+    return runtime
+
+
+@pytest.mark.parametrize("cfg", list(range(8)) + [-1])
+@pytest.mark.parametrize("M,N,K", [(77, 96, 100), (300, 512, 256), (128, 32, 64), (33, 1024, 512)])
+def test_gemm_linear_all_tile_configs(rt, cfg, M, N, K):
+    rng = np.random.default_rng(M * 7 + N + K)
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((N, K)).astype(np.float32) / math.sqrt(K)
+    b = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    ref = np.maximum(X.astype(np.float64) @ W.T.astype(np.float64) + b, 0) * 0.5 + R
+    out = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), epi_act=rt.ACT_RELU, out_scale=0.5, force_cfg=cfg)
+    assert rel(out.cpu().numpy(), ref) < 2e-6
+
+
+def test_gemm_is_transpose_detecting(rt):
+    # asymmetric operands: a swapped C layout or operand order cannot pass
+    M, N, K = 64, 96, 32
+    X = np.zeros((M, K), np.float32)
+    X[np.arange(K), np.arange(K)] = 1.0                     # top-left identity
+    W = (np.arange(N * K, dtype=np.float32).reshape(N, K) % 97) / 97.0
+    out = rt.op_gemm(dev(X), dev(W)).cpu().numpy()
+    assert np.array_equal(out[:K], W.T.astype(np.float32))
+    assert not out[K:].any()
+
+
+@pytest.mark.parametrize("k,dil,cin,cout", [(3, 1, 80, 64), (5, 1, 64, 96), (17, 1, 32, 32), (11, 5, 32, 32),
+                                            (7, 3, 64, 64), (5, 1, 20, 96)])
+def test_gemm_conv1d_with_gaps(rt, k, dil, cin, cout):
+    """Conv1d 'same' over gap-padded rows == per-utterance zero-padded conv (batch-1 semantics)."""
+    rng = np.random.default_rng(k * 100 + dil)
+    lens = [37, 1, 64, 5]
+    G = ((k - 1) // 2) * dil + 1
+    off, rows = [], G
+    for n in lens:
+        off.append(rows)
+        rows += n + G
+    ldx = 80 if cin == 20 else cin
+    X = np.zeros((rows, ldx), np.float32)
+    valid = np.zeros(rows, np.int32)
+    w = (rng.standard_normal((cout, cin, k)) / math.sqrt(cin * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    utts = []
+    for o, n in zip(off, lens):
+        u = rng.standard_normal((n, ldx)).astype(np.float32)
+        X[o:o + n] = u
+        valid[o:o + n] = 1
+        utts.append(u)
+    wp = np.ascontiguousarray(w.transpose(0, 2, 1).reshape(cout, k * cin))       # [Cout, k*Cin]
+    out = rt.op_gemm(dev(X), dev(wp), dev(b), valid=dev(valid), shift0=-((k - 1) // 2) * dil, taps=k, dil=dil,
+                     Cin=cin, pro_act=rt.ACT_LRELU, pro_slope=0.1, ldx=ldx).cpu().numpy()
+    for o, n, u in zip(off, lens, utts):
+        ref = O.conv1d(O.leaky_relu(u[:, :cin], 0.1), w, b, padding=((k - 1) // 2) * dil, dilation=dil)
+        assert rel(out[o:o + n], ref) < 3e-6
+    assert not out[valid == 0].any()                                             # gap rows stay zero
+
+
+def test_gemm_strided_conv_rowbase(rt):
+    """MRTE middle layer: Conv1d(k=17, stride 16, pad 8) through per-row base indices."""
+    rng = np.random.default_rng(5)
+    C, k, s = 32, 17, 16
+    lens = [50, 16, 1, 97]
+    G = 8
+    off, rows = [], G
+    for n in lens:
+        off.append(rows)
+        rows += n + G
+    X = np.zeros((rows, C), np.float32)
+    utts = []
+    for o, n in zip(off, lens):
+        u = rng.standard_normal((n, C)).astype(np.float32)
+        X[o:o + n] = u
+        utts.append(u)
+    w = (rng.standard_normal((C, C, k)) / math.sqrt(C * k)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    tc = [(n - 1) // s + 1 for n in lens]
+    base, spans, r = [], [], 0
+    for o, t in zip(off, tc):
+        spans.append((r, t))
+        base += [o + j * s - s // 2 for j in range(t)]
+        r += t
+    wp = np.ascontiguousarray(w.transpose(0, 2, 1).reshape(C, k * C))
+    out = rt.op_gemm(dev(X), dev(wp), dev(b), rowbase=dev(np.asarray(base, np.int32)), taps=k, Cin=C,
+                     M=len(base)).cpu().numpy()
+    for (r0, t), u in zip(spans, utts):
+        assert rel(out[r0:r0 + t], O.conv1d(u, w, b, stride=s, padding=s // 2)) < 3e-6
+
+
+@pytest.mark.parametrize("C", [32, 64, 384, 512, 768, 1024])
+def test_layernorm(rt, C):
+    rng = np.random.default_rng(C)
+    M = 131
+    x = (rng.standard_normal((M, C)) * 3 + 1).astype(np.float32)
+    g = rng.standard_normal(C).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    R = rng.standard_normal((M, C)).astype(np.float32)
+    valid = (rng.random(M) > 0.2).astype(np.int32)
+    out = rt.op_layernorm(dev(x), dev(g), dev(b), R1=dev(R), valid=dev(valid), act=rt.ACT_RELU).cpu().numpy()
+    x64 = x.astype(np.float64)
+    ref = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * g + b
+    ref = (np.maximum(ref, 0) + R) * valid[:, None]
+    assert rel(out, ref) < 2e-6
+    assert not out[valid == 0].any()
+
+
+@pytest.mark.parametrize("H,D", [(2, 32), (16, 64), (8, 96), (2, 256), (1, 512)])
+def test_attention_ragged(rt, H, D):
+    """Non-causal attention restricted to each utterance's own rows (self- and cross-shaped)."""
+    rng = np.random.default_rng(H * 1000 + D)
+    qlens, kvlens = [33, 1, 70, 7], [17, 40, 1, 65]
+    d = H * D
+    qs = np.cumsum([0] + qlens[:-1]).astype(np.int32) + 3
+    ks = np.cumsum([0] + kvlens[:-1]).astype(np.int32) + 5
+    Q = rng.standard_normal((qs[-1] + qlens[-1] + 2, d)).astype(np.float32)
+    KV = rng.standard_normal((ks[-1] + kvlens[-1] + 2, 2 * d)).astype(np.float32)
+    kv = dev(KV)
+    out = rt.op_attention(dev(Q), kv[:, :d], kv[:, d:], dev(qs), dev(np.asarray(qlens, np.int32)), dev(ks),
+                          dev(np.asarray(kvlens, np.int32)), H, D, 1.0 / math.sqrt(D)).cpu().numpy()
+    for b in range(4):
+        q = Q[qs[b]:qs[b] + qlens[b]].astype(np.float64)
+        k = KV[ks[b]:ks[b] + kvlens[b], :d].astype(np.float64)
+        v = KV[ks[b]:ks[b] + kvlens[b], d:].astype(np.float64)
+        for h in range(H):
+            sl = slice(h * D, (h + 1) * D)
+            s = q[:, sl] @ k[:, sl].T / math.sqrt(D)
+            p = np.exp(s - s.max(1, keepdims=True))
+            ref = (p / p.sum(1, keepdims=True)) @ v[:, sl]
+            assert rel(out[qs[b]:qs[b] + qlens[b], sl], ref) < 3e-6
+
+
+def test_attention_forces_online_softmax_rescale(rt):
+    """A key tile whose scores dwarf the previous tiles' maximum exercises the rescale branch."""
+    rng = np.random.default_rng(9)
+    D, n = 64, 100
+    Q = rng.standard_normal((n, D)).astype(np.float32)
+    K = rng.standard_normal((n, D)).astype(np.float32)
+    V = rng.standard_normal((n, D)).astype(np.float32)
+    K[70] = Q[3] * 4.0                     # spike in the third key tile
+    z = np.zeros(1, np.int32)
+    ln = np.asarray([n], np.int32)
+    out = rt.op_attention(dev(Q), dev(K), dev(V), dev(z), dev(ln), dev(z), dev(ln), 1, D, 0.125).cpu().numpy()
+    s = Q.astype(np.float64) @ K.astype(np.float64).T * 0.125
+    p = np.exp(s - s.max(1, keepdims=True))
+    ref = (p / p.sum(1, keepdims=True)) @ V.astype(np.float64)
+    assert rel(out, ref) < 3e-6

@@ -150,9 +150,24 @@ __global__ void gather_rows_kernel(const float* src, int lds_, const int* map, f
         *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = v;
     }
 }
+__global__ void gather_rows_scalar_kernel(const float* src, int lds_, const int* map, float* out, int ldo, int C,
+                                          int R) {
+    const long long total = (long long)R * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / C), c = (int)(i % C);
+        const int sr = map[r];
+        out[(long long)r * ldo + c] = sr >= 0 ? src[(long long)sr * lds_ + c] : 0.0f;
+    }
+}
 hipError_t launch_gather_rows(const float* src, int lds_, const int* map, float* out, int ldo, int C, int R,
                               hipStream_t s) {
     if (R <= 0) return hipSuccess;
+    if ((C & 3) || (lds_ & 3) || (ldo & 3)) {   // odd widths: scalar path
+        hipLaunchKernelGGL(gather_rows_scalar_kernel, row_grid((long long)R * C), dim3(256), 0, s, src, lds_, map, out,
+                           ldo, C, R);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(gather_rows_kernel, row_grid((long long)R * (C >> 2)), dim3(256), 0, s, src, lds_, map, out,
                        ldo, C, R);
     return hipGetLastError();

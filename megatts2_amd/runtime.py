@@ -58,6 +58,9 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch-ROCm bundles its own HIP runtime: it must be the one already mapped when this library
+    # resolves libamdhip64, otherwise two runtimes end up in the process (and the second sees no device).
+    import torch  # noqa: F401
     path = library_path()
     if not os.path.exists(path):
         from .build import build

@@ -1,0 +1,33 @@
+#!/bin/bash
+# One GPU-box session.  usage: bash tools/gpu_round.sh [tests] [smoke] [bench] [prof] [sweep]
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+WHAT="${@:-tests smoke bench}"
+python -m megatts2_amd.build > gpurun_out/build.log 2>&1
+for w in $WHAT; do
+case $w in
+tests)
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --no-header -p no:cacheprovider --maxfail=40 -rf > gpurun_out/kernels.log 2>&1
+  echo "kernels rc=$?"; tail -3 gpurun_out/kernels.log
+  timeout 1500 python -m pytest tests/test_gpu_stages.py -m gpu -q --no-header -p no:cacheprovider --maxfail=40 -rf > gpurun_out/stages.log 2>&1
+  echo "stages rc=$?"; tail -6 gpurun_out/stages.log ;;
+smoke)
+  timeout 600 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke.log 2>&1
+  echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log ;;
+bench)
+  timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/bench.log 2>&1
+  echo "bench rc=$?"; tail -1 gpurun_out/bench.log ;;
+bench3)
+  timeout 1200 python bench.py --workload C3 --steps 2 --warmup 1 > gpurun_out/bench_c3.log 2>&1
+  echo "bench3 rc=$?"; tail -1 gpurun_out/bench_c3.log ;;
+prof)
+  rm -rf gpurun_out/prof
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline) > gpurun_out/prof.log 2>&1
+  echo "prof rc=$?"; tail -2 gpurun_out/prof.log
+  find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
+  find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete ;;
+sweep)
+  timeout 900 python tools/gemm_sweep.py > gpurun_out/gemm_sweep.txt 2>&1
+  echo "sweep rc=$?"; cat gpurun_out/gemm_sweep.txt ;;
+esac
+done

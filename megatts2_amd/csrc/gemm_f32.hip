@@ -43,6 +43,36 @@ __device__ __forceinline__ float act_rt(int act, float v, float slope) {
     }
 }
 
+// Fused epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], int g, int mw, int nw, int lane) {
+    const float* __restrict__ bias = p.bias ? p.bias + (long long)g * p.strideB : nullptr;
+    const float* __restrict__ R = p.R ? p.R + (long long)g * p.strideR : nullptr;
+    float* __restrict__ C = p.C + (long long)g * p.strideC;
+    const int epi_act = p.epi_act;
+    const float out_scale = p.out_scale;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 32 + (lane & 31);
+        const bool nok = n < p.N;
+        const float bv = (bias && nok) ? bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (nok && m < p.M) {
+                    float v = acc[i][j][e] + bv;
+                    v = act_rt(epi_act, v, 0.0f) * out_scale;
+                    if (R) v += R[(long long)m * p.ldr + n];
+                    if (p.valid && p.valid[m] == 0) v = 0.0f;
+                    C[(long long)m * p.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
 constexpr int BK = 32;   // K chunk (floats)
 constexpr int LS = 36;   // LDS row stride (floats): 144 B = 9 x 16 B -> conflict-free ds_read_b128
 
@@ -165,32 +195,182 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f32_kernel(GemmP p) {
         __syncthreads();
     }
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-    const float* __restrict__ bias = p.bias ? p.bias + (long long)g * p.strideB : nullptr;
-    const float* __restrict__ R = p.R ? p.R + (long long)g * p.strideR : nullptr;
-    float* __restrict__ C = p.C + (long long)g * p.strideC;
-    const int epi_act = p.epi_act;
-    const float out_scale = p.out_scale;
+    epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
+// ===================================================================================================
+// v2: LDS-DMA pipelined variant.  Same math, same epilogue; the operand path differs:
+//   * global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass), NST-deep ring,
+//     NST-1 chunks in flight per workgroup - the v1 kernel exposed one full L2/HBM latency per chunk
+//     whenever fewer than ~4 workgroups shared a CU (every AR-step GEMM, measured 1-60 TF/s);
+//   * the DMA writes LDS linearly (wave-uniform base + lane*16 B: one instruction = 8 rows x 128 B), so
+//     padding is impossible; bank conflicts of the MFMA operand fetch are removed with an XOR swizzle of
+//     the 16-B slot index, slot' = slot ^ ((row >> 1) & 7), applied on the SOURCE address of the DMA and on
+//     the ds_read_b128 address (the same involution on both sides);
+//   * zero fill (conv halo rows beyond the buffer, gap sentinel rows, K tail) comes from pointing the
+//     lane's source at a 16-byte zero constant; the input activation (ReLU / leaky ReLU prologue) moves
+//     to the fragment registers after the ds_read;
+//   * one raw s_barrier per chunk, preceded by a COUNTED s_waitcnt vmcnt((NST-2)*L) so younger chunks stay
+//     in flight across the barrier (hipcc's __syncthreads would drain them with vmcnt(0)).
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 lds_read_b128(unsigned byte_addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr) : "memory");
+    return v;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field on gfx9");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));   // expcnt/lgkmcnt: no wait
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST, int PRO>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_f32_dma_kernel(GemmP p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW);   // 1-KiB DMA pieces per wave per chunk
+    constexpr int L = A_IT + B_IT;
+    constexpr int STAGE = (BM + BN) * BK;                       // floats per ring stage
+    static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "piece/wave mismatch");
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NST >= 3 && (NST - 2) * L < 64, "config");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int g = blockIdx.z;
+
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+    const float* __restrict__ X = p.X + (long long)g * p.strideX;
+    const float* __restrict__ W = p.W + (long long)g * p.strideW;
+    // invalid lanes (halo beyond the buffer, gap sentinel rows, M/N/K tails) read 16 zero bytes: their
+    // element offset relative to X / W is redirected to the zero constant, branch-free
+    const long long zoff_x = (const float*)g_zero16 - X;
+    const long long zoff_w = (const float*)g_zero16 - W;
+
+    // DMA coordinates of this lane: piece row lane>>3, physical 16-B slot lane&7, logical slot = phys ^ swz(row)
+    const int lrow = lane >> 3;
+    const int kslot = ((lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7)) * 4;   // k offset inside the chunk
+    int abase[A_IT];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-        const bool nok = n < p.N;
-        const float bv = (bias && nok) ? bias[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (nok && m < p.M) {
-                    float v = acc[i][j][e] + bv;
-                    v = act_rt(epi_act, v, 0.0f) * out_scale;
-                    if (R) v += R[(long long)m * p.ldr + n];
-                    if (p.valid && p.valid[m] == 0) v = 0.0f;
-                    C[(long long)m * p.ldc + n] = v;
-                }
-            }
-        }
+    for (int j = 0; j < A_IT; ++j) {
+        const int m = m0 + (j * NW + wave) * 8 + lrow;
+        int b = kInvalidRow;
+        if (m < p.M) b = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
+        abase[j] = b;
     }
+    long long wofs[B_IT];    // element offset of the lane's weight row, or < 0 when the row is beyond N
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int n = n0 + (j * NW + wave) * 8 + lrow;
+        wofs[j] = n < p.N ? (long long)n * p.ldw : -1;
+    }
+    const int nk = (p.K + BK - 1) / BK;
+    const int ldx = p.ldx, Rx = p.Rx, Kt = p.K, Cin = p.Cin, dil = p.dil;
+    const bool multi_tap = p.taps > 1;
+    // retire the rowbase loads HERE: once DMAs are in flight hipcc can only wait for an ordinary load
+    // with vmcnt(0), which would drain the ring in the prologue
+    wait_vmcnt<0>();
+
+    auto issue = [&](int kc, int st) {
+        const int k = kc * BK + kslot;
+        const bool kok = k < Kt;
+        int tap = 0, c = k;
+        if (multi_tap) { tap = k / Cin; c = k - tap * Cin; }
+        const int shift = tap * dil;
+        float* As = smem + st * STAGE + wave * 256;            // + j*NW*256 floats per piece
+        float* Bs = As + BM * BK;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            const int src = abase[j] + shift;
+            const bool ok = kok & ((unsigned)src < (unsigned)Rx);
+            const long long off = ok ? (long long)src * ldx + c : zoff_x;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                             (__attribute__((address_space(3))) void*)(As + j * NW * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const bool ok = kok & (wofs[j] >= 0);
+            const long long off = ok ? wofs[j] + k : zoff_w;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + off),
+                                             (__attribute__((address_space(3))) void*)(Bs + j * NW * 256), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nk) issue(st, st);
+
+    const float pro_slope = p.pro_slope;
+    // MFMA operand fetch: inline-asm ds_read_b128 (a compiler-visible LDS load would make hipcc drain the
+    // DMA queue with s_waitcnt vmcnt(0) in front of it), software-pipelined one k-group ahead.
+    const int swz = (lane >> 1) & 7;                    // ((row >> 1) & 7), row = lane & 31 (+ multiples of 32)
+    const int half = lane >> 5;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+    const unsigned a_lane = lds0 + ((wm * WTM + (lane & 31)) * BK) * 4;
+    const unsigned b_lane = lds0 + ((BM + wn * WTN + (lane & 31)) * BK) * 4;
+    unsigned koff[BK / 8];
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) koff[kk] = (unsigned)(((2 * kk + half) ^ swz) * 16);
+
+    int st = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+        // chunk kc has landed once at most NST-2 younger chunks of this wave are still in flight
+        if (kc + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kc + NST - 1 < nk) issue(kc + NST - 1, st == 0 ? NST - 1 : st - 1);
+        const unsigned sa = a_lane + (unsigned)st * (STAGE * 4), sb = b_lane + (unsigned)st * (STAGE * 4);
+        f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128(sa + koff[0] + i * 32 * BK * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128(sb + koff[0] + j * 32 * BK * 4);
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < BK / 8) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read_b128(sa + koff[kk + 1] + i * 32 * BK * 4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128(sb + koff[kk + 1] + j * 32 * BK * 4);
+            }
+            if (PRO != ACT_NONE) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fa[cur][i][e] = apply_act<PRO>(fa[cur][i][e], pro_slope);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][e], fb[cur][j][e], acc[i][j], 0, 0, 0);
+        }
+        st = st + 1 == NST ? 0 : st + 1;
+    }
+    epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -198,22 +378,42 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f32_kernel(GemmP p) {
 
 struct TileCfg {
     int bm, bn, threads;
+    size_t lds;
     const char* name;
-    void (*fn)(GemmP);
+    void (*fn[3])(GemmP);     // indexed by the prologue activation (none / relu / leaky relu)
 };
 
-#define MT2_CFG(BM_, BN_, WM_, WN_) \
-    { BM_, BN_, WM_* WN_ * 64, #BM_ "x" #BN_ "_" #WM_ "x" #WN_, gemm_f32_kernel<BM_, BN_, WM_, WN_> }
+#define MT2_CFG(BM_, BN_, WM_, WN_)                                                                    \
+    { BM_, BN_, WM_* WN_ * 64, 2ull * (BM_ + BN_) * LS * sizeof(float), #BM_ "x" #BN_ "_" #WM_ "x" #WN_, \
+      { gemm_f32_kernel<BM_, BN_, WM_, WN_>, gemm_f32_kernel<BM_, BN_, WM_, WN_>,                        \
+        gemm_f32_kernel<BM_, BN_, WM_, WN_> } }
+#define MT2_DMA(BM_, BN_, WM_, WN_, NST_)                                              \
+    { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (BM_ + BN_) * BK * sizeof(float),          \
+      "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                   \
+      { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_LRELU> } }
 
 static const TileCfg kCfgs[] = {
-    MT2_CFG(128, 128, 2, 2),   // 64x64 per wave: the MFMA-bound workhorse (large M, N >= 128)
-    MT2_CFG(64, 128, 2, 2),    // 32x64 per wave
-    MT2_CFG(128, 64, 2, 2),    // 64x32 per wave
-    MT2_CFG(64, 64, 2, 2),     // 32x32 per wave: small-M AR steps, fills the chip sooner
-    MT2_CFG(32, 128, 1, 4),    // very small M (first AR steps, per-utterance heads)
-    MT2_CFG(32, 64, 1, 2),
-    MT2_CFG(128, 32, 4, 1),    // narrow N (HiFi-GAN 32-channel stage, conv_post)
-    MT2_CFG(64, 32, 2, 1),
+    // v1: register-staged double buffer (kept for A/B runs and as the reference implementation)
+    MT2_CFG(128, 128, 2, 2),   // 0
+    MT2_CFG(64, 128, 2, 2),    // 1
+    MT2_CFG(128, 64, 2, 2),    // 2
+    MT2_CFG(64, 64, 2, 2),     // 3
+    MT2_CFG(32, 128, 1, 4),    // 4
+    MT2_CFG(32, 64, 1, 2),     // 5
+    MT2_CFG(128, 32, 4, 1),    // 6
+    MT2_CFG(64, 32, 2, 1),     // 7
+    // v2: LDS-DMA ring
+    MT2_DMA(128, 128, 2, 2, 3),   // 8
+    MT2_DMA(128, 128, 2, 2, 4),   // 9
+    MT2_DMA(64, 128, 2, 2, 4),    // 10
+    MT2_DMA(64, 64, 2, 2, 4),     // 11
+    MT2_DMA(64, 64, 2, 2, 3),     // 12
+    MT2_DMA(32, 128, 1, 4, 4),    // 13
+    MT2_DMA(32, 64, 1, 2, 4),     // 14
+    MT2_DMA(128, 32, 4, 1, 4),    // 15
+    MT2_DMA(256, 128, 4, 2, 3),   // 16: 8 waves (2 per SIMD), 64x64 per wave, 43 FLOP per operand byte
+    MT2_DMA(128, 128, 4, 2, 4),   // 17: 8 waves, 32x64 per wave
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -223,7 +423,7 @@ const char* gemm_last_config() { return g_last_cfg; }
 static int g_force_cfg = -1;
 extern "C" void mt2_debug_force_gemm_config(int idx) { g_force_cfg = idx; }
 
-static bool g_attr_done[kNumCfgs] = {};
+static bool g_attr_done[kNumCfgs][3] = {};
 
 // ---- launch trace (measurement only): HIP events around every GEMM launch, on the launch stream
 struct TraceRec { int cfg; double flops; hipEvent_t e0, e1; };
@@ -259,37 +459,44 @@ extern "C" int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches
     return n;
 }
 
-// Cost model (cycles per CU-slot): a tile costs max(MFMA time, operand-fetch time) per unit of K plus
-// a fixed prologue/epilogue; the grid runs in ceil(tiles / 256) rounds (one tile per CU per round).
+// Tile choice, from tools/gemm_sweep.py on MI355X (profiles/r01_gemm_sweep_v3.txt).  Two regimes:
+//   * operand ingest: a CU sustains ~20 GB/s of global->LDS DMA however many workgroups it hosts, so a
+//     tile costs about (bm + bn) * K * 4 B / 20 GB/s; 64x64 tiles (16 FLOP per operand byte) are ingest-bound
+//     at ~85 TFLOP/s but fill the chip earliest - they win for every GEMM of the autoregressive steps
+//     (M <= ~2200 rows);
+//   * matrix issue: big tiles (32-43 FLOP/B) need >= 2 waves per SIMD to keep the MFMA pipe busy across the
+//     per-chunk barrier: the 8-wave 256x128 / 128x128 tiles reach 95-106 TFLOP/s once there are enough of
+//     them to load every CU (conv stacks, vocoder).
 static const TileCfg* choose_cfg(const GemmP& p, int* idx_out) {
-    double best = 1e300;
-    int bi = 0;
-    for (int i = 0; i < kNumCfgs; ++i) {
-        const TileCfg& c = kCfgs[i];
-        const long long tiles = (long long)((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn) * p.groups;
-        const double rounds = (double)((tiles + 255) / 256);
-        const double mfma = (double)c.bm * c.bn / 128.0;            // 128 MAC/clk/CU on f32 MFMA
-        const double fetch = (double)(c.bm + c.bn) / 3.0;            // ~12 B/clk/CU of L2->LDS staging
-        const double per_k = mfma > fetch ? mfma : fetch;
-        const double cost = rounds * (per_k * p.K + 3000.0);
-        if (cost < best) { best = cost; bi = i; }
-    }
+    int bi = 12;                                                        // dma64x64_2x2_s3
+    const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.groups;
+    const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.groups;
+    if (p.N <= 32) bi = 15;                                             // dma128x32_4x1_s4
+    else if (t256 >= 400) bi = 16;                                      // dma256x128_4x2_s3
+    else if (t128 >= 400) bi = 17;                                      // dma128x128_4x2_s4
     if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs) bi = g_force_cfg;
     *idx_out = bi;
     return &kCfgs[bi];
 }
 
-hipError_t launch_gemm(const GemmP& p, hipStream_t s) {
+static int g_debug_mode = 0;
+extern "C" void mt2_debug_gemm_mode(int mode) { g_debug_mode = mode; }
+
+hipError_t launch_gemm(const GemmP& p_in, hipStream_t s) {
+    GemmP p = p_in;
+    p.debug = g_debug_mode;
     if (p.M <= 0 || p.N <= 0 || p.groups <= 0) return hipSuccess;
     if ((p.Cin & 3) || (p.ldx & 3) || (p.ldw & 3) || p.K != p.taps * p.Cin) return hipErrorInvalidValue;
     int idx = 0;
     const TileCfg* c = choose_cfg(p, &idx);
-    const size_t lds = 2ull * (c->bm + c->bn) * LS * sizeof(float);
-    if (!g_attr_done[idx]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(c->fn),
+    const size_t lds = c->lds;
+    if (p.pro_act < 0 || p.pro_act > ACT_LRELU) return hipErrorInvalidValue;
+    void (*fn)(GemmP) = c->fn[p.pro_act];
+    if (!g_attr_done[idx][p.pro_act]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        g_attr_done[idx] = true;
+        g_attr_done[idx][p.pro_act] = true;
     }
     const int tiles = ((p.M + c->bm - 1) / c->bm) * ((p.N + c->bn - 1) / c->bn);
     dim3 grid(tiles, 1, p.groups), block(c->threads);
@@ -300,12 +507,12 @@ hipError_t launch_gemm(const GemmP& p, hipStream_t s) {
         r.flops = 2.0 * p.M * p.N * p.K * p.groups;
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return hipErrorUnknown;
         (void)hipEventRecord(r.e0, s);
-        hipLaunchKernelGGL(c->fn, grid, block, lds, s, p);
+        hipLaunchKernelGGL(fn, grid, block, lds, s, p);
         (void)hipEventRecord(r.e1, s);
         g_trace.push_back(r);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(c->fn, grid, block, lds, s, p);
+    hipLaunchKernelGGL(fn, grid, block, lds, s, p);
     return hipGetLastError();
 }
 

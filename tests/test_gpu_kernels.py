@@ -32,7 +32,7 @@ def rt():
     return runtime
 
 
-@pytest.mark.parametrize("cfg", list(range(8)) + [-1])
+@pytest.mark.parametrize("cfg", list(range(18)) + [-1])
 @pytest.mark.parametrize("M,N,K", [(77, 96, 100), (300, 512, 256), (128, 32, 64), (33, 1024, 512)])
 def test_gemm_linear_all_tile_configs(rt, cfg, M, N, K):
     rng = np.random.default_rng(M * 7 + N + K)
@@ -56,9 +56,10 @@ def test_gemm_is_transpose_detecting(rt):
     assert not out[K:].any()
 
 
+@pytest.mark.parametrize("cfg", [-1, 3, 8, 11, 13, 15])
 @pytest.mark.parametrize("k,dil,cin,cout", [(3, 1, 80, 64), (5, 1, 64, 96), (17, 1, 32, 32), (11, 5, 32, 32),
                                             (7, 3, 64, 64), (5, 1, 20, 96)])
-def test_gemm_conv1d_with_gaps(rt, k, dil, cin, cout):
+def test_gemm_conv1d_with_gaps(rt, k, dil, cin, cout, cfg):
     """Conv1d 'same' over gap-padded rows == per-utterance zero-padded conv (batch-1 semantics)."""
     rng = np.random.default_rng(k * 100 + dil)
     lens = [37, 1, 64, 5]
@@ -80,14 +81,15 @@ def test_gemm_conv1d_with_gaps(rt, k, dil, cin, cout):
         utts.append(u)
     wp = np.ascontiguousarray(w.transpose(0, 2, 1).reshape(cout, k * cin))       # [Cout, k*Cin]
     out = rt.op_gemm(dev(X), dev(wp), dev(b), valid=dev(valid), shift0=-((k - 1) // 2) * dil, taps=k, dil=dil,
-                     Cin=cin, pro_act=rt.ACT_LRELU, pro_slope=0.1, ldx=ldx).cpu().numpy()
+                     Cin=cin, pro_act=rt.ACT_LRELU, pro_slope=0.1, ldx=ldx, force_cfg=cfg).cpu().numpy()
     for o, n, u in zip(off, lens, utts):
         ref = O.conv1d(O.leaky_relu(u[:, :cin], 0.1), w, b, padding=((k - 1) // 2) * dil, dilation=dil)
         assert rel(out[o:o + n], ref) < 3e-6
     assert not out[valid == 0].any()                                             # gap rows stay zero
 
 
-def test_gemm_strided_conv_rowbase(rt):
+@pytest.mark.parametrize("cfg", [-1, 3, 9, 12, 14])
+def test_gemm_strided_conv_rowbase(rt, cfg):
     """MRTE middle layer: Conv1d(k=17, stride 16, pad 8) through per-row base indices."""
     rng = np.random.default_rng(5)
     C, k, s = 32, 17, 16
@@ -113,7 +115,7 @@ def test_gemm_strided_conv_rowbase(rt):
         r += t
     wp = np.ascontiguousarray(w.transpose(0, 2, 1).reshape(C, k * C))
     out = rt.op_gemm(dev(X), dev(wp), dev(b), rowbase=dev(np.asarray(base, np.int32)), taps=k, Cin=C,
-                     M=len(base)).cpu().numpy()
+                     M=len(base), force_cfg=cfg).cpu().numpy()
     for (r0, t), u in zip(spans, utts):
         assert rel(out[r0:r0 + t], O.conv1d(u, w, b, stride=s, padding=s // 2)) < 3e-6
 

@@ -101,6 +101,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--thresh", default="", help="debug: tile-choice thresholds 'ks4_tiles,ks2_tiles,m32_rows'")
     args = ap.parse_args()
 
     import torch
@@ -133,6 +134,9 @@ def main() -> None:
     sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.") if full else None
     sd_h = weights.synth_state_dict(weights.inventory_hifigan(h), 0, "hifigan.") if full else None
     model = NativeModel(g, p, a, h, sd_g, sd_p, sd_a, sd_h)
+    if args.thresh:
+        t = [int(v) for v in args.thresh.split(",")]
+        model.lib.mt2_debug_set_thresholds(t[0], t[1], t[2])
 
     shape = {"C1": synth.C1, "C2": synth.C2, "C3": synth.C3}[args.workload]
     B = args.batch or shape.B

@@ -15,6 +15,13 @@
 //                   alpha[q] is lane-local.
 // Wide heads are split across the waves of a workgroup along d (<= 128 columns = 64 accumulator
 // VGPRs per wave); each wave recomputes S (cheap: these heads only occur in the tiny cross-attention).
+//
+// Two kernels: attn_f32_reg_kernel<D> for head dims <= 128 (every autoregressive step of the ADM / PLM:
+// 8x96, 16x64) keeps the Q fragments in registers for the whole kernel, issues ALL loads of a key tile
+// (K fragments, V columns) before the first MFMA and prefetches the next tile's K fragments while the
+// current tile is on the matrix pipe - these launches are latency-bound (<= 3 key tiles, one wave per
+// (utterance, head, 32 queries)), so what matters is that a tile costs one memory round trip, not D/8.
+// attn_f32_kernel<DT> is the streaming form for the wide heads (2x256 phone encoder, 1x512 cross).
 #include "mt2_kernels.h"
 #include <math.h>
 
@@ -39,6 +46,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
     const bool qok = qrow < ql;
     const float* __restrict__ qptr =
         p.Q + (long long)(qs + (qok ? qrow : qt * 32)) * p.ldq + h * D + 4 * half;
+    const int os = p.o_start ? p.o_start[b] : (p.q_start ? qs : b * (p.u_ostride ? p.u_ostride : p.u_qstride));
     const int d0 = wave * DT * 32;
     const float scale = p.scale;
 
@@ -99,7 +107,122 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
     }
     if (!qok) return;
     const float inv = 1.0f / l_run;
-    float* __restrict__ orow = p.O + (long long)(qs + qrow) * p.ldo + h * D + d0 + 4 * half;
+    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo + h * D + d0 + 4 * half;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            float4 v;
+            v.x = o[t][4 * e4 + 0] * inv;
+            v.y = o[t][4 * e4 + 1] * inv;
+            v.z = o[t][4 * e4 + 2] * inv;
+            v.w = o[t][4 * e4 + 3] * inv;
+            *reinterpret_cast<float4*>(orow + t * 32 + 8 * e4) = v;
+        }
+}
+
+// Register-resident form for D <= 128 (see the file header).  One wave per block.
+template <int D>
+__global__ __launch_bounds__(64) void attn_f32_reg_kernel(AttnP p) {
+    constexpr int NF = D / 8;      // float4 fragments per row along the head dim
+    constexpr int DT = D / 32;     // 32-column output tiles
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+    int qs, ql, ks, kl;
+    if (p.q_start) {
+        qs = p.q_start[b]; ql = p.q_len[b]; ks = p.kv_start[b]; kl = p.kv_len[b];
+    } else {
+        qs = b * p.u_qstride; ql = p.u_qlen; ks = b * p.u_kvstride; kl = p.u_kvlen;
+    }
+    if (qt * 32 >= ql || kl <= 0) return;
+    const int os = p.o_start ? p.o_start[b] : (p.q_start ? qs : b * (p.u_ostride ? p.u_ostride : p.u_qstride));
+    const int qrow = qt * 32 + l31;
+    const bool qok = qrow < ql;
+    const float scale = p.scale;
+
+    float4 qf[NF], kf[NF], kn[NF];
+    {
+        const float* __restrict__ qptr =
+            p.Q + (long long)(qs + (qok ? qrow : qt * 32)) * p.ldq + h * D + 4 * half;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) qf[f] = *reinterpret_cast<const float4*>(qptr + 8 * f);
+    }
+    auto load_k = [&](int kv0, float4 (&dst)[NF]) {
+        const int kvrow = kv0 + l31;
+        const float* __restrict__ kptr =
+            p.K + (long long)(ks + (kvrow < kl ? kvrow : kv0)) * p.ldk + h * D + 4 * half;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) dst[f] = *reinterpret_cast<const float4*>(kptr + 8 * f);
+    };
+    load_k(0, kf);
+
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.0f;
+
+    for (int kv0 = 0; kv0 < kl; kv0 += 32) {
+        // every load of this tile (V columns) and the next tile's K fragments go out before the first MFMA
+        float vr[DT][16];
+        const float* __restrict__ vcol = p.V + h * D + l31;
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                vr[t][e] = kvr < kl ? vcol[(long long)(ks + kvr) * p.ldv + t * 32] : 0.0f;
+            }
+        const bool more = kv0 + 32 < kl;
+        if (more) load_k(kv0 + 32, kn);
+
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.0f;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].x, qf[f].x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].y, qf[f].y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].z, qf[f].z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].w, qf[f].w, s, 0, 0, 0);
+        }
+        // s[e] = S^T[kv0 + (e&3) + 8*(e>>2) + 4*half][q = l31]
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            s[e] = kvr < kl ? s[e] * scale : -INFINITY;
+            mloc = fmaxf(mloc, s[e]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);          // finite: key kv0 is always in range
+        const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
+        float lsum = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[e] = expf(s[e] - m_new);
+            lsum += s[e];
+        }
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[t][e], s[e], o[t], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) kf[f] = kn[f];
+        }
+    }
+    if (!qok) return;
+    const float inv = 1.0f / l_run;
+    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo + h * D + 4 * half;
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -116,6 +239,16 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
 hipError_t launch_attention(const AttnP& p, hipStream_t s) {
     if (p.B <= 0 || p.H <= 0 || p.max_qlen <= 0) return hipSuccess;
     if (p.D % 32 != 0 || (p.ldq & 3) || (p.ldk & 3) || (p.ldo & 3)) return hipErrorInvalidValue;
+    if (p.D <= 128) {
+        dim3 grid((p.max_qlen + 31) / 32, p.H, p.B), block(64);
+        switch (p.D) {
+            case 32: hipLaunchKernelGGL(attn_f32_reg_kernel<32>, grid, block, 0, s, p); break;
+            case 64: hipLaunchKernelGGL(attn_f32_reg_kernel<64>, grid, block, 0, s, p); break;
+            case 96: hipLaunchKernelGGL(attn_f32_reg_kernel<96>, grid, block, 0, s, p); break;
+            default: hipLaunchKernelGGL(attn_f32_reg_kernel<128>, grid, block, 0, s, p); break;
+        }
+        return hipGetLastError();
+    }
     const int tiles = p.D / 32;
     int nw = (p.D + 127) / 128;
     while (nw <= 4 && tiles % nw != 0) ++nw;

@@ -44,8 +44,11 @@ __device__ __forceinline__ float act_rt(int act, float v, float slope) {
 }
 
 // Fused epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], int g, int mw, int nw, int lane) {
+// EPG < 16: only accumulator elements e with e / EPG == esel are written (the K-split reduction shares the
+// 16 elements of a 32x32 tile among the K groups; esel is wave-uniform).
+template <int TM, int TN, int EPG = 16>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], int g, int mw, int nw, int lane,
+                                         int esel = 0) {
     const float* __restrict__ bias = p.bias ? p.bias + (long long)g * p.strideB : nullptr;
     const float* __restrict__ R = p.R ? p.R + (long long)g * p.strideR : nullptr;
     float* __restrict__ C = p.C + (long long)g * p.strideC;
@@ -60,6 +63,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], 
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                if (EPG < 16 && e / EPG != esel) continue;
                 const int m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (nok && m < p.M) {
                     float v = acc[i][j][e] + bv;
@@ -226,20 +230,29 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));   // expcnt/lgkmcnt: no wait
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, int PRO>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_f32_dma_kernel(GemmP p) {
-    constexpr int NW = WGM * WGN;
+// KS > 1: in-workgroup K split.  The workgroup holds KS groups of WGM x WGN waves; group kg walks the chunks
+// kg, kg+KS, kg+2KS, ... through its OWN ring and all groups meet at the one barrier per round.  This puts
+// KS waves on every SIMD even when the launch has fewer tiles than the chip has CUs (every GEMM of the
+// autoregressive steps): one wave's barrier / DMA-issue / ds_read bubble is covered by its neighbours' MFMAs
+// and the serial MFMA chain of a tile shrinks KS-fold.  The partial tiles are summed through LDS in a FIXED
+// order (deterministic) and each group writes 16/KS of the accumulator elements in the fused epilogue.
+template <int BM, int BN, int WGM, int WGN, int KS, int NST, int PRO>
+__global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP p) {
+    constexpr int NW = WGM * WGN;                               // waves of one K group
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW);   // 1-KiB DMA pieces per wave per chunk
     constexpr int L = A_IT + B_IT;
-    constexpr int STAGE = (BM + BN) * BK;                       // floats per ring stage
+    constexpr int STAGE = (BM + BN) * BK;                       // floats per ring stage (of one K group)
     static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "piece/wave mismatch");
-    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NST >= 3 && (NST - 2) * L < 64, "config");
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64, "config");
+    static_assert(KS == 1 || (TM == 1 && TN == 1 && 16 % KS == 0), "K split: one 32x32 tile per wave");
+    static_assert(KS * NW <= 16, "at most 16 waves per workgroup");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kg = wave_all / NW, wave = wave_all % NW;
     const int wm = wave / WGN, wn = wave % WGN;
     const int g = blockIdx.z;
 
@@ -274,19 +287,21 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f32_dma_kernel(GemmP p) {
         wofs[j] = n < p.N ? (long long)n * p.ldw : -1;
     }
     const int nk = (p.K + BK - 1) / BK;
+    const int nr = (nk + KS - 1) / KS;        // rounds; group kg owns chunk r*KS + kg of round r (zeros past K)
     const int ldx = p.ldx, Rx = p.Rx, Kt = p.K, Cin = p.Cin, dil = p.dil;
     const bool multi_tap = p.taps > 1;
     // retire the rowbase loads HERE: once DMAs are in flight hipcc can only wait for an ordinary load
     // with vmcnt(0), which would drain the ring in the prologue
     wait_vmcnt<0>();
 
-    auto issue = [&](int kc, int st) {
-        const int k = kc * BK + kslot;
+    float* ring = smem + kg * (NST * STAGE);
+    auto issue = [&](int rd, int st) {
+        const int k = (rd * KS + kg) * BK + kslot;
         const bool kok = k < Kt;
         int tap = 0, c = k;
         if (multi_tap) { tap = k / Cin; c = k - tap * Cin; }
         const int shift = tap * dil;
-        float* As = smem + st * STAGE + wave * 256;            // + j*NW*256 floats per piece
+        float* As = ring + st * STAGE + wave * 256;            // + j*NW*256 floats per piece
         float* Bs = As + BM * BK;
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
@@ -315,14 +330,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f32_dma_kernel(GemmP p) {
 
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
-        if (st < nk) issue(st, st);
+        if (st < nr) issue(st, st);
 
     const float pro_slope = p.pro_slope;
     // MFMA operand fetch: inline-asm ds_read_b128 (a compiler-visible LDS load would make hipcc drain the
     // DMA queue with s_waitcnt vmcnt(0) in front of it), software-pipelined one k-group ahead.
     const int swz = (lane >> 1) & 7;                    // ((row >> 1) & 7), row = lane & 31 (+ multiples of 32)
     const int half = lane >> 5;
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)ring;
     const unsigned a_lane = lds0 + ((wm * WTM + (lane & 31)) * BK) * 4;
     const unsigned b_lane = lds0 + ((BM + wn * WTN + (lane & 31)) * BK) * 4;
     unsigned koff[BK / 8];
@@ -330,13 +345,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f32_dma_kernel(GemmP p) {
     for (int kk = 0; kk < BK / 8; ++kk) koff[kk] = (unsigned)(((2 * kk + half) ^ swz) * 16);
 
     int st = 0;
-    for (int kc = 0; kc < nk; ++kc) {
-        // chunk kc has landed once at most NST-2 younger chunks of this wave are still in flight
-        if (kc + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();
+    for (int rd = 0; rd < nr; ++rd) {
+        // round rd has landed once at most NST-2 younger rounds of this wave are still in flight
+        if (rd + NST - 2 < nr) wait_vmcnt<(NST - 2) * L>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kc + NST - 1 < nk) issue(kc + NST - 1, st == 0 ? NST - 1 : st - 1);
+        if (rd + NST - 1 < nr) issue(rd + NST - 1, st == 0 ? NST - 1 : st - 1);
         const unsigned sa = a_lane + (unsigned)st * (STAGE * 4), sb = b_lane + (unsigned)st * (STAGE * 4);
         f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -370,7 +385,27 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f32_dma_kernel(GemmP p) {
         }
         st = st + 1 == NST ? 0 : st + 1;
     }
-    epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    if constexpr (KS > 1) {
+        // sum the KS partial tiles through LDS (ring memory is free: every DMA has been waited for and the
+        // barrier below orders the last operand reads), fixed order kg = 0..KS-1
+        constexpr int EPG = 16 / KS;
+        __syncthreads();
+        float* red = smem + ((kg * NW + wave) * 16) * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[e * 64] = acc[0][0][e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (e / EPG != kg) continue;
+            float v = 0.0f;
+#pragma unroll
+            for (int g2 = 0; g2 < KS; ++g2) v += smem[(((g2 * NW + wave) * 16) + e) * 64 + lane];
+            acc[0][0][e] = v;
+        }
+        epilogue<TM, TN, EPG>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane, kg);
+    } else {
+        epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -390,8 +425,13 @@ struct TileCfg {
 #define MT2_DMA(BM_, BN_, WM_, WN_, NST_)                                              \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (BM_ + BN_) * BK * sizeof(float),          \
       "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                   \
-      { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_LRELU> } }
+      { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_RELU>, \
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_LRELU> } }
+#define MT2_DMAK(BM_, BN_, WM_, WN_, KS_, NST_)                                                        \
+    { BM_, BN_, WM_* WN_ * KS_ * 64, (size_t)KS_ * NST_ * (BM_ + BN_) * BK * sizeof(float),              \
+      "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "_s" #NST_,                                        \
+      { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_RELU>, \
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_LRELU> } }
 
 static const TileCfg kCfgs[] = {
     // v1: register-staged double buffer (kept for A/B runs and as the reference implementation)
@@ -414,6 +454,12 @@ static const TileCfg kCfgs[] = {
     MT2_DMA(128, 32, 4, 1, 4),    // 15
     MT2_DMA(256, 128, 4, 2, 3),   // 16: 8 waves (2 per SIMD), 64x64 per wave, 43 FLOP per operand byte
     MT2_DMA(128, 128, 4, 2, 4),   // 17: 8 waves, 32x64 per wave
+    // v2 + in-workgroup K split (one 32x32 tile per wave, KS waves per SIMD)
+    MT2_DMAK(64, 64, 2, 2, 2, 2),   // 18:  8 waves,  64 KiB LDS (2 workgroups per CU)
+    MT2_DMAK(64, 64, 2, 2, 2, 4),   // 19:  8 waves, 128 KiB
+    MT2_DMAK(64, 64, 2, 2, 4, 2),   // 20: 16 waves, 128 KiB
+    MT2_DMAK(32, 64, 1, 2, 4, 3),   // 21:  8 waves, 144 KiB, 32-row tiles for the first AR steps
+    MT2_DMAK(32, 64, 1, 2, 4, 2),   // 22:  8 waves,  96 KiB
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -467,13 +513,24 @@ extern "C" int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches
 //   * matrix issue: big tiles (32-43 FLOP/B) need >= 2 waves per SIMD to keep the MFMA pipe busy across the
 //     per-chunk barrier: the 8-wave 256x128 / 128x128 tiles reach 95-106 TFLOP/s once there are enough of
 //     them to load every CU (conv stacks, vocoder).
+//   * chain / fill (AR steps): a launch with fewer 64x64 tiles than the chip has CUs leaves one workgroup per
+//     CU at best, and a 4-wave tile then runs at the pace of ONE wave per SIMD: serial chain K/2 x 64 cycles
+//     plus an exposed barrier + DMA-issue + ds_read bubble per chunk (measured ~1 us per 32-wide chunk vs
+//     0.43 us of MFMA).  The K-split tiles put 2-4 waves on each SIMD of the same CU instead.
+static int g_t_ks4 = 320, g_t_ks2 = 640, g_m32 = 32;   // thresholds (64x64 tiles / rows), tools/gemm_sweep.py
+extern "C" void mt2_debug_set_thresholds(int t_ks4, int t_ks2, int m32) { g_t_ks4 = t_ks4; g_t_ks2 = t_ks2; g_m32 = m32; }
+
 static const TileCfg* choose_cfg(const GemmP& p, int* idx_out) {
     int bi = 12;                                                        // dma64x64_2x2_s3
+    const long long t64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.groups;
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.groups;
     const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.groups;
     if (p.N <= 32) bi = 15;                                             // dma128x32_4x1_s4
     else if (t256 >= 400) bi = 16;                                      // dma256x128_4x2_s3
     else if (t128 >= 400) bi = 17;                                      // dma128x128_4x2_s4
+    else if (p.M <= g_m32) bi = 21;                                     // dma32x64_1x2_k4_s3
+    else if (t64 <= g_t_ks4) bi = 20;                                   // dma64x64_2x2_k4_s2
+    else if (t64 <= g_t_ks2) bi = 18;                                   // dma64x64_2x2_k2_s2
     if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs) bi = g_force_cfg;
     *idx_out = bi;
     return &kCfgs[bi];

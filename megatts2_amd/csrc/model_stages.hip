@@ -195,6 +195,89 @@ static void encoder_layer(const Ctx& c, const EncW& e, const EncLayerW& w, float
     }
 }
 
+// ---- autoregressive-step forms of the encoder layer (Linear-FF encoders only).  Both are exact
+// identities of TransformerEncoderLayer.forward, not approximations:
+//
+// LAST layer: only row n-1 of each sequence is consumed downstream (models/megatts2.py:178,272).  LayerNorm
+// and the K/V projections are row-wise and needed for all rows; attention row i depends on query row i only,
+// and out-projection, norm2 and the feed-forward are row-wise - so Q, attention, out-proj, LN2 and FF are
+// evaluated for the A last rows only.  x: [A*n, d] compact step rows; y: [A, d] result rows.
+static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, const float* x, int n, int A,
+                               const EncScratch& s, float* y) {
+    MT2_REQUIRE(!e.conv_ff, "AR step layers use the Linear feed-forward");
+    const int d = e.d, M = A * n, D = d / e.heads;
+    layernorm(c, x, d, w.ln1g, w.ln1b, M, d, s.h, d);
+    float* kv = s.qkv;                                   // [M, 2d]: K | V
+    linear(c, s.h, d, M, w.wqkv + (size_t)d * d, w.bqkv + d, 2 * d, d, kv, 2 * d);
+    float* q = s.att;                                    // [A, d]
+    float* att = s.att + (size_t)A * d;                  // [A, d]
+    {
+        GemmP p{};
+        p.X = s.h; p.ldx = d; p.Rx = M; p.a_mul = n; p.shift0 = n - 1; p.Cin = d; p.W = w.wqkv; p.bias = w.bqkv;
+        p.C = q; p.ldc = d; p.M = A; p.N = d;
+        gemm(c, p);
+    }
+    AttnP a{};
+    a.Q = q; a.ldq = d; a.K = kv; a.ldk = 2 * d; a.V = kv + d; a.ldv = 2 * d; a.O = att; a.ldo = d;
+    a.u_qstride = 1; a.u_qlen = 1; a.u_kvstride = n; a.u_kvlen = n; a.B = A; a.H = e.heads; a.D = D; a.max_qlen = 1;
+    a.scale = 1.0f / std::sqrt((float)D);
+    MT2_HIP(launch_attention(a, c.s));
+    // y = x[last rows] + out_proj(att): the residual rows sit n*d floats apart starting at row n-1
+    linear(c, att, d, A, w.wo, w.bo, d, d, y, d, x + (size_t)(n - 1) * d, n * d);
+    float* h2 = s.h;                                     // [A, d] (LN1 output no longer needed)
+    layernorm(c, y, d, w.ln2g, w.ln2b, A, d, h2, d);
+    linear(c, h2, d, A, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, nullptr, 0, nullptr, ACT_RELU);
+    linear(c, s.f, e.ff, A, w.ff1w, w.ff1b, d, e.ff, y, d, y, d);
+}
+
+// FIRST layer: its input rows (embeddings + positional table of positions < t) never change between steps,
+// so LN1 -> QKV of position i is computed once, at step i, into a per-sequence cache with a FIXED row
+// stride (slot j owns rows [j*cs, j*cs + n)); every later step only adds row n-1.  Attention reads the
+// cache and writes compact rows; the rest of the layer is the ordinary full-row form.
+static void encoder_layer_first_cached(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int n, int A,
+                                       float* qkv_cache, int cs, const EncScratch& s) {
+    MT2_REQUIRE(!e.conv_ff, "AR step layers use the Linear feed-forward");
+    const int d = e.d, M = A * n, D = d / e.heads;
+    // LN1 + QKV of the newest row of every active sequence
+    {
+        LnP p{};
+        p.x = x + (size_t)(n - 1) * d; p.ldx = n * d; p.gamma = w.ln1g; p.beta = w.ln1b;
+        p.out = s.h; p.ldo = d; p.M = A; p.C = d; p.eps = 1e-5f; p.act = ACT_NONE;
+        MT2_HIP(launch_layernorm(p, c.s));
+    }
+    {
+        GemmP p{};
+        p.X = s.h; p.ldx = d; p.Rx = A; p.Cin = d; p.W = w.wqkv; p.bias = w.bqkv;
+        p.C = qkv_cache + (size_t)(n - 1) * 3 * d; p.ldc = cs * 3 * d; p.M = A; p.N = 3 * d;
+        gemm(c, p);
+    }
+    AttnP a{};
+    a.Q = qkv_cache; a.ldq = 3 * d; a.K = qkv_cache + d; a.ldk = 3 * d; a.V = qkv_cache + 2 * d; a.ldv = 3 * d;
+    a.O = s.att; a.ldo = d;
+    a.u_qstride = cs; a.u_qlen = n; a.u_kvstride = cs; a.u_kvlen = n; a.u_ostride = n;
+    a.B = A; a.H = e.heads; a.D = D; a.max_qlen = n; a.scale = 1.0f / std::sqrt((float)D);
+    MT2_HIP(launch_attention(a, c.s));
+    linear(c, s.att, d, M, w.wo, w.bo, d, d, x, d, x, d);
+    layernorm(c, x, d, w.ln2g, w.ln2b, M, d, s.h, d);
+    linear(c, s.h, d, M, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, nullptr, 0, nullptr, ACT_RELU);
+    linear(c, s.f, e.ff, M, w.ff1w, w.ff1b, d, e.ff, x, d, x, d);
+}
+
+// One AR step of an encoder over A sequences of n positions (x: [A*n, d], overwritten); the rows the head
+// needs (position n-1 of each sequence) are returned as a [A, d] matrix.
+static const float* ar_step_layers(const Ctx& c, const EncW& e, float* x, int n, int A, float* qkv_cache, int cs,
+                                   const EncScratch& sc, float* ylast) {
+    const int L = (int)e.layers.size();
+    AttnGeom g;
+    g.u_stride = n; g.u_len = n; g.B = A; g.max_len = n;
+    for (int l = 0; l < L; ++l) {
+        if (l == L - 1) encoder_layer_last(c, e, e.layers[l], x, n, A, sc, ylast);
+        else if (l == 0 && qkv_cache) encoder_layer_first_cached(c, e, e.layers[l], x, n, A, qkv_cache, cs, sc);
+        else encoder_layer(c, e, e.layers[l], x, A * n, g, nullptr, sc);
+    }
+    return ylast;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // stage timers (HIP events on the caller's stream)
 
@@ -386,17 +469,17 @@ static void adm_run(const Ctx& c, const float* tc, int ld_tc, int tc_rows, const
     MT2_HIP(hipMemsetAsync(p, 0, sizeof(float) * B * pstride, c.s));                    // p_code starts at 0.0 (:262)
     const int Mmax = B * ord.nmax;
     float* x = c.ws.get<float>((size_t)Mmax * d);
-    EncScratch sc = enc_scratch(c, e, Mmax);
+    EncScratch sc = enc_scratch(c, e, std::max(Mmax, 2 * B));   // last layer: q | att rows of A sequences
+    float* ylast = c.ws.get<float>((size_t)B * d);
+    float* qkv0 = e.layers.size() >= 2 ? c.ws.get<float>((size_t)Mmax * 3 * d) : nullptr;   // layer-0 QKV cache
     int A = B;
     for (int t = 0; t < ord.nmax; ++t) {
         while (A > 0 && ord.len[A - 1] <= t) --A;
-        const int n = t + 1, M = A * n;
+        const int n = t + 1;
         MT2_HIP(launch_adm_step_input(tcemb, Dc, ip.dev(o_tcrow), m.adm_wdt, p, pstride, m.pe_adm, x, Dc, De, n, A,
                                       c.s));
-        AttnGeom g;
-        g.u_stride = n; g.u_len = n; g.B = A; g.max_len = n;
-        for (auto& lw : e.layers) encoder_layer(c, e, lw, x, M, g, nullptr, sc);
-        MT2_HIP(launch_adm_predict(x, d, m.adm_wpred, p, pstride, n, A, c.s));
+        const float* y = ar_step_layers(c, e, x, n, A, qkv0, ord.nmax, sc, ylast);
+        MT2_HIP(launch_adm_predict(y, d, m.adm_wpred, p, pstride, n, 1, A, c.s));
     }
     MT2_HIP(launch_adm_finalize(p, pstride, ip.dev(o_len), ip.dev(o_slot), dur_out, flt_out, dstride, B,
                                 dstride < ord.nmax ? dstride : ord.nmax, c.s));
@@ -429,19 +512,19 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
     const int Mmax = B * ord.nmax;
     float* x = c.ws.get<float>((size_t)Mmax * d);
     float* logits = c.ws.get<float>((size_t)B * NB);
-    EncScratch sc = enc_scratch(c, e, Mmax);
+    EncScratch sc = enc_scratch(c, e, std::max(Mmax, 2 * B));   // last layer: q | att rows of A sequences
+    float* ylast = c.ws.get<float>((size_t)B * d);
+    float* qkv0 = e.layers.size() >= 2 ? c.ws.get<float>((size_t)Mmax * 3 * d) : nullptr;   // layer-0 QKV cache
     int A = B;
     for (int t = 0; t < ord.nmax; ++t) {
         while (A > 0 && ord.len[A - 1] <= t) --A;
-        const int n = t + 1, M = A * n;
+        const int n = t + 1;
         MT2_HIP(launch_plm_step_input(cond, ld_c, ip.dev(o_crow), m.plm_emb, codes, cstride, m.pe_plm, x, Dc, De, n,
                                       A, c.s));
-        AttnGeom g;
-        g.u_stride = n; g.u_len = n; g.B = A; g.max_len = n;
-        for (auto& lw : e.layers) encoder_layer(c, e, lw, x, M, g, nullptr, sc);
+        const float* y = ar_step_layers(c, e, x, n, A, qkv0, ord.nmax, sc, ylast);
         // predict_layer on the last position of each sequence only (:178 takes [:, -1:]), then argmax
         GemmP p{};
-        p.X = x; p.ldx = d; p.Rx = M; p.a_mul = n; p.shift0 = n - 1; p.Cin = d; p.W = m.plm_wpred;
+        p.X = y; p.ldx = d; p.Rx = A; p.Cin = d; p.W = m.plm_wpred;
         p.C = logits; p.ldc = NB; p.M = A; p.N = NB;
         gemm(c, p);
         MT2_HIP(launch_argmax_rows(logits, NB, NB, codes, cstride, n, A, c.s));

@@ -56,11 +56,12 @@ hipError_t launch_layernorm(const LnP& p, hipStream_t s);
 //   Q rows of utterance b: [q_start[b], q_start[b]+q_len[b]) in Q (ld ldq), head h at column h*D.
 //   K/V likewise with kv_start/kv_len.  If q_start == nullptr the batch is uniform:
 //   start = b * u_qstride (q) / b * u_kvstride (kv), len = u_qlen / u_kvlen.
+//   Output rows: o_start[b] + i (default q_start), uniform: b * u_ostride + i (default u_qstride).
 struct AttnP {
     const float* Q; int ldq; const float* K; int ldk; const float* V; int ldv;
     float* O; int ldo;
-    const int* q_start; const int* q_len; const int* kv_start; const int* kv_len;
-    int u_qstride, u_qlen, u_kvstride, u_kvlen;
+    const int* q_start; const int* q_len; const int* kv_start; const int* kv_len; const int* o_start;
+    int u_qstride, u_qlen, u_kvstride, u_kvlen, u_ostride;
     int B, H, D, max_qlen; float scale;
 };
 hipError_t launch_attention(const AttnP& p, hipStream_t s);
@@ -95,8 +96,9 @@ hipError_t launch_adm_step_input(const float* tc_emb, int ld_tc, const int* tc_r
 hipError_t launch_plm_step_input(const float* cond, int ld_c, const int* cond_row, const float* emb,
                                  const int64_t* codes, int cstride, const float* pe, float* x, int Dc, int De,
                                  int n, int A, hipStream_t s);
-// ADM head: p[j*pstride + n] = dot(x[j*n + n-1, 0:D], w)      (predict_layer, last position only)
-hipError_t launch_adm_predict(const float* x, int D, const float* w, float* p, int pstride, int n, int A,
+// ADM head: p[j*pstride + n] = dot(x[j*xn + xn-1, 0:D], w)    (predict_layer, last position only; xn = rows
+// per sequence in x: n for the full step matrix, 1 for the last-row matrix of the last layer)
+hipError_t launch_adm_predict(const float* x, int D, const float* w, float* p, int pstride, int n, int xn, int A,
                               hipStream_t s);
 // dur[i] = clamp(trunc(p + 0.5), 1, 128)  (models/megatts2.py:275)
 hipError_t launch_adm_finalize(const float* p, int pstride, const int* lens, const int* slot_b, int32_t* dur,

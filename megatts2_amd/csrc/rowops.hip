@@ -366,11 +366,11 @@ hipError_t launch_plm_step_input(const float* cond, int ld_c, const int* cond_ro
 
 // MegaADM predict_layer on the last position only (models/megatts2.py:272): one wave per sequence
 __global__ __launch_bounds__(256) void adm_predict_kernel(const float* x, int D, const float* w, float* p,
-                                                          int pstride, int n, int A) {
+                                                          int pstride, int n, int xn, int A) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x * 4 + wave;
     if (j >= A) return;
-    const float* xr = x + ((long long)j * n + (n - 1)) * D;
+    const float* xr = x + ((long long)j * xn + (xn - 1)) * D;
     float s = 0.0f;
     for (int c = lane * 4; c < D; c += 256) {
         const float4 a = *reinterpret_cast<const float4*>(xr + c);
@@ -380,10 +380,10 @@ __global__ __launch_bounds__(256) void adm_predict_kernel(const float* x, int D,
     s = wave_sum(s);
     if (lane == 0) p[(long long)j * pstride + n] = s;
 }
-hipError_t launch_adm_predict(const float* x, int D, const float* w, float* p, int pstride, int n, int A,
+hipError_t launch_adm_predict(const float* x, int D, const float* w, float* p, int pstride, int n, int xn, int A,
                               hipStream_t s) {
     if (A <= 0) return hipSuccess;
-    hipLaunchKernelGGL(adm_predict_kernel, dim3((A + 3) / 4), dim3(256), 0, s, x, D, w, p, pstride, n, A);
+    hipLaunchKernelGGL(adm_predict_kernel, dim3((A + 3) / 4), dim3(256), 0, s, x, D, w, p, pstride, n, xn, A);
     return hipGetLastError();
 }
 

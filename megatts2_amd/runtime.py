@@ -450,7 +450,7 @@ def gemm_trace_begin() -> None:
 def gemm_trace_end():
     """-> list of dicts {config, launches, flops, ms} for the launches since gemm_trace_begin()."""
     lib = load_library()
-    cap = 16
+    cap = 32
     names = (C.c_char_p * cap)()
     launches = (C.c_int64 * cap)()
     flops = (C.c_double * cap)()
@@ -462,9 +462,9 @@ def gemm_trace_end():
             for i in range(n)]
 
 
-def bench_gemm(M, N, K, taps=1, force_cfg=-1, iters=20):
+def bench_gemm(M, N, K, taps=1, force_cfg=-1, iters=20, w_copies=1):
     lib = load_library()
     ms = C.c_float(0)
     name = C.create_string_buffer(64)
-    _check(lib.mt2_bench_gemm(_stream(), M, N, K, taps, force_cfg, iters, C.byref(ms), name, 64))
+    _check(lib.mt2_bench_gemm(_stream(), M, N, K, taps, force_cfg, iters, w_copies, C.byref(ms), name, 64))
     return ms.value, name.value.decode()

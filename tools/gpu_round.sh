@@ -22,12 +22,29 @@ bench3)
   echo "bench3 rc=$?"; tail -1 gpurun_out/bench_c3.log ;;
 prof)
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline) > gpurun_out/prof.log 2>&1
-  echo "prof rc=$?"; tail -2 gpurun_out/prof.log
-  find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -25 "$f"
-  find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete ;;
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline) > gpurun_out/prof.log 2>&1
+  echo "prof rc=$?"; tail -2 gpurun_out/prof.log | cut -c1-400
+  f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/prof_kernel_stats.csv && head -30 "$f"
+  find gpurun_out/prof -name "*kernel_trace.csv" -size +8M -delete ;;
 sweep)
   timeout 900 python tools/gemm_sweep.py > gpurun_out/gemm_sweep.txt 2>&1
   echo "sweep rc=$?"; cat gpurun_out/gemm_sweep.txt ;;
+sweep_ar)
+  timeout 600 python tools/gemm_sweep.py ar > gpurun_out/gemm_sweep_ar.txt 2>&1
+  echo "sweep_ar rc=$?"; cat gpurun_out/gemm_sweep_ar.txt ;;
+thresh)
+  for t in 0,0,0 512,1024,32; do
+    timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --thresh $t > gpurun_out/bench_t_$t.log 2>&1
+    echo "thresh $t rc=$?"; tail -1 gpurun_out/bench_t_$t.log | cut -c1-400
+  done ;;
+pmc)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/pmc_$c
+    (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline) > gpurun_out/pmc_$c.log 2>&1
+    echo "pmc $c rc=$?"; tail -1 gpurun_out/pmc_$c.log | cut -c1-300
+    f=$(find gpurun_out/pmc_$c -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python tools/pmc_summary.py "$f" 2 gpurun_out/pmc_$c.md | tail -8
+    find gpurun_out/pmc_$c -name "*.csv" -size +8M -delete
+  done ;;
 esac
 done

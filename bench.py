@@ -102,6 +102,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--thresh", default="", help="debug: tile-choice thresholds 'ks4_tiles,ks2_tiles,m32_rows'")
+    ap.add_argument("--ar-groups", type=int, default=0, help="AR stream groups (default: the library's, 2)")
     args = ap.parse_args()
 
     import torch
@@ -134,6 +135,8 @@ def main() -> None:
     sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.") if full else None
     sd_h = weights.synth_state_dict(weights.inventory_hifigan(h), 0, "hifigan.") if full else None
     model = NativeModel(g, p, a, h, sd_g, sd_p, sd_a, sd_h)
+    if args.ar_groups:
+        model.set_ar_groups(args.ar_groups)
     if args.thresh:
         t = [int(v) for v in args.thresh.split(",")]
         model.lib.mt2_debug_set_thresholds(t[0], t[1], t[2])
@@ -207,17 +210,31 @@ def main() -> None:
         result["stage_ms"] = {k: round(v, 3) for k, v in model.last_stage_ms().items()}
         model.set_profiling(False)
         alg_gemm, alg_attn = gemm_flops_model(g, a, p, h, utts, stages)
-        t_ms = sum(r["ms"] for r in tr)
+        uni = [r for r in tr if r["config"] == "union"]
+        tr = [r for r in tr if r["config"] != "union"]
+        sum_ms = sum(r["ms"] for r in tr)
+        # engine-busy time = union of the launch intervals (AR stream groups overlap launches of two chains)
+        t_ms = uni[0]["ms"] if uni else sum_ms
         n_launch = sum(r["launches"] for r in tr)
         exe = sum(r["flops"] for r in tr)
         achieved = alg_gemm / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", f"r01_pmc_{args.workload.lower()}_latest.json")
+        if os.path.exists(pmc_path):
+            pm = json.load(open(pmc_path))["gemm_engine"]
+            traffic = {"bytes_per_launch": round((pm["read_gb_per_step_corrected"] + pm["write_gb_per_step"]) * 1e9
+                                                 / pm["launches_per_step"]),
+                       "read_gb_per_step": pm["read_gb_per_step_corrected"], "write_gb_per_step": pm["write_gb_per_step"],
+                       "source": os.path.relpath(pmc_path, ROOT)}
         result["roofline"] = {
-            "bound": "mfma", "kernel": "gemm_f32_kernel<*> (implicit-GEMM conv/linear engine, f32 MFMA)",
+            "bound": "mfma", "kernel": "gemm_f32_dma_kernel<*> (implicit-GEMM conv/linear engine, f32 MFMA)",
             "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "launches_per_step": n_launch, "avg_launch_us": round(t_ms * 1e3 / max(n_launch, 1), 2),
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "launches_per_step": n_launch, "avg_launch_us": round(sum_ms * 1e3 / max(n_launch, 1), 2),
             "algorithmic_gflop_per_step": round(alg_gemm / 1e9, 1), "executed_gflop_per_step": round(exe / 1e9, 1),
             "attention_gflop_per_step": round(alg_attn / 1e9, 1), "gemm_ms_per_step": round(t_ms, 3),
+            "gemm_ms_sum_of_launches": round(sum_ms, 3),
+            "step_frac": round(alg_gemm / (ms_per_step * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
             "per_config": [{"config": r["config"], "launches": r["launches"], "ms": round(r["ms"], 3),
                             "tflops": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2)} for r in tr],
         }

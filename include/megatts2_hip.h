@@ -149,6 +149,11 @@ int mt2_synthesize_batch(mt2_model* m, void* stream, const int64_t* phone, const
                          int flags, float* mel, int Tm_cap, int32_t* mel_lens /*host*/, int32_t* dur_out,
                          int64_t* codes_out, float* wav);
 
+/* ---- tuning: the sequences of an autoregressive run (mt2_adm_infer / mt2_plm_infer / the AR stages of
+ * mt2_synthesize_batch) are dealt into `groups` independent kernel chains on internal HIP streams that fork
+ * from and join back into `stream` (default 2; 1 = everything on `stream`).  Results do not depend on it. */
+int mt2_set_ar_groups(mt2_model* m, int groups);
+
 /* ---- measurement support: time (ms, HIP events on `stream`) spent in each stage of the last
  * mt2_synthesize_batch when profiling was enabled with mt2_set_profiling(m, 1).
  * names: "mrte", "adm", "regulate", "plm", "decoder", "vocoder".  Returns the number of stages. */
@@ -168,8 +173,9 @@ int mt2_op_attention(void* stream, const float* Q, int ldq, const float* K, int 
                      const int32_t* kv_len, int B, int H, int D, int max_qlen, float scale);
 /* Launch trace of the GEMM/conv engine (measurement only): between begin and end every launch is
  * bracketed by HIP events on its own stream.  end() reports, per tile configuration, the number of
- * launches, the executed FLOPs (2*M*N*K*groups) and the summed kernel time in ms; returns the
- * number of configurations written (<= cap). */
+ * launches, the executed FLOPs (2*M*N*K*groups) and the summed kernel time in ms, plus a last entry named
+ * "union" = length of the union of all launch intervals (launches on different internal streams overlap);
+ * returns the number of entries written (<= cap). */
 int mt2_gemm_trace_begin(void);
 int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches, double* flops, double* ms);
 /* time `iters` back-to-back launches of one GEMM with HIP events on `stream`, cycling through `w_copies`

@@ -20,6 +20,8 @@
 // residual add, gap-row mask, all fused.
 #include "mt2_kernels.h"
 
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 namespace mt2 {
@@ -351,16 +353,21 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (rd + NST - 1 < nr) issue(rd + NST - 1, st == 0 ? NST - 1 : st - 1);
+        // first operand fetch of this round goes out BEFORE the address arithmetic of the next DMA issue, so
+        // its LDS latency is covered by that VALU work instead of adding to it
         const unsigned sa = a_lane + (unsigned)st * (STAGE * 4), sb = b_lane + (unsigned)st * (STAGE * 4);
         f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128(sa + koff[0] + i * 32 * BK * 4);
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128(sb + koff[0] + j * 32 * BK * 4);
+        if (rd + NST - 1 < nr) issue(rd + NST - 1, st == 0 ? NST - 1 : st - 1);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1;
+            // fences on both sides: hipcc otherwise hoists this wait into the previous group's MFMAs, right behind
+            // the reads it waits for
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if (kk + 1 < BK / 8) {
@@ -369,6 +376,9 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128(sb + koff[kk + 1] + j * 32 * BK * 4);
             }
+            // pin the fetch of group kk+1 ABOVE the MFMAs of group kk (hipcc otherwise sinks the asm reads below
+            // them and the s_waitcnt of the next group then exposes the whole LDS latency, every group)
+            __builtin_amdgcn_sched_barrier(0);
             if (PRO != ACT_NONE) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -482,22 +492,41 @@ extern "C" int mt2_gemm_trace_begin(void) {
     g_trace_on = true;
     return 0;
 }
-// Per tile configuration: launches, executed FLOPs (2*M*N*K*groups) and summed kernel time (ms).
+// Per tile configuration: launches, executed FLOPs (2*M*N*K*groups) and summed kernel time (ms).  When the
+// launches ran on several streams (AR stream groups) their intervals overlap; a last pseudo-entry named
+// "union" carries the length of the UNION of all launch intervals (= time during which at least one engine
+// kernel was running), the right denominator for a whole-engine throughput.
 extern "C" int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches, double* flops, double* ms) {
     g_trace_on = false;
     int n = 0;
+    std::vector<std::pair<double, double>> iv;
+    double fl_all = 0.0;
     for (int i = 0; i < kNumCfgs && n < cap; ++i) {
         int64_t cnt = 0;
         double fl = 0.0, t = 0.0;
         for (auto& r : g_trace) {
             if (r.cfg != i) continue;
             if (hipEventSynchronize(r.e1) != hipSuccess) return -1;
-            float dt = 0.f;
+            float dt = 0.f, t0 = 0.f;
             if (hipEventElapsedTime(&dt, r.e0, r.e1) != hipSuccess) return -1;
+            if (hipEventElapsedTime(&t0, g_trace.front().e0, r.e0) != hipSuccess) return -1;
+            iv.emplace_back((double)t0, (double)t0 + dt);
             ++cnt; fl += r.flops; t += dt;
         }
         if (cnt == 0) continue;
         names[n] = kCfgs[i].name; launches[n] = cnt; flops[n] = fl; ms[n] = t;
+        fl_all += fl;
+        ++n;
+    }
+    if (n < cap && !iv.empty()) {
+        std::sort(iv.begin(), iv.end());
+        double uni = 0.0, lo = iv[0].first, hi = iv[0].second;
+        for (auto& x : iv) {
+            if (x.first > hi) { uni += hi - lo; lo = x.first; hi = x.second; }
+            else if (x.second > hi) hi = x.second;
+        }
+        uni += hi - lo;
+        names[n] = "union"; launches[n] = (int64_t)iv.size(); flops[n] = fl_all; ms[n] = uni;
         ++n;
     }
     for (auto& r : g_trace) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -517,18 +546,24 @@ extern "C" int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches
 //     CU at best, and a 4-wave tile then runs at the pace of ONE wave per SIMD: serial chain K/2 x 64 cycles
 //     plus an exposed barrier + DMA-issue + ds_read bubble per chunk (measured ~1 us per 32-wide chunk vs
 //     0.43 us of MFMA).  The K-split tiles put 2-4 waves on each SIMD of the same CU instead.
-static int g_t_ks4 = 320, g_t_ks2 = 640, g_m32 = 32;   // thresholds (64x64 tiles / rows), tools/gemm_sweep.py
-extern "C" void mt2_debug_set_thresholds(int t_ks4, int t_ks2, int m32) { g_t_ks4 = t_ks4; g_t_ks2 = t_ks2; g_m32 = m32; }
+static int g_t_ks4 = 256, g_t_ks2 = 640, g_t32 = 256;   // thresholds in tiles, from tools/gemm_sweep.py
+extern "C" void mt2_debug_set_thresholds(int t_ks4, int t_ks2, int t32) { g_t_ks4 = t_ks4; g_t_ks2 = t_ks2; g_t32 = t32; }
 
+// A CU retires one 64x64 tile of K=768 in ~12 us whatever the launch looks like, so for the AR-step shapes the
+// choice is about how many CUs get a tile and how many tiles the busiest CU gets (profiles/r01_gemm_sweep_ar_*):
+//   32x64 K-split tiles while they fit one per CU; 64x64 K-split tiles while THEY fit one (k4) / two (k2) per CU;
+//   a big 8-wave tile when its tile count just fills the chip once (200..256); otherwise plain 64x64 tiles
+//   (three workgroups per CU, de-phased) and the 8-wave tiles for the conv stacks and the vocoder.
 static const TileCfg* choose_cfg(const GemmP& p, int* idx_out) {
     int bi = 12;                                                        // dma64x64_2x2_s3
+    const long long t32 = (long long)((p.M + 31) / 32) * ((p.N + 63) / 64) * p.groups;
     const long long t64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.groups;
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.groups;
     const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.groups;
     if (p.N <= 32) bi = 15;                                             // dma128x32_4x1_s4
-    else if (t256 >= 400) bi = 16;                                      // dma256x128_4x2_s3
-    else if (t128 >= 400) bi = 17;                                      // dma128x128_4x2_s4
-    else if (p.M <= g_m32) bi = 21;                                     // dma32x64_1x2_k4_s3
+    else if (t256 >= 400 || (t256 >= 200 && t256 <= 256)) bi = 16;      // dma256x128_4x2_s3
+    else if (t128 >= 400 || (t128 >= 200 && t128 <= 256)) bi = 17;      // dma128x128_4x2_s4
+    else if (t32 <= g_t32) bi = 22;                                     // dma32x64_1x2_k4_s2
     else if (t64 <= g_t_ks4) bi = 20;                                   // dma64x64_2x2_k4_s2
     else if (t64 <= g_t_ks2) bi = 18;                                   // dma64x64_2x2_k2_s2
     if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs) bi = g_force_cfg;

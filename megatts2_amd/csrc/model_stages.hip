@@ -447,6 +447,48 @@ static ArOrder ar_order(const int* lens, int B) {
     return o;
 }
 
+// ---- stream groups.  The sequences of an AR run are dealt round-robin (in length order) into G groups and
+// every group runs its own step loop on its own HIP stream.  Nothing changes arithmetically - sequences are
+// independent (batch-1 semantics) - but two independent kernel chains are in flight: one chain's launch
+// boundary, workgroup-tail and prologue bubbles (~5 us fixed per launch, and the idle CUs of a launch whose
+// tile count is not a multiple of the chip) are filled by the other chain's kernels.
+struct ArGroups {
+    int G = 1;
+    std::vector<std::vector<int>> slots;   // group -> positions in the length-sorted order
+    std::vector<hipStream_t> stream;
+};
+static ArGroups ar_groups(mt2_model& m, hipStream_t main, const ArOrder& ord, int B) {
+    ArGroups g;
+    g.G = std::max(1, std::min(m.ar_groups, B));
+    g.slots.resize(g.G);
+    for (int j = 0; j < B; ++j) g.slots[j % g.G].push_back(j);
+    while ((int)m.aux_streams.size() < g.G - 1) {
+        hipStream_t s;
+        MT2_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        m.aux_streams.push_back(s);
+    }
+    if (!m.ev_fork) MT2_HIP(hipEventCreateWithFlags(&m.ev_fork, hipEventDisableTiming));
+    while ((int)m.ev_join.size() < g.G - 1) {
+        hipEvent_t e;
+        MT2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m.ev_join.push_back(e);
+    }
+    g.stream.push_back(main);
+    for (int i = 1; i < g.G; ++i) g.stream.push_back(m.aux_streams[i - 1]);
+    return g;
+}
+static void ar_fork(mt2_model& m, const ArGroups& g) {
+    if (g.G <= 1) return;
+    MT2_HIP(hipEventRecord(m.ev_fork, g.stream[0]));
+    for (int i = 1; i < g.G; ++i) MT2_HIP(hipStreamWaitEvent(g.stream[i], m.ev_fork, 0));
+}
+static void ar_join(mt2_model& m, const ArGroups& g) {
+    for (int i = 1; i < g.G; ++i) {
+        MT2_HIP(hipEventRecord(m.ev_join[i - 1], g.stream[i]));
+        MT2_HIP(hipStreamWaitEvent(g.stream[0], m.ev_join[i - 1], 0));
+    }
+}
+
 // MegaADM.infer (models/megatts2.py:257-275).  tc: rows buffer (ld), utterance b's first row row0[b].
 static void adm_run(const Ctx& c, const float* tc, int ld_tc, int tc_rows, const std::vector<int>& row0,
                     const int* lens, int B, int32_t* dur_out, float* flt_out, int dstride) {
@@ -456,33 +498,64 @@ static void adm_run(const Ctx& c, const float* tc, int ld_tc, int tc_rows, const
     const int d = e.d, Dc = cfg.adm_tc_emb_dim, De = cfg.adm_emb_dim;
     ArOrder ord = ar_order(lens, B);
     MT2_REQUIRE(ord.nmax <= cfg.max_positions, "ADM sequence longer than the positional table");
+    ArGroups grp = ar_groups(m, c.s, ord, B);
+    struct Grp {
+        int B, nmax, A; int o_tcrow, o_len, o_slot;
+        std::vector<int> len;
+        float *p, *x, *ylast, *qkv0; EncScratch sc;
+    };
+    std::vector<Grp> gs(grp.G);
     IntPlan ip;
-    std::vector<int> tcrow(B);
-    for (int j = 0; j < B; ++j) tcrow[j] = row0[ord.slot_b[j]];
-    const int o_tcrow = ip.add(tcrow), o_len = ip.add(ord.len), o_slot = ip.add(ord.slot_b);
+    for (int g = 0; g < grp.G; ++g) {
+        Grp& q = gs[g];
+        q.B = (int)grp.slots[g].size();
+        std::vector<int> tcrow, slot;
+        for (int j : grp.slots[g]) {
+            tcrow.push_back(row0[ord.slot_b[j]]);
+            q.len.push_back(ord.len[j]);
+            slot.push_back(ord.slot_b[j]);
+        }
+        q.nmax = q.len[0];
+        q.A = q.B;
+        q.o_tcrow = ip.add(tcrow); q.o_len = ip.add(q.len); q.o_slot = ip.add(slot);
+    }
     ip.upload(c.ws, c.s);
 
     float* tcemb = c.ws.get<float>((size_t)tc_rows * Dc);
     linear(c, tc, ld_tc, tc_rows, m.adm_wtc, nullptr, Dc, cfg.adm_tc_dim, tcemb, Dc);   // tc_linear_emb (no bias)
     const int pstride = ord.nmax + 1;
-    float* p = c.ws.get<float>((size_t)B * pstride);
-    MT2_HIP(hipMemsetAsync(p, 0, sizeof(float) * B * pstride, c.s));                    // p_code starts at 0.0 (:262)
-    const int Mmax = B * ord.nmax;
-    float* x = c.ws.get<float>((size_t)Mmax * d);
-    EncScratch sc = enc_scratch(c, e, std::max(Mmax, 2 * B));   // last layer: q | att rows of A sequences
-    float* ylast = c.ws.get<float>((size_t)B * d);
-    float* qkv0 = e.layers.size() >= 2 ? c.ws.get<float>((size_t)Mmax * 3 * d) : nullptr;   // layer-0 QKV cache
-    int A = B;
-    for (int t = 0; t < ord.nmax; ++t) {
-        while (A > 0 && ord.len[A - 1] <= t) --A;
-        const int n = t + 1;
-        MT2_HIP(launch_adm_step_input(tcemb, Dc, ip.dev(o_tcrow), m.adm_wdt, p, pstride, m.pe_adm, x, Dc, De, n, A,
-                                      c.s));
-        const float* y = ar_step_layers(c, e, x, n, A, qkv0, ord.nmax, sc, ylast);
-        MT2_HIP(launch_adm_predict(y, d, m.adm_wpred, p, pstride, n, 1, A, c.s));
+    float* p_all = c.ws.get<float>((size_t)B * pstride);
+    MT2_HIP(hipMemsetAsync(p_all, 0, sizeof(float) * B * pstride, c.s));                // p_code starts at 0.0 (:262)
+    int pofs = 0;
+    for (Grp& q : gs) {
+        const int Mmax = q.B * q.nmax;
+        q.p = p_all + (size_t)pofs * pstride;
+        pofs += q.B;
+        q.x = c.ws.get<float>((size_t)Mmax * d);
+        q.sc = enc_scratch(c, e, std::max(Mmax, 2 * q.B));   // last layer: q | att rows of A sequences
+        q.ylast = c.ws.get<float>((size_t)q.B * d);
+        q.qkv0 = e.layers.size() >= 2 ? c.ws.get<float>((size_t)Mmax * 3 * d) : nullptr;   // layer-0 QKV cache
     }
-    MT2_HIP(launch_adm_finalize(p, pstride, ip.dev(o_len), ip.dev(o_slot), dur_out, flt_out, dstride, B,
-                                dstride < ord.nmax ? dstride : ord.nmax, c.s));
+    ar_fork(m, grp);
+    for (int t = 0; t < ord.nmax; ++t) {
+        const int n = t + 1;
+        for (int g = 0; g < grp.G; ++g) {
+            Grp& q = gs[g];
+            while (q.A > 0 && q.len[q.A - 1] <= t) --q.A;
+            if (q.A == 0) continue;
+            Ctx cg{m, grp.stream[g], c.ws};
+            MT2_HIP(launch_adm_step_input(tcemb, Dc, ip.dev(q.o_tcrow), m.adm_wdt, q.p, pstride, m.pe_adm, q.x, Dc, De,
+                                          n, q.A, cg.s));
+            const float* y = ar_step_layers(cg, e, q.x, n, q.A, q.qkv0, q.nmax, q.sc, q.ylast);
+            MT2_HIP(launch_adm_predict(y, d, m.adm_wpred, q.p, pstride, n, 1, q.A, cg.s));
+        }
+    }
+    for (int g = 0; g < grp.G; ++g) {
+        Grp& q = gs[g];
+        MT2_HIP(launch_adm_finalize(q.p, pstride, ip.dev(q.o_len), ip.dev(q.o_slot), dur_out, flt_out, dstride, q.B,
+                                    dstride < q.nmax ? dstride : q.nmax, grp.stream[g]));
+    }
+    ar_join(m, grp);
 }
 
 // MegaPLM.infer (models/megatts2.py:165-181).  cond rows buffer (ld), utterance b's first row row0[b].
@@ -494,47 +567,79 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
     const int d = e.d, Dc = cfg.plm_tc_dim, De = cfg.plm_vq_dim, NB = cfg.plm_bins;
     ArOrder ord = ar_order(lens, B);
     MT2_REQUIRE(ord.nmax <= cfg.max_positions, "PLM sequence longer than the positional table");
+    MT2_REQUIRE(1024 < cfg.plm_bins + 2, "pc_embedding too small for the BOS id 1024");
+    ArGroups grp = ar_groups(m, c.s, ord, B);
+    struct Grp {
+        int B, nmax, A; int o_crow, o_len, o_slot;
+        std::vector<int> len, slot;
+        int64_t* codes; float *x, *ylast, *qkv0, *logits; EncScratch sc;
+    };
+    std::vector<Grp> gs(grp.G);
     IntPlan ip;
-    std::vector<int> crow(B);
-    for (int j = 0; j < B; ++j) crow[j] = row0[ord.slot_b[j]];
-    const int o_crow = ip.add(crow), o_len = ip.add(ord.len), o_slot = ip.add(ord.slot_b);
+    for (int g = 0; g < grp.G; ++g) {
+        Grp& q = gs[g];
+        q.B = (int)grp.slots[g].size();
+        std::vector<int> crow;
+        for (int j : grp.slots[g]) {
+            crow.push_back(row0[ord.slot_b[j]]);
+            q.len.push_back(ord.len[j]);
+            q.slot.push_back(ord.slot_b[j]);
+        }
+        q.nmax = q.len[0];
+        q.A = q.B;
+        q.o_crow = ip.add(crow); q.o_len = ip.add(q.len); q.o_slot = ip.add(q.slot);
+    }
     ip.upload(c.ws, c.s);
 
     const int cstride = ord.nmax + 1;
-    int64_t* codes = c.ws.get<int64_t>((size_t)B * cstride);
+    int64_t* codes_all = c.ws.get<int64_t>((size_t)B * cstride);
     {
         std::vector<int64_t> init((size_t)B * cstride, 0);
         for (int j = 0; j < B; ++j) init[(size_t)j * cstride] = 1024;   // BOS literal, models/megatts2.py:170
-        MT2_HIP(hipMemcpyAsync(codes, init.data(), init.size() * sizeof(int64_t), hipMemcpyHostToDevice, c.s));
+        MT2_HIP(hipMemcpyAsync(codes_all, init.data(), init.size() * sizeof(int64_t), hipMemcpyHostToDevice, c.s));
         MT2_HIP(hipStreamSynchronize(c.s));   // `init` is a stack temporary
     }
-    MT2_REQUIRE(1024 < cfg.plm_bins + 2, "pc_embedding too small for the BOS id 1024");
-    const int Mmax = B * ord.nmax;
-    float* x = c.ws.get<float>((size_t)Mmax * d);
-    float* logits = c.ws.get<float>((size_t)B * NB);
-    EncScratch sc = enc_scratch(c, e, std::max(Mmax, 2 * B));   // last layer: q | att rows of A sequences
-    float* ylast = c.ws.get<float>((size_t)B * d);
-    float* qkv0 = e.layers.size() >= 2 ? c.ws.get<float>((size_t)Mmax * 3 * d) : nullptr;   // layer-0 QKV cache
-    int A = B;
-    for (int t = 0; t < ord.nmax; ++t) {
-        while (A > 0 && ord.len[A - 1] <= t) --A;
-        const int n = t + 1;
-        MT2_HIP(launch_plm_step_input(cond, ld_c, ip.dev(o_crow), m.plm_emb, codes, cstride, m.pe_plm, x, Dc, De, n,
-                                      A, c.s));
-        const float* y = ar_step_layers(c, e, x, n, A, qkv0, ord.nmax, sc, ylast);
-        // predict_layer on the last position of each sequence only (:178 takes [:, -1:]), then argmax
-        GemmP p{};
-        p.X = y; p.ldx = d; p.Rx = A; p.Cin = d; p.W = m.plm_wpred;
-        p.C = logits; p.ldc = NB; p.M = A; p.N = NB;
-        gemm(c, p);
-        MT2_HIP(launch_argmax_rows(logits, NB, NB, codes, cstride, n, A, c.s));
-        if (last_logits)
-            for (int j = 0; j < A; ++j)
-                MT2_HIP(hipMemcpyAsync(last_logits + ((size_t)ord.slot_b[j] * logit_tmax + t) * NB,
-                                       logits + (size_t)j * NB, sizeof(float) * NB, hipMemcpyDeviceToDevice, c.s));
+    int cofs = 0;
+    for (Grp& q : gs) {
+        const int Mmax = q.B * q.nmax;
+        q.codes = codes_all + (size_t)cofs * cstride;
+        cofs += q.B;
+        q.x = c.ws.get<float>((size_t)Mmax * d);
+        q.logits = c.ws.get<float>((size_t)q.B * NB);
+        q.sc = enc_scratch(c, e, std::max(Mmax, 2 * q.B));   // last layer: q | att rows of A sequences
+        q.ylast = c.ws.get<float>((size_t)q.B * d);
+        q.qkv0 = e.layers.size() >= 2 ? c.ws.get<float>((size_t)Mmax * 3 * d) : nullptr;   // layer-0 QKV cache
     }
-    MT2_HIP(launch_plm_finalize(codes, cstride, ip.dev(o_len), ip.dev(o_slot), codes_out, ostride, B,
-                                ostride < ord.nmax ? ostride : ord.nmax, c.s));
+    ar_fork(m, grp);
+    for (int t = 0; t < ord.nmax; ++t) {
+        const int n = t + 1;
+        for (int g = 0; g < grp.G; ++g) {
+            Grp& q = gs[g];
+            while (q.A > 0 && q.len[q.A - 1] <= t) --q.A;
+            if (q.A == 0) continue;
+            Ctx cg{m, grp.stream[g], c.ws};
+            MT2_HIP(launch_plm_step_input(cond, ld_c, ip.dev(q.o_crow), m.plm_emb, q.codes, cstride, m.pe_plm, q.x, Dc,
+                                          De, n, q.A, cg.s));
+            const float* y = ar_step_layers(cg, e, q.x, n, q.A, q.qkv0, q.nmax, q.sc, q.ylast);
+            // predict_layer on the last position of each sequence only (:178 takes [:, -1:]), then argmax
+            GemmP p{};
+            p.X = y; p.ldx = d; p.Rx = q.A; p.Cin = d; p.W = m.plm_wpred;
+            p.C = q.logits; p.ldc = NB; p.M = q.A; p.N = NB;
+            gemm(cg, p);
+            MT2_HIP(launch_argmax_rows(q.logits, NB, NB, q.codes, cstride, n, q.A, cg.s));
+            if (last_logits)
+                for (int j = 0; j < q.A; ++j)
+                    MT2_HIP(hipMemcpyAsync(last_logits + ((size_t)q.slot[j] * logit_tmax + t) * NB,
+                                           q.logits + (size_t)j * NB, sizeof(float) * NB, hipMemcpyDeviceToDevice,
+                                           cg.s));
+        }
+    }
+    for (int g = 0; g < grp.G; ++g) {
+        Grp& q = gs[g];
+        MT2_HIP(launch_plm_finalize(q.codes, cstride, ip.dev(q.o_len), ip.dev(q.o_slot), codes_out, ostride, q.B,
+                                    ostride < q.nmax ? ostride : q.nmax, grp.stream[g]));
+    }
+    ar_join(m, grp);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -124,6 +124,12 @@ struct mt2_model {
     std::vector<mt2::UpW> hg_up;
     std::vector<mt2::ResW> hg_res;
 
+    // AR stream groups (model_stages.hip): sequences are split into `ar_groups` independent kernel chains
+    int ar_groups = 2;
+    std::vector<hipStream_t> aux_streams;
+    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> ev_join;
+
     bool profiling = false;
     std::vector<std::string> stage_names;
     std::vector<float> stage_ms;

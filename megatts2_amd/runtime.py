@@ -392,7 +392,10 @@ class NativeModel:
             return mel, mel_lens, {"dur": dur_out, "codes": codes_out, "wav": wav}
         return mel, mel_lens
 
-    # ---- measurement
+    # ---- tuning / measurement
+    def set_ar_groups(self, groups: int) -> None:
+        _check(self.lib.mt2_set_ar_groups(self.h, int(groups)))
+
     def set_profiling(self, on: bool) -> None:
         _check(self.lib.mt2_set_profiling(self.h, 1 if on else 0))
 

@@ -94,6 +94,26 @@ def test_tiny_adm(tiny_batch):
     assert d3.shape == (1, tiny_batch[0]["tc_latent"].shape[0], 1) and d3.dtype == torch.int32
 
 
+@pytest.mark.parametrize("groups", [1, 2, 3])
+def test_tiny_ar_stream_groups_do_not_change_results(tiny_batch, groups):
+    """The AR loops split the batch into independent kernel chains on internal streams (mt2_set_ar_groups);
+    every grouping must give the reference's discrete outputs and the same floats."""
+    tts = model("tiny")
+    tts.native.set_ar_groups(groups)
+    try:
+        tc, ln = pad_stack([z["tc_latent"] for z in tiny_batch])
+        dur, flt = tts.native.adm_infer(dev(tc), ln, return_float=True)
+        cond, lq = pad_stack([z["plm_cond"] for z in tiny_batch])
+        codes = tts.native.plm_infer(dev(cond), lq)
+        torch.cuda.synchronize()
+        for i, z in enumerate(tiny_batch):
+            assert np.allclose(flt[i, :ln[i]].cpu().numpy(), z["adm_float"], rtol=1e-4, atol=1e-4)
+            assert np.array_equal(dur[i, :ln[i]].cpu().numpy(), z["adm_dur"])
+            assert np.array_equal(codes[i, :lq[i]].cpu().numpy(), z["p_codes"])
+    finally:
+        tts.native.set_ar_groups(2)
+
+
 def test_tiny_regulate_and_pool(tiny_batch):
     tts = model("tiny")
     tc, ln = pad_stack([z["tc_latent"] for z in tiny_batch])

@@ -16,10 +16,10 @@ smoke)
   echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log ;;
 bench)
   timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/bench.log 2>&1
-  echo "bench rc=$?"; tail -1 gpurun_out/bench.log ;;
+  echo "bench rc=$?"; tail -1 gpurun_out/bench.log | cut -c1-1800 ;;
 bench3)
   timeout 1200 python bench.py --workload C3 --steps 2 --warmup 1 > gpurun_out/bench_c3.log 2>&1
-  echo "bench3 rc=$?"; tail -1 gpurun_out/bench_c3.log ;;
+  echo "bench3 rc=$?"; tail -1 gpurun_out/bench_c3.log | cut -c1-1500 ;;
 prof)
   rm -rf gpurun_out/prof
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline) > gpurun_out/prof.log 2>&1
@@ -32,6 +32,11 @@ sweep)
 sweep_ar)
   timeout 600 python tools/gemm_sweep.py ar > gpurun_out/gemm_sweep_ar.txt 2>&1
   echo "sweep_ar rc=$?"; cat gpurun_out/gemm_sweep_ar.txt ;;
+groups)
+  for g in ${GROUPS_LIST:-1 2}; do
+    timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --ar-groups $g > gpurun_out/bench_g$g.log 2>&1
+    echo "groups $g rc=$?"; tail -1 gpurun_out/bench_g$g.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('stage_ms'), d['roofline']['frac'], d['roofline']['gemm_ms_per_step'])"
+  done ;;
 thresh)
   for t in 0,0,0 512,1024,32; do
     timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --thresh $t > gpurun_out/bench_t_$t.log 2>&1

@@ -97,7 +97,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3"])
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -131,7 +131,7 @@ def main() -> None:
     sd_g[O.CODEBOOK] = emb
     sd_g[O.CODEBOOK.replace("embed", "embed_avg")] = emb.copy()
     sd_a = weights.synth_state_dict(weights.inventory_adm(a), 0, "adm.")
-    full = args.workload == "C3"
+    full = args.workload in ("C3", "C5")
     sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.") if full else None
     sd_h = weights.synth_state_dict(weights.inventory_hifigan(h), 0, "hifigan.") if full else None
     model = NativeModel(g, p, a, h, sd_g, sd_p, sd_a, sd_h)
@@ -141,7 +141,7 @@ def main() -> None:
         t = [int(v) for v in args.thresh.split(",")]
         model.lib.mt2_debug_set_thresholds(t[0], t[1], t[2])
 
-    shape = {"C1": synth.C1, "C2": synth.C2, "C3": synth.C3}[args.workload]
+    shape = synth.SHAPES[args.workload]
     B = args.batch or shape.B
     utts = synth.make_batch(shape, seed=1000 + int(args.workload[1]) + 17 * rank, batch=B)
     Np, Tp = shape.Np, shape.Tp

@@ -79,6 +79,58 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], 
     }
 }
 
+// Epilogue operands fetched BEFORE the K loop (one 32x32 tile per wave only: 33 registers).  A launch of the
+// autoregressive steps has at most one workgroup per CU, so the bias / residual / row-mask loads at the end
+// of the kernel were ~1.5 us of exposed latency per launch; here they fly during the K loop.
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ int g_one_i[4] = {1, 1, 1, 1};
+// A wave writes accumulator elements e = e0 .. e0+NE-1 of its 32x32 tile (all 16, or its 16/KS share after a
+// K-split reduction; e0 is wave-uniform but a RUN-TIME value, so everything is indexed by i = e - e0).
+template <int NE> struct EpiPre { float r[NE]; int v[NE]; float b; };
+template <int NE>
+__device__ __forceinline__ void epi_prefetch(const GemmP& p, EpiPre<NE>& q, int g, int mw, int nw, int lane, int e0) {
+    // every load is unconditional from a safe address (absent operands point at constants): a conditional load
+    // becomes a phi and hipcc folds the epilogue's compare into it, i.e. waits for each load where it is issued
+    const int n = nw + (lane & 31);
+    const bool nok = n < p.N;
+    const float* __restrict__ bias = p.bias ? p.bias + (long long)g * p.strideB + (nok ? n : 0) : g_zero16;
+    const float* __restrict__ R = p.R ? p.R + (long long)g * p.strideR + (nok ? n : 0) : g_zero16;
+    const long long ldr = p.R ? p.ldr : 0;
+    const int* __restrict__ vp = p.valid ? p.valid : g_one_i;
+    const int vs = p.valid ? 1 : 0;
+    q.b = *bias;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = e0 + i;
+        int m = mw + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        m = m < p.M ? m : 0;
+        q.r[i] = R[m * ldr];
+        q.v[i] = vp[m * vs];
+    }
+}
+template <int NE>
+__device__ __forceinline__ void epilogue_pre(const GemmP& p, const float (&acc)[NE], const EpiPre<NE>& q, int g, int mw,
+                                             int nw, int lane, int e0) {
+    float* __restrict__ C = p.C + (long long)g * p.strideC;
+    const int epi_act = p.epi_act;
+    const float out_scale = p.out_scale;
+    const bool hasR = p.R != nullptr;
+    const int n = nw + (lane & 31);
+    const bool nok = n < p.N;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = e0 + i;
+        const int m = mw + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (nok && m < p.M) {
+            float v = acc[i] + q.b;
+            v = act_rt(epi_act, v, 0.0f) * out_scale;
+            if (hasR) v += q.r[i];
+            if (q.v[i] == 0) v = 0.0f;
+            C[(long long)m * p.ldc + n] = v;
+        }
+    }
+}
+
 constexpr int BK = 32;   // K chunk (floats)
 constexpr int LS = 36;   // LDS row stride (floats): 144 B = 9 x 16 B -> conflict-free ds_read_b128
 
@@ -218,8 +270,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f32_kernel(GemmP p) {
 //     to the fragment registers after the ds_read;
 //   * one raw s_barrier per chunk, preceded by a COUNTED s_waitcnt vmcnt((NST-2)*L) so younger chunks stay
 //     in flight across the barrier (hipcc's __syncthreads would drain them with vmcnt(0)).
-__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 lds_read_b128(unsigned byte_addr) {
     f32x4 v;
@@ -295,6 +345,10 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     // retire the rowbase loads HERE: once DMAs are in flight hipcc can only wait for an ordinary load
     // with vmcnt(0), which would drain the ring in the prologue
     wait_vmcnt<0>();
+    constexpr bool PRE = TM * TN == 1;          // epilogue operands in flight during the K loop
+    constexpr int EPGK = 16 / KS;
+    EpiPre<PRE ? EPGK : 1> pre;
+    if constexpr (PRE) epi_prefetch<EPGK>(p, pre, g, m0 + wm * WTM, n0 + wn * WTN, lane, kg * EPGK);
 
     float* ring = smem + kg * (NST * STAGE);
     auto issue = [&](int rd, int st) {
@@ -397,22 +451,29 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     }
     if constexpr (KS > 1) {
         // sum the KS partial tiles through LDS (ring memory is free: every DMA has been waited for and the
-        // barrier below orders the last operand reads), fixed order kg = 0..KS-1
+        // barrier below orders the last operand reads), fixed order kg = 0..KS-1; group kg finishes elements
+        // e = kg*EPG .. kg*EPG+EPG-1 of every tile
         constexpr int EPG = 16 / KS;
         __syncthreads();
         float* red = smem + ((kg * NW + wave) * 16) * 64 + lane;
 #pragma unroll
         for (int e = 0; e < 16; ++e) red[e * 64] = acc[0][0][e];
         __syncthreads();
+        float out[EPG];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (e / EPG != kg) continue;
+        for (int i = 0; i < EPG; ++i) {
+            const int e = kg * EPG + i;
             float v = 0.0f;
 #pragma unroll
             for (int g2 = 0; g2 < KS; ++g2) v += smem[(((g2 * NW + wave) * 16) + e) * 64 + lane];
-            acc[0][0][e] = v;
+            out[i] = v;
         }
-        epilogue<TM, TN, EPG>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane, kg);
+        epilogue_pre<EPG>(p, out, pre, g, m0 + wm * WTM, n0 + wn * WTN, lane, kg * EPG);
+    } else if constexpr (PRE) {
+        float out[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[e] = acc[0][0][e];
+        epilogue_pre<16>(p, out, pre, g, m0 + wm * WTM, n0 + wn * WTN, lane, 0);
     } else {
         epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     }
@@ -470,6 +531,9 @@ static const TileCfg kCfgs[] = {
     MT2_DMAK(64, 64, 2, 2, 4, 2),   // 20: 16 waves, 128 KiB
     MT2_DMAK(32, 64, 1, 2, 4, 3),   // 21:  8 waves, 144 KiB, 32-row tiles for the first AR steps
     MT2_DMAK(32, 64, 1, 2, 4, 2),   // 22:  8 waves,  96 KiB
+    // 64-wide outputs (HiFi-GAN stage 3): a 128-wide tile would idle half of its MFMAs
+    MT2_DMA(256, 64, 4, 2, 3),      // 23: 8 waves, 64x32 per wave, 120 KiB
+    MT2_DMA(128, 64, 4, 2, 4),      // 24: 8 waves, 32x32 per wave,  96 KiB
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -561,6 +625,8 @@ static const TileCfg* choose_cfg(const GemmP& p, int* idx_out) {
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.groups;
     const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.groups;
     if (p.N <= 32) bi = 15;                                             // dma128x32_4x1_s4
+    else if (p.N <= 64 && t128 >= 400) bi = 23;                         // dma256x64_4x2_s3
+    else if (p.N <= 256 && t128 >= 400) bi = 17;                        // two n-tiles: 128x128 beats 256x128 (vocoder)
     else if (t256 >= 400 || (t256 >= 200 && t256 <= 256)) bi = 16;      // dma256x128_4x2_s3
     else if (t128 >= 400 || (t128 >= 200 && t128 <= 256)) bi = 17;      // dma128x128_4x2_s4
     else if (t32 <= g_t32) bi = 22;                                     // dma32x64_1x2_k4_s2

@@ -17,6 +17,20 @@ smoke)
 bench)
   timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/bench.log 2>&1
   echo "bench rc=$?"; tail -1 gpurun_out/bench.log | cut -c1-1800 ;;
+bench5)
+  timeout 900 python bench.py --workload C5 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_c5.log 2>&1
+  echo "bench5 rc=$?"; tail -1 gpurun_out/bench_c5.log | cut -c1-1500 ;;
+sweep_voc)
+  timeout 600 python tools/gemm_sweep.py voc > gpurun_out/gemm_sweep_voc.txt 2>&1
+  echo "sweep_voc rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_voc.txt ;;
+bench1)
+  timeout 600 python bench.py --workload C1 --steps 5 --warmup 2 > gpurun_out/bench_c1.log 2>&1
+  echo "bench1 rc=$?"; tail -1 gpurun_out/bench_c1.log | cut -c1-1200 ;;
+prof3)
+  rm -rf gpurun_out/prof3
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof3 -o bench -- python $GRAFT_REPO_ROOT/bench.py --workload C3 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline) > gpurun_out/prof3.log 2>&1
+  echo "prof3 rc=$?"; f=$(find gpurun_out/prof3 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/prof3_kernel_stats.csv && head -24 "$f" | cut -c1-200
+  find gpurun_out/prof3 -name "*kernel_trace.csv" -size +8M -delete ;;
 bench3)
   timeout 1200 python bench.py --workload C3 --steps 2 --warmup 1 > gpurun_out/bench_c3.log 2>&1
   echo "bench3 rc=$?"; tail -1 gpurun_out/bench_c3.log | cut -c1-1500 ;;
@@ -37,6 +51,12 @@ groups)
     timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --ar-groups $g > gpurun_out/bench_g$g.log 2>&1
     echo "groups $g rc=$?"; tail -1 gpurun_out/bench_g$g.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('stage_ms'), d['roofline']['frac'], d['roofline']['gemm_ms_per_step'])"
   done ;;
+probe)
+  rm -rf gpurun_out/probe
+  (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/probe -o probe -- python $GRAFT_REPO_ROOT/tools/gemm_probe.py) > gpurun_out/probe.log 2>&1
+  echo "probe rc=$?"; grep -v "^W2026\|amdgpu.ids" gpurun_out/probe.log | tail -14
+  python tools/pmc_probe_summary.py gpurun_out/probe | tee gpurun_out/probe_summary.txt | cut -c1-400
+  find gpurun_out/probe -name "*.csv" -size +4M -delete ;;
 thresh)
   for t in 0,0,0 512,1024,32; do
     timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --thresh $t > gpurun_out/bench_t_$t.log 2>&1

@@ -130,6 +130,19 @@ int mt2_mel_decoder(mt2_model* m, void* stream, const float* x, const int32_t* l
 int mt2_hifigan(mt2_model* m, void* stream, const float* mel, const int32_t* lens /*host*/, int T_max, int B,
                 float* wav);
 
+/* ---- extract_mel_spec(samples) (modules/tokenizer.py:107-125): speechbrain `mel_spectogram` = torchaudio
+ * Spectrogram(n_fft, win_length, hop_length, power=1, center=True, pad_mode="reflect", periodic Hann) ->
+ * MelScale(n_mels, f_min, f_max, norm="slaney", mel_scale="slaney") -> log(clamp(x, clip)).
+ * wav f32 [B, L_max] (16 kHz mono in the reference) -> mel f32 [B, T_max, n_mels], T_b = 1 + L_b / hop.
+ * The STFT is an implicit conv on the GEMM engine: frame t = n_fft/hop consecutive hop-sized blocks of the
+ * reflect-padded signal against a windowed DFT basis [2*(n_fft/2+1), n_fft].  n_fft % hop == 0, hop % 4 == 0. */
+typedef struct mt2_audio_config {
+    int32_t sample_rate, n_fft, hop_length, win_length, n_mels;
+    float f_min, f_max, clip;
+} mt2_audio_config;
+int mt2_mel_spectrogram(mt2_model* m, void* stream, const mt2_audio_config* ac, const float* wav,
+                        const int32_t* lens /*host*/, int L_max, int B, float* mel, int T_max);
+
 /* ---- the whole of Megatts.forward's no_grad block (models/megatts2.py:353-368 [+370]) for a batch,
  * activations staying in the packed internal layout between stages.
  *   forced_dur   (host, optional) int32 [B, Np_max]: replaces the ADM's integer durations AFTER the ADM

@@ -26,6 +26,20 @@ HIFIGAN_MAX_FREQ = 8000
 
 
 @dataclass
+class AudioConfig:
+    """The constants of reference modules/tokenizer.py:19-24 and the arguments extract_mel_spec passes
+    to speechbrain's mel_spectogram (:107-125); clip = dynamic_range_compression's clip_val."""
+    sample_rate: int = HIFIGAN_SR
+    n_fft: int = HIFIGAN_NFFT
+    hop_length: int = HIFIGAN_HOP_LENGTH
+    win_length: int = HIFIGAN_WIN_LENGTH
+    n_mels: int = HIFIGAN_MEL_CHANNELS
+    f_min: float = 0.0
+    f_max: float = float(HIFIGAN_MAX_FREQ)
+    clip: float = 1e-5
+
+
+@dataclass
 class MRTEConfig:
     mel_bins: int = 80
     mel_kernel_size: int = 3

@@ -41,6 +41,7 @@ __device__ __forceinline__ float act_rt(int act, float v, float slope) {
         case ACT_RELU: return fmaxf(v, 0.0f);
         case ACT_LRELU: return v >= 0.0f ? v : v * slope;
         case ACT_TANH: return tanhf(v);
+        case ACT_LOGCLAMP: return logf(fmaxf(v, slope));
         default: return v;
     }
 }
@@ -55,6 +56,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], 
     const float* __restrict__ R = p.R ? p.R + (long long)g * p.strideR : nullptr;
     float* __restrict__ C = p.C + (long long)g * p.strideC;
     const int epi_act = p.epi_act;
+    const float epi_par = p.pro_slope;     // parameter of the epilogue activation (ACT_LOGCLAMP: the clip value)
     const float out_scale = p.out_scale;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -69,7 +71,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x16 (&acc)[TM][TN], 
                 const int m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (nok && m < p.M) {
                     float v = acc[i][j][e] + bv;
-                    v = act_rt(epi_act, v, 0.0f) * out_scale;
+                    v = act_rt(epi_act, v, epi_par) * out_scale;
                     if (R) v += R[(long long)m * p.ldr + n];
                     if (p.valid && p.valid[m] == 0) v = 0.0f;
                     C[(long long)m * p.ldc + n] = v;
@@ -113,6 +115,7 @@ __device__ __forceinline__ void epilogue_pre(const GemmP& p, const float (&acc)[
                                              int nw, int lane, int e0) {
     float* __restrict__ C = p.C + (long long)g * p.strideC;
     const int epi_act = p.epi_act;
+    const float epi_par = p.pro_slope;     // parameter of the epilogue activation (ACT_LOGCLAMP: the clip value)
     const float out_scale = p.out_scale;
     const bool hasR = p.R != nullptr;
     const int n = nw + (lane & 31);
@@ -123,7 +126,7 @@ __device__ __forceinline__ void epilogue_pre(const GemmP& p, const float (&acc)[
         const int m = mw + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
         if (nok && m < p.M) {
             float v = acc[i] + q.b;
-            v = act_rt(epi_act, v, 0.0f) * out_scale;
+            v = act_rt(epi_act, v, epi_par) * out_scale;
             if (hasR) v += q.r[i];
             if (q.v[i] == 0) v = 0.0f;
             C[(long long)m * p.ldc + n] = v;

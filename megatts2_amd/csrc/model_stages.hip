@@ -832,6 +832,107 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
     return wav;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// mel front-end: extract_mel_spec (modules/tokenizer.py:107-125).  Restates torchaudio's Spectrogram +
+// MelScale (neither is in the reference tree; parity unpinned): periodic Hann window,
+// center=True with reflect padding, one-sided magnitude (power 1), slaney mel scale and slaney area norm,
+// log(clamp(., clip)).  Constants are built once per audio configuration in double precision.
+
+static double hz_to_mel_slaney(double f) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+static double mel_to_hz_slaney(double mel) {
+    const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    return mel >= min_log_mel ? min_log_hz * std::exp(logstep * (mel - min_log_mel)) : f_sp * mel;
+}
+static void frontend_prepare(mt2_model& m, const mt2_audio_config& ac) {
+    if (m.fe_basis && std::memcmp(&m.fe_cfg, &ac, sizeof(ac)) == 0) return;
+    MT2_REQUIRE(ac.n_fft >= 8 && ac.hop_length >= 4 && ac.hop_length % 4 == 0 && ac.n_fft % ac.hop_length == 0,
+                "n_fft must be a multiple of hop_length, hop_length a multiple of 4");
+    MT2_REQUIRE(ac.win_length >= 1 && ac.win_length <= ac.n_fft && ac.n_mels >= 1 && ac.n_mels % 4 == 0,
+                "win_length <= n_fft, n_mels a multiple of 4");
+    MT2_REQUIRE(ac.f_max > ac.f_min && ac.sample_rate > 0 && ac.clip > 0.0f, "bad audio configuration");
+    const int N = ac.n_fft, F = N / 2 + 1, Fp = (F + 3) & ~3;
+    const double PI = 3.14159265358979323846;
+    std::vector<double> win(N, 0.0);
+    const int left = (N - ac.win_length) / 2;       // torch.stft centres a short window inside n_fft
+    for (int k = 0; k < ac.win_length; ++k) win[left + k] = 0.5 - 0.5 * std::cos(2.0 * PI * k / ac.win_length);
+    std::vector<float> basis((size_t)2 * F * N);
+    for (int f = 0; f < F; ++f)
+        for (int k = 0; k < N; ++k) {
+            const double ang = 2.0 * PI * (double)(((long long)f * k) % N) / N;
+            basis[(size_t)f * N + k] = (float)(win[k] * std::cos(ang));
+            basis[(size_t)(F + f) * N + k] = (float)(-win[k] * std::sin(ang));
+        }
+    // torchaudio.functional.melscale_fbanks(n_freqs=F, f_min, f_max, n_mels, sample_rate, "slaney", "slaney")
+    std::vector<float> fb((size_t)ac.n_mels * Fp, 0.0f);
+    const double m_min = hz_to_mel_slaney(ac.f_min), m_max = hz_to_mel_slaney(ac.f_max);
+    std::vector<double> fpts(ac.n_mels + 2);
+    for (int i = 0; i < ac.n_mels + 2; ++i) fpts[i] = mel_to_hz_slaney(m_min + (m_max - m_min) * i / (ac.n_mels + 1));
+    for (int j = 0; j < ac.n_mels; ++j) {
+        const double enorm = 2.0 / (fpts[j + 2] - fpts[j]);
+        for (int f = 0; f < F; ++f) {
+            const double freq = (double)(ac.sample_rate / 2) * f / (F - 1);
+            const double down = (freq - fpts[j]) / (fpts[j + 1] - fpts[j]);
+            const double up = (fpts[j + 2] - freq) / (fpts[j + 2] - fpts[j + 1]);
+            fb[(size_t)j * Fp + f] = (float)(std::max(0.0, std::min(down, up)) * enorm);
+        }
+    }
+    auto up = [&](const std::vector<float>& v) {
+        float* d = nullptr;
+        MT2_HIP(hipMalloc(reinterpret_cast<void**>(&d), v.size() * sizeof(float)));
+        MT2_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        m.dev_allocs.push_back(d);
+        return d;
+    };
+    m.fe_basis = up(basis);
+    m.fe_fb = up(fb);
+    m.fe_nfreq = F; m.fe_nfreq_pad = Fp;
+    m.fe_cfg = ac;
+}
+
+static void mel_spectrogram_run(const Ctx& c, const mt2_audio_config& ac, const float* wav, const int* lens, int L_max,
+                                int B, float* mel, int T_max) {
+    mt2_model& m = c.m;
+    frontend_prepare(m, ac);
+    const int hop = ac.hop_length, taps = ac.n_fft / hop, pad = ac.n_fft / 2, F = m.fe_nfreq, Fp = m.fe_nfreq_pad;
+    std::vector<int> blk_b, blk_t, rowbase, rowmap, len(lens, lens + B);
+    for (int b = 0; b < B; ++b) {
+        MT2_REQUIRE(lens[b] > pad && lens[b] <= L_max, "waveform shorter than n_fft/2 + 1 samples (reflect padding) or > L_max");
+        const int T = 1 + lens[b] / hop, row0 = (int)blk_b.size();
+        MT2_REQUIRE(T <= T_max, "T_max smaller than 1 + L / hop_length");
+        for (int t = 0; t < T - 1 + taps; ++t) { blk_b.push_back(b); blk_t.push_back(t); }
+        for (int t = 0; t < T; ++t) { rowbase.push_back(row0 + t); rowmap.push_back(b * T_max + t); }
+    }
+    const int Rb = (int)blk_b.size(), Fr = (int)rowbase.size();
+    IntPlan ip;
+    const int o_b = ip.add(blk_b), o_t = ip.add(blk_t), o_len = ip.add(len), o_base = ip.add(rowbase),
+              o_map = ip.add(rowmap);
+    ip.upload(c.ws, c.s);
+    float* xp = c.ws.get<float>((size_t)Rb * hop);
+    MT2_HIP(launch_reflect_pad_blocks(wav, L_max, ip.dev(o_b), ip.dev(o_t), ip.dev(o_len), hop, pad, xp, Rb, c.s));
+    const int lds = (2 * F + 3) & ~3;
+    float* spec = c.ws.get<float>((size_t)Fr * lds);
+    {   // STFT = Conv1d over hop-sized blocks: frame t reads blocks t .. t+taps-1
+        GemmP p{};
+        p.X = xp; p.ldx = hop; p.Rx = Rb; p.rowbase = ip.dev(o_base); p.taps = taps; p.Cin = hop;
+        p.W = m.fe_basis; p.C = spec; p.ldc = lds; p.M = Fr; p.N = 2 * F;
+        gemm(c, p);
+    }
+    float* mag = c.ws.get<float>((size_t)Fr * Fp);
+    MT2_HIP(launch_magnitude(spec, lds, F, mag, Fp, Fr, c.s));
+    float* mrows = c.ws.get<float>((size_t)Fr * ac.n_mels);
+    {   // MelScale + dynamic range compression
+        GemmP p{};
+        p.X = mag; p.ldx = Fp; p.Rx = Fr; p.Cin = Fp; p.W = m.fe_fb; p.C = mrows; p.ldc = ac.n_mels; p.M = Fr;
+        p.N = ac.n_mels; p.epi_act = ACT_LOGCLAMP; p.pro_slope = ac.clip;
+        gemm(c, p);
+    }
+    MT2_HIP(hipMemsetAsync(mel, 0, sizeof(float) * (size_t)B * T_max * ac.n_mels, c.s));
+    MT2_HIP(launch_unpack_rows(mrows, ac.n_mels, ac.n_mels, T_max, 0, ip.dev(o_map), mel, Fr, c.s));
+}
+
 }  // namespace mt2
 
 // the C ABI lives in capi.hip and includes this translation unit's helpers

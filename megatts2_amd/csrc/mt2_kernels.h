@@ -14,7 +14,8 @@ namespace mt2 {
 
 constexpr int kInvalidRow = -(1 << 30);   // rowbase sentinel: "this A row is all zeros"
 
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3,
+                 ACT_LOGCLAMP = 4 };   // epilogue only: log(max(v, pro_slope))  (dynamic range compression)
 
 // C[g][m, n] = epi( sum_{tap, c} pro(X[g][src(m) + tap*dil, c]) * W[g][n, tap*Cin + c] )
 //   src(m)  = rowbase ? rowbase[m] : m * a_mul + shift0           (rows outside [0, Rx) read as 0)
@@ -124,6 +125,10 @@ hipError_t launch_decoder_input(const float* tc, int ld_tc, const int* tcmap, co
 // zq rows (modules/vqpe.py:59-61): out[r] = E[codes[codemap[r]]]
 hipError_t launch_codebook_rows(const float* E, const int64_t* codes, const int* codemap, float* out, int ldo,
                                 int Dq, int R, hipStream_t s);
+// mel front-end helpers (rowops.hip)
+hipError_t launch_reflect_pad_blocks(const float* wav, long long wstride, const int* blk_b, const int* blk_t,
+                                     const int* len, int hop, int pad, float* out, int R, hipStream_t s);
+hipError_t launch_magnitude(const float* spec, int lds_, int F, float* out, int ldo, int M, hipStream_t s);
 hipError_t launch_tanh_col(const float* x, int ldx, float* out, long long n, hipStream_t s);
 
 }  // namespace mt2

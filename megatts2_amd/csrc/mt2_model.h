@@ -130,6 +130,11 @@ struct mt2_model {
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
 
+    // mel front-end constants for the last mt2_audio_config seen (windowed DFT basis, mel filterbank)
+    mt2_audio_config fe_cfg{};
+    float *fe_basis = nullptr, *fe_fb = nullptr;
+    int fe_nfreq = 0, fe_nfreq_pad = 0;
+
     bool profiling = false;
     std::vector<std::string> stage_names;
     std::vector<float> stage_ms;

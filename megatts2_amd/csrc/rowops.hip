@@ -605,4 +605,54 @@ hipError_t launch_tanh_col(const float* x, int ldx, float* out, long long n, hip
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// mel front-end (reference modules/tokenizer.py:107-125 -> torchaudio Spectrogram, center=True, reflect)
+
+// Reflect-padded waveform laid out as hop-sized blocks: row r belongs to utterance blk_b[r], block blk_t[r];
+// sample (r, c) = wav[b, reflect(blk_t*hop + c - pad)], zero beyond the padded signal.
+__global__ void reflect_pad_blocks_kernel(const float* wav, long long wstride, const int* blk_b, const int* blk_t,
+                                          const int* len, int hop, int pad, float* out, int R) {
+    const long long total = (long long)R * hop;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / hop), c = (int)(i % hop);
+        const int b = blk_b[r], L = len[b];
+        long long j = (long long)blk_t[r] * hop + c - pad;
+        float v = 0.0f;
+        if (j < (long long)L + pad) {
+            if (j < 0) j = -j;
+            else if (j >= L) j = 2ll * (L - 1) - j;
+            v = wav[(long long)b * wstride + j];
+        }
+        out[i] = v;
+    }
+}
+hipError_t launch_reflect_pad_blocks(const float* wav, long long wstride, const int* blk_b, const int* blk_t,
+                                     const int* len, int hop, int pad, float* out, int R, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(reflect_pad_blocks_kernel, row_grid((long long)R * hop), dim3(256), 0, s, wav, wstride, blk_b,
+                       blk_t, len, hop, pad, out, R);
+    return hipGetLastError();
+}
+
+// |X|: spec rows hold [re(0..F-1) | im(0..F-1)]; out[m, f] = sqrt(re^2 + im^2), columns F..ldo-1 zeroed
+__global__ void magnitude_kernel(const float* spec, int lds_, int F, float* out, int ldo, int M) {
+    const long long total = (long long)M * ldo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / ldo), f = (int)(i % ldo);
+        float v = 0.0f;
+        if (f < F) {
+            const float re = spec[(long long)m * lds_ + f], im = spec[(long long)m * lds_ + F + f];
+            v = sqrtf(re * re + im * im);
+        }
+        out[i] = v;
+    }
+}
+hipError_t launch_magnitude(const float* spec, int lds_, int F, float* out, int ldo, int M, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    hipLaunchKernelGGL(magnitude_kernel, row_grid((long long)M * ldo), dim3(256), 0, s, spec, lds_, F, out, ldo, M);
+    return hipGetLastError();
+}
+
 }  // namespace mt2

@@ -26,6 +26,25 @@ def _np_sd(sd) -> Dict[str, np.ndarray]:
     return {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in sd.items()}
 
 
+_FRONTEND = None
+
+
+def extract_mel_spec(samples):
+    """reference modules/tokenizer.py:107-125: 1-D waveform tensor (16 kHz) -> mel [80, T] (the reference
+    returns channels first and `Megatts.forward` transposes it, models/megatts2.py:339).  Runs on the GPU
+    (runtime.MelFrontEnd); a [B, L] input gives [B, 80, T]."""
+    import torch
+    global _FRONTEND
+    if _FRONTEND is None:
+        from .runtime import MelFrontEnd
+        _FRONTEND = MelFrontEnd()
+    x = samples if hasattr(samples, "is_cuda") else torch.as_tensor(np.asarray(samples, np.float32))
+    batched = x.dim() == 2
+    x = (x if batched else x.unsqueeze(0)).to("cuda", torch.float32)
+    mel = _FRONTEND(x).transpose(1, 2)
+    return mel if batched else mel[0]
+
+
 class LengthRegulator:
     """reference modules/mrte.py:34-60 (FastSpeech length regulator) as a device gather."""
 
@@ -294,30 +313,36 @@ class Megatts:
                                            run_plm=not have_c, vocoder=vocoder)
         return out[0], out[1]
 
-    # -- the reference's entry point (models/megatts2.py:325-375).  The audio / text front-end
-    # (librosa, speechbrain mel, pypinyin G2P) is host pre-processing outside the hot path
-    # (SURVEY.md 2.1 rows 12-13); it is used when importable.
-    def forward(self, wavs_dir: str, text: str):
+    # -- the reference's entry point (models/megatts2.py:325-375).  Prompt audio: every *.wav of the directory
+    # is loaded (16 kHz mono), peak-normalised, turned into a mel by extract_mel_spec (on the GPU) and the mels
+    # are concatenated along time (:332-344).  Text -> phone ids is the reference's G2P (pypinyin + MFA
+    # dictionary, host side, outside the hot path); when it is not importable pass `phone_tokens` instead.
+    def forward(self, wavs_dir: str, text: Optional[str] = None, phone_tokens=None, out_path: Optional[str] = "test.wav"):
         import torch
-        try:
-            import librosa  # noqa: F401
-            from modules.tokenizer import TextTokenizer, extract_mel_spec   # reference front-end, if on sys.path
-            from modules.datamodule import TokensCollector
-        except Exception as e:  # pragma: no cover - front-end absent in this image
-            raise NativeError("Megatts.forward(wavs_dir, text) needs the reference's audio/text front-end "
-                              "(librosa, speechbrain, pypinyin); call synthesize(phone_tokens, mels) instead") from e
-        mels, mels_prompt = [], None
-        for wav in glob.glob(f"{wavs_dir}/*.wav"):
-            y = librosa.util.normalize(librosa.load(wav, sr=HIFIGAN_SR)[0])
-            mel_spec = extract_mel_spec(torch.from_numpy(y)).transpose(0, 1)
-            mels.append(mel_spec)
-            if mels_prompt is None:
-                mels_prompt = mel_spec
-        mels = torch.cat(mels, dim=0).unsqueeze(0).cuda()
-        if self.tt is None:
-            self.tt, self.ttc = TextTokenizer(), TokensCollector(self.symbol_table)
-        phone_tokens = self.ttc.phone2token(self.tt.tokenize_lty(self.tt.tokenize(text))).unsqueeze(0).cuda()
+        from . import audio_io
+        wavs = sorted(glob.glob(f"{wavs_dir}/*.wav"))
+        if not wavs:
+            raise NativeError(f"no *.wav under {wavs_dir}")
+        mels = [extract_mel_spec(torch.from_numpy(audio_io.load_audio(w, HIFIGAN_SR))).transpose(0, 1) for w in wavs]
+        mels_prompt = mels[0]
+        mels = torch.cat(mels, dim=0).unsqueeze(0)
+        if phone_tokens is None:
+            try:
+                from modules.tokenizer import TextTokenizer          # reference G2P, if it is on sys.path
+                from modules.datamodule import TokensCollector
+            except Exception as e:  # pragma: no cover - pypinyin / lhotse absent in this image
+                raise NativeError("text input needs the reference's G2P (modules.tokenizer.TextTokenizer: pypinyin, "
+                                  "phonemizer); pass phone_tokens=[...] instead") from e
+            if self.tt is None:
+                self.tt, self.ttc = TextTokenizer(), TokensCollector(self.symbol_table)
+            phone_tokens = self.ttc.phone2token(self.tt.tokenize_lty(self.tt.tokenize(text)))
+        phone_tokens = torch.as_tensor(np.asarray(phone_tokens)).to(torch.int64).reshape(1, -1).cuda()
         mel, mel_lens, aux = self.synthesize(phone_tokens, mels, vocoder=self.hifi_gan is not None, return_aux=True)
+        if self.hifi_gan is not None and out_path:
+            # :370-375  prompt audio (vocoded first prompt mel) followed by the generated audio
+            prompt = self.hifi_gan.decode_batch(mels_prompt.transpose(0, 1).unsqueeze(0).contiguous())[0, 0]
+            audio = torch.cat([prompt, aux["wav"][0, :int(mel_lens[0]) * self.hifi_gan.cfg.hop]])
+            audio_io.write_wav(out_path, audio, HIFIGAN_SR)
         return mel, mel_lens, aux
 
     __call__ = forward

@@ -49,6 +49,12 @@ class MT2Config(C.Structure):
     ]
 
 
+class MT2AudioConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("n_fft", C.c_int32), ("hop_length", C.c_int32),
+                ("win_length", C.c_int32), ("n_mels", C.c_int32),
+                ("f_min", C.c_float), ("f_max", C.c_float), ("clip", C.c_float)]
+
+
 def library_path() -> str:
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmegatts2_hip.so")
 
@@ -404,6 +410,48 @@ class NativeModel:
         ms = (C.c_float * 16)()
         n = self.lib.mt2_last_stage_ms(self.h, names, ms, 16)
         return {names[i].decode(): float(ms[i]) for i in range(max(n, 0))}
+
+
+class MelFrontEnd:
+    """extract_mel_spec on the GPU (reference modules/tokenizer.py:107-125): STFT as an implicit conv on the
+    GEMM engine, magnitude, slaney mel filterbank, log(clamp(., 1e-5)).  Owns a bare handle (no weights)."""
+
+    def __init__(self, audio: Optional[cfgmod.AudioConfig] = None):
+        import torch
+        self.lib = load_library()
+        device_check()
+        if not torch.cuda.is_available():
+            raise NativeError("PyTorch-ROCm sees no GPU")
+        self.audio = audio or cfgmod.AudioConfig()
+        a = self.audio
+        self.ac = MT2AudioConfig(a.sample_rate, a.n_fft, a.hop_length, a.win_length, a.n_mels, a.f_min, a.f_max, a.clip)
+        ccfg = make_config(None, None, None, None)
+        self.h = C.c_void_p(self.lib.mt2_model_create(C.byref(ccfg)))
+        if not self.h:
+            raise NativeError(self.lib.mt2_last_error().decode())
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.mt2_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __call__(self, wav, lens=None):
+        """wav f32 [B, L] (device) -> mel f32 [B, 1 + L // hop, n_mels]; rows beyond 1 + lens[b] // hop are zero."""
+        import torch
+        assert wav.is_cuda and wav.dim() == 2
+        wav = wav.contiguous().to(torch.float32)
+        B, L = wav.shape
+        ln = np.full(B, L, np.int32) if lens is None else _i32(lens)
+        T = 1 + int(ln.max()) // self.audio.hop_length
+        mel = torch.empty(B, T, self.audio.n_mels, device=wav.device, dtype=torch.float32)
+        _check(self.lib.mt2_mel_spectrogram(self.h, _stream(), C.byref(self.ac), _ptr(wav), _iptr(ln), L, B, _ptr(mel), T))
+        return mel
 
 
 # ---- kernel-level entry points -------------------------------------------------------------------------

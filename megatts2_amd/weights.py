@@ -227,6 +227,9 @@ def synth_state_dict(inv, seed: int = 0, prefix: str = "") -> Dict[str, np.ndarr
 def load_lightning_state_dict(ckpt_path: str, prefix: str) -> Dict[str, np.ndarray]:
     """`torch.load(ckpt)['state_dict']`, keep keys under `prefix`, strip it
     (reference models/megatts2.py:111-116,192-197,287-291)."""
+    if ckpt_path.endswith(".mt2"):       # packed file written by audio_io.save_packed (same names, memory-mapped)
+        from .audio_io import load_packed
+        return OrderedDict((k[len(prefix):], v) for k, v in load_packed(ckpt_path).items() if k.startswith(prefix))
     import torch
 
     raw = torch.load(ckpt_path, map_location="cpu", weights_only=False)["state_dict"]

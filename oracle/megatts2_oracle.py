@@ -457,3 +457,57 @@ def rel_l2(a: np.ndarray, b: np.ndarray) -> float:
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------
+# mel front-end.  PARITY UNPINNED: the arithmetic is speechbrain's `mel_spectogram`
+# = torchaudio.transforms.Spectrogram + MelScale (reference call site modules/tokenizer.py:107-125 with
+# n_fft 1024, win 1024, hop 256, 80 mels, 0-8000 Hz, power 1, norm/mel_scale "slaney", compression);
+# neither package is in /root/reference nor installed.  Restated from torchaudio's published algorithm;
+# tests/test_oracle_golden.py pins the STFT half against torch.stft (the routine torchaudio calls).
+
+
+def _hz_to_mel_slaney(f: float) -> float:
+    f_sp, min_log_hz = 200.0 / 3.0, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, math.log(6.4) / 27.0
+    return min_log_mel + math.log(f / min_log_hz) / logstep if f >= min_log_hz else f / f_sp
+
+
+def _mel_to_hz_slaney(m: np.ndarray) -> np.ndarray:
+    f_sp, min_log_hz = 200.0 / 3.0, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, math.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def melscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int) -> np.ndarray:
+    """torchaudio.functional.melscale_fbanks(..., norm="slaney", mel_scale="slaney") -> [n_freqs, n_mels]."""
+    all_freqs = np.linspace(0, sample_rate // 2, n_freqs)
+    m_pts = np.linspace(_hz_to_mel_slaney(f_min), _hz_to_mel_slaney(f_max), n_mels + 2)
+    f_pts = _mel_to_hz_slaney(m_pts)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - all_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    fb = np.maximum(0.0, np.minimum(down, up))
+    return fb * (2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels]))[None, :]
+
+
+def stft_magnitude(wav: np.ndarray, n_fft: int = 1024, hop: int = 256, win: int = 1024) -> np.ndarray:
+    """torch.stft(center=True, pad_mode="reflect", window=hann_window(win) periodic, onesided) -> |X| [T, n_fft/2+1]."""
+    x = np.asarray(wav, np.float64)
+    pad = n_fft // 2
+    xp = np.pad(x, (pad, pad), mode="reflect")
+    w = np.zeros(n_fft)
+    left = (n_fft - win) // 2
+    w[left:left + win] = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win) / win)
+    T = 1 + x.size // hop
+    frames = np.stack([xp[t * hop:t * hop + n_fft] * w for t in range(T)])
+    return np.abs(np.fft.rfft(frames, axis=1))
+
+
+def mel_spectrogram(wav: np.ndarray, sample_rate: int = 16000, n_fft: int = 1024, hop: int = 256, win: int = 1024,
+                    n_mels: int = 80, f_min: float = 0.0, f_max: float = 8000.0, clip: float = 1e-5) -> np.ndarray:
+    """extract_mel_spec (modules/tokenizer.py:107-125), time-major: -> [T, n_mels] f32."""
+    mag = stft_magnitude(wav, n_fft, hop, win)
+    fb = melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)
+    return np.log(np.maximum(mag @ fb, clip)).astype(F32)

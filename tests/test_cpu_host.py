@@ -144,3 +144,35 @@ def test_flop_model_matches_survey():
     assert abs(tot["plm"] - 454.2) < 8.0
     assert abs(tot["decoder"] - 10.9) < 0.3
     assert abs(tot["vocoder"] - 264.7) < 6.0
+
+
+def test_wav_io_and_packed_weights(tmp_path):
+    """Row f4: WAV reader/writer (stdlib `wave` as the independent check) and the packed weight file."""
+    import wave
+    from megatts2_amd import audio_io as A
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(1000) * 0.2).astype(np.float32)
+    p16 = str(tmp_path / "a.wav")
+    A.write_wav(p16, x, 16000, "PCM_S16")
+    with wave.open(p16, "rb") as w:                        # independent reader
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 16000, 1000)
+        ref = np.frombuffer(w.readframes(1000), "<i2")
+    assert np.array_equal(ref, np.clip(np.rint(x * 32768.0), -32768, 32767).astype(np.int16))
+    y, sr = A.read_wav(p16)
+    assert sr == 16000 and np.abs(y - x).max() <= 0.5 / 32768 + 1e-7
+    pf = str(tmp_path / "f.wav")
+    A.write_wav(pf, np.stack([x, -x]), 22050)              # float32, 2 channels -> mono mean = 0
+    z, sr = A.read_wav(pf)
+    assert sr == 22050 and z.shape == (1000,) and not z.any()
+    with pytest.raises(ValueError):
+        A.load_audio(pf, sr=16000)
+    n = A.load_audio(p16)
+    assert abs(np.abs(n).max() - 1.0) < 1e-6              # librosa.util.normalize: peak 1
+    sd = {"a.weight": rng.standard_normal((3, 5, 7)).astype(np.float32), "b": np.float32(2.5).reshape(1),
+          "c.bias": rng.standard_normal(17).astype(np.float32)}
+    pk = str(tmp_path / "w.mt2")
+    A.save_packed(pk, sd)
+    back = A.load_packed(pk)
+    assert list(back) == list(sd)
+    for k in sd:
+        assert back[k].shape == sd[k].shape and np.array_equal(back[k], sd[k])

@@ -300,3 +300,59 @@ def test_prod_c2_properties():
     ref = O.synthesize(sd_g, sd_p, sd_a, g, p, a, u.phone, u.prompt_mel, forced_durations=u.durations,
                        forced_codes=u.p_codes)
     assert O.rel_l2(out[5, :lens[5]], ref["mel"]) < NORTH_STAR
+
+
+# ---------------------------------------------------------------------------------------------------
+# row f3: mel front-end on the GPU (extract_mel_spec, modules/tokenizer.py:107-125)
+
+
+def test_mel_frontend_matches_oracle():
+    from megatts2_amd.runtime import MelFrontEnd
+    from megatts2_amd import megatts2 as M
+    rng = np.random.default_rng(11)
+    lens = np.asarray([16000, 5000, 777, 12345], np.int32)
+    wav = np.zeros((4, 16000), np.float32)
+    for i, n in enumerate(lens):
+        t = np.arange(n) / 16000.0
+        wav[i, :n] = (0.3 * np.sin(2 * np.pi * (220.0 * (i + 1)) * t) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    fe = MelFrontEnd()
+    mel = fe(dev(wav), lens).cpu().numpy()
+    assert mel.shape == (4, 1 + 16000 // 256, 80)
+    for i, n in enumerate(lens):
+        ref = O.mel_spectrogram(wav[i, :n])
+        T = 1 + n // 256
+        assert ref.shape == (T, 80)
+        assert np.abs(mel[i, :T] - ref).max() < 2e-3            # log-mel, absolute
+        assert O.rel_l2(np.exp(mel[i, :T]), np.exp(ref)) < 1e-4  # linear mel
+        assert not mel[i, T:].any()
+    # mirror of the reference function: 1-D samples -> [80, T]
+    one = M.extract_mel_spec(torch.from_numpy(wav[1, :5000]))
+    assert tuple(one.shape) == (80, 1 + 5000 // 256)
+    assert np.abs(one.cpu().numpy().T - O.mel_spectrogram(wav[1, :5000])).max() < 2e-3
+    # silence hits the clamp floor exactly
+    z = fe(dev(np.zeros((1, 2048), np.float32))).cpu().numpy()
+    assert np.allclose(z, np.log(np.float32(1e-5)))
+
+
+def test_tiny_forward_from_wav_dir(tmp_path):
+    """Megatts.forward(wavs_dir, ...) (models/megatts2.py:325-375) with the in-repo front-end: *.wav ->
+    normalise -> GPU mel -> concatenated prompt -> synthesis -> prompt audio + generated audio -> test.wav."""
+    from megatts2_amd import audio_io as A
+    tts = model("tiny")
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("tiny")
+    rng = np.random.default_rng(5)
+    mels = []
+    for i, n in enumerate((6000, 4321)):
+        t = np.arange(n) / 16000.0
+        y = (0.4 * np.sin(2 * np.pi * 330.0 * (i + 1) * t) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+        A.write_wav(str(tmp_path / f"p{i}.wav"), y, 16000, "PCM_S16")
+        mels.append(O.mel_spectrogram(A.load_audio(str(tmp_path / f"p{i}.wav"))))
+    prompt = np.concatenate(mels, axis=0)
+    phone = rng.integers(0, g.mrte.phone_vocab_size, 6)
+    out_wav = str(tmp_path / "test.wav")
+    mel, lens, aux = tts.forward(str(tmp_path), phone_tokens=phone, out_path=out_wav)
+    ref = O.synthesize(sd_g, sd_p, sd_a, g, p, a, phone.astype(np.int64), prompt)
+    assert lens[0] == ref["mel"].shape[0]
+    assert O.rel_l2(mel[0, :lens[0]].cpu().numpy(), ref["mel"]) < NORTH_STAR
+    y, sr = A.read_wav(out_wav)
+    assert sr == 16000 and y.size == (mels[0].shape[0] + int(lens[0])) * h.hop

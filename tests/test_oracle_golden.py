@@ -90,3 +90,24 @@ def test_known_answers():
     # all-zero codebook -> every distance ties -> index 0 (lowest index)
     assert O.vq_quantize(np.zeros((16, 4), np.float32), np.ones((3, 4), np.float32)).tolist() == [0, 0, 0]
     assert O.max_pool1d_ceil(np.arange(10, dtype=np.float32)[:, None], 8)[:, 0].tolist() == [7, 9]
+
+
+def test_mel_frontend_restatement_against_torch_stft():
+    """Row f3.  torchaudio / speechbrain are not installed (parity unpinned); the STFT half of the oracle's
+    front-end is checked against torch.stft (the routine torchaudio.transforms.Spectrogram calls) and the
+    filterbank against its defining properties (slaney area normalisation, triangle peaks at the centres)."""
+    import torch
+    rng = np.random.default_rng(3)
+    wav = rng.standard_normal(5000).astype(np.float32) * 0.1
+    ref = torch.stft(torch.from_numpy(wav), 1024, 256, 1024, window=torch.hann_window(1024), center=True,
+                     pad_mode="reflect", normalized=False, onesided=True, return_complex=True).abs().T.numpy()
+    got = O.stft_magnitude(wav)
+    assert got.shape == ref.shape == (1 + 5000 // 256, 513)
+    assert O.rel_l2(got, ref) < 1e-5
+    fb = O.melscale_fbanks(513, 0.0, 8000.0, 80, 16000)
+    assert fb.shape == (513, 80) and (fb >= 0).all()
+    df = 8000.0 / 512
+    area = fb.sum(0) * df                      # slaney norm: every triangle has unit area (up to sampling)
+    assert np.allclose(area[5:], 1.0, atol=0.08)
+    mel = O.mel_spectrogram(wav)
+    assert mel.shape == (20, 80) and mel.dtype == np.float32 and mel.min() >= np.log(1e-5) - 1e-6

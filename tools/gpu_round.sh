@@ -23,6 +23,9 @@ bench5)
 sweep_voc)
   timeout 600 python tools/gemm_sweep.py voc > gpurun_out/gemm_sweep_voc.txt 2>&1
   echo "sweep_voc rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_voc.txt ;;
+frontend)
+  timeout 300 python tools/bench_frontend.py > gpurun_out/bench_frontend.log 2>&1
+  echo "frontend rc=$?"; tail -1 gpurun_out/bench_frontend.log | cut -c1-700 ;;
 bench1)
   timeout 600 python bench.py --workload C1 --steps 5 --warmup 2 > gpurun_out/bench_c1.log 2>&1
   echo "bench1 rc=$?"; tail -1 gpurun_out/bench_c1.log | cut -c1-1200 ;;

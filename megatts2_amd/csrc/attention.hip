@@ -121,12 +121,16 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
         }
 }
 
-// Register-resident form for D <= 128 (see the file header).  One wave per block.
+// Register-resident form for D <= 128 (see the file header).  The key tiles of one (utterance, head, 32
+// queries) are dealt round-robin to the 1..4 waves of the block (split-KV: a sequence of 70 positions is
+// three tiles - three waves finish in the time of one); the partial (m, l, O) states are merged through LDS
+// by wave 0 with the usual log-sum-exp rescale.
 template <int D>
-__global__ __launch_bounds__(64) void attn_f32_reg_kernel(AttnP p) {
+__global__ __launch_bounds__(256) void attn_f32_reg_kernel(AttnP p) {
     constexpr int NF = D / 8;      // float4 fragments per row along the head dim
     constexpr int DT = D / 32;     // 32-column output tiles
-    const int lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) float amem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
     int qs, ql, ks, kl;
@@ -135,27 +139,12 @@ __global__ __launch_bounds__(64) void attn_f32_reg_kernel(AttnP p) {
     } else {
         qs = b * p.u_qstride; ql = p.u_qlen; ks = b * p.u_kvstride; kl = p.u_kvlen;
     }
-    if (qt * 32 >= ql || kl <= 0) return;
+    if (qt * 32 >= ql || kl <= 0) return;          // block-uniform
     const int os = p.o_start ? p.o_start[b] : (p.q_start ? qs : b * (p.u_ostride ? p.u_ostride : p.u_qstride));
     const int qrow = qt * 32 + l31;
     const bool qok = qrow < ql;
     const float scale = p.scale;
-
-    float4 qf[NF], kf[NF], kn[NF];
-    {
-        const float* __restrict__ qptr =
-            p.Q + (long long)(qs + (qok ? qrow : qt * 32)) * p.ldq + h * D + 4 * half;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) qf[f] = *reinterpret_cast<const float4*>(qptr + 8 * f);
-    }
-    auto load_k = [&](int kv0, float4 (&dst)[NF]) {
-        const int kvrow = kv0 + l31;
-        const float* __restrict__ kptr =
-            p.K + (long long)(ks + (kvrow < kl ? kvrow : kv0)) * p.ldk + h * D + 4 * half;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) dst[f] = *reinterpret_cast<const float4*>(kptr + 8 * f);
-    };
-    load_k(0, kf);
+    const int kstep = 32 * nwv;
 
     float m_run = -INFINITY, l_run = 0.0f;
     f32x16 o[DT];
@@ -164,60 +153,104 @@ __global__ __launch_bounds__(64) void attn_f32_reg_kernel(AttnP p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[t][e] = 0.0f;
 
-    for (int kv0 = 0; kv0 < kl; kv0 += 32) {
-        // every load of this tile (V columns) and the next tile's K fragments go out before the first MFMA
-        float vr[DT][16];
-        const float* __restrict__ vcol = p.V + h * D + l31;
+    if (wave * 32 < kl) {
+        float4 qf[NF], kf[NF], kn[NF];
+        {
+            const float* __restrict__ qptr =
+                p.Q + (long long)(qs + (qok ? qrow : qt * 32)) * p.ldq + h * D + 4 * half;
 #pragma unroll
-        for (int t = 0; t < DT; ++t)
+            for (int f = 0; f < NF; ++f) qf[f] = *reinterpret_cast<const float4*>(qptr + 8 * f);
+        }
+        auto load_k = [&](int kv0, float4 (&dst)[NF]) {
+            const int kvrow = kv0 + l31;
+            const float* __restrict__ kptr =
+                p.K + (long long)(ks + (kvrow < kl ? kvrow : kv0)) * p.ldk + h * D + 4 * half;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) dst[f] = *reinterpret_cast<const float4*>(kptr + 8 * f);
+        };
+        load_k(wave * 32, kf);
+        for (int kv0 = wave * 32; kv0 < kl; kv0 += kstep) {
+            // every load of this tile (V columns) and this wave's next K fragments go out before the first MFMA
+            float vr[DT][16];
+            const float* __restrict__ vcol = p.V + h * D + l31;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    vr[t][e] = kvr < kl ? vcol[(long long)(ks + kvr) * p.ldv + t * 32] : 0.0f;
+                }
+            const bool more = kv0 + kstep < kl;
+            if (more) load_k(kv0 + kstep, kn);
+
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.0f;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].x, qf[f].x, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].y, qf[f].y, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].z, qf[f].z, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].w, qf[f].w, s, 0, 0, 0);
+            }
+            // s[e] = S^T[kv0 + (e&3) + 8*(e>>2) + 4*half][q = l31]
+            float mloc = -INFINITY;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                vr[t][e] = kvr < kl ? vcol[(long long)(ks + kvr) * p.ldv + t * 32] : 0.0f;
+                s[e] = kvr < kl ? s[e] * scale : -INFINITY;
+                mloc = fmaxf(mloc, s[e]);
             }
-        const bool more = kv0 + 32 < kl;
-        if (more) load_k(kv0 + 32, kn);
-
-        f32x16 s;
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float m_new = fmaxf(m_run, mloc);          // finite: key kv0 is always in range
+            const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
+            float lsum = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.0f;
+            for (int e = 0; e < 16; ++e) {
+                s[e] = expf(s[e] - m_new);
+                lsum += s[e];
+            }
+            lsum += __shfl_xor(lsum, 32);
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
 #pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].x, qf[f].x, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].y, qf[f].y, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].z, qf[f].z, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].w, qf[f].w, s, 0, 0, 0);
+            for (int t = 0; t < DT; ++t) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[t][e], s[e], o[t], 0, 0, 0);
+            }
+            if (more) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) kf[f] = kn[f];
+            }
         }
-        // s[e] = S^T[kv0 + (e&3) + 8*(e>>2) + 4*half][q = l31]
-        float mloc = -INFINITY;
+    }
+    if (nwv > 1) {                                 // merge the per-wave partial states (block-uniform branch)
+        constexpr int WS = (DT * 16 + 2) * 64;     // floats per wave: O^T tiles, m, l; [.][lane] = conflict-free
+        if (wave > 0) {
+            float* mine = amem + (wave - 1) * WS + lane;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-            s[e] = kvr < kl ? s[e] * scale : -INFINITY;
-            mloc = fmaxf(mloc, s[e]);
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mine[(t * 16 + e) * 64] = o[t][e];
+            mine[DT * 16 * 64] = m_run;
+            mine[(DT * 16 + 1) * 64] = l_run;
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-        const float m_new = fmaxf(m_run, mloc);          // finite: key kv0 is always in range
-        const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
-        float lsum = 0.0f;
+        __syncthreads();
+        if (wave > 0) return;
+        for (int w = 1; w < nwv; ++w) {
+            const float* oth = amem + (w - 1) * WS + lane;
+            const float m_o = oth[DT * 16 * 64], l_o = oth[(DT * 16 + 1) * 64];
+            const float m_new = fmaxf(m_run, m_o);           // wave 0 always has key tile 0: finite
+            const float a0 = expf(m_run - m_new), a1 = expf(m_o - m_new);   // exp(-inf) = 0 for an idle wave
+            l_run = l_run * a0 + l_o * a1;
+            m_run = m_new;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            s[e] = expf(s[e] - m_new);
-            lsum += s[e];
-        }
-        lsum += __shfl_xor(lsum, 32);
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
+            for (int t = 0; t < DT; ++t)
 #pragma unroll
-        for (int t = 0; t < DT; ++t) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[t][e], s[e], o[t], 0, 0, 0);
-        }
-        if (more) {
-#pragma unroll
-            for (int f = 0; f < NF; ++f) kf[f] = kn[f];
+                for (int e = 0; e < 16; ++e) o[t][e] = o[t][e] * a0 + oth[(t * 16 + e) * 64] * a1;
         }
     }
     if (!qok) return;
@@ -240,12 +273,19 @@ hipError_t launch_attention(const AttnP& p, hipStream_t s) {
     if (p.B <= 0 || p.H <= 0 || p.max_qlen <= 0) return hipSuccess;
     if (p.D % 32 != 0 || (p.ldq & 3) || (p.ldk & 3) || (p.ldo & 3)) return hipErrorInvalidValue;
     if (p.D <= 128) {
-        dim3 grid((p.max_qlen + 31) / 32, p.H, p.B), block(64);
+        // split-KV width: the longest key range of the launch (uniform geometry knows it exactly; ragged
+        // launches pass max_kvlen, 0 = unknown -> assume as long as the queries)
+        int kvmax = p.q_start ? (p.max_kvlen > 0 ? p.max_kvlen : p.max_qlen) : p.u_kvlen;
+        int nwv = (kvmax + 31) / 32;
+        nwv = nwv < 1 ? 1 : (nwv > 4 ? 4 : nwv);
+        const int DT = p.D / 32;
+        const size_t lds = nwv > 1 ? (size_t)(nwv - 1) * (DT * 16 + 2) * 64 * sizeof(float) : 0;
+        dim3 grid((p.max_qlen + 31) / 32, p.H, p.B), block(64 * nwv);
         switch (p.D) {
-            case 32: hipLaunchKernelGGL(attn_f32_reg_kernel<32>, grid, block, 0, s, p); break;
-            case 64: hipLaunchKernelGGL(attn_f32_reg_kernel<64>, grid, block, 0, s, p); break;
-            case 96: hipLaunchKernelGGL(attn_f32_reg_kernel<96>, grid, block, 0, s, p); break;
-            default: hipLaunchKernelGGL(attn_f32_reg_kernel<128>, grid, block, 0, s, p); break;
+            case 32: hipLaunchKernelGGL(attn_f32_reg_kernel<32>, grid, block, lds, s, p); break;
+            case 64: hipLaunchKernelGGL(attn_f32_reg_kernel<64>, grid, block, lds, s, p); break;
+            case 96: hipLaunchKernelGGL(attn_f32_reg_kernel<96>, grid, block, lds, s, p); break;
+            default: hipLaunchKernelGGL(attn_f32_reg_kernel<128>, grid, block, lds, s, p); break;
         }
         return hipGetLastError();
     }

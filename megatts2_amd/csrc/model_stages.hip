@@ -172,7 +172,8 @@ static void attention_self(const Ctx& c, const EncW& e, const AttnGeom& g, const
     a.O = att; a.ldo = d;
     a.q_start = g.start; a.q_len = g.len; a.kv_start = g.start; a.kv_len = g.len;
     a.u_qstride = g.u_stride; a.u_qlen = g.u_len; a.u_kvstride = g.u_stride; a.u_kvlen = g.u_len;
-    a.B = g.B; a.H = e.heads; a.D = D; a.max_qlen = g.max_len; a.scale = 1.0f / std::sqrt((float)D);
+    a.B = g.B; a.H = e.heads; a.D = D; a.max_qlen = g.max_len; a.max_kvlen = g.max_len;
+    a.scale = 1.0f / std::sqrt((float)D);
     MT2_HIP(launch_attention(a, c.s));
 }
 static void encoder_layer(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int M, const AttnGeom& g,
@@ -416,7 +417,7 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
     AttnP a{};
     a.Q = q; a.ldq = H; a.K = kv; a.ldk = 2 * H; a.V = kv + H; a.ldv = 2 * H; a.O = sc.att; a.ldo = H;
     a.q_start = P.d_start; a.q_len = P.d_len; a.kv_start = mp.X.d_start; a.kv_len = mp.X.d_len;
-    a.B = B; a.H = 1; a.D = H; a.max_qlen = P.maxlen; a.scale = 1.0f / std::sqrt((float)H);
+    a.B = B; a.H = 1; a.D = H; a.max_qlen = P.maxlen; a.max_kvlen = mp.X.maxlen; a.scale = 1.0f / std::sqrt((float)H);
     MT2_HIP(launch_attention(a, c.s));
     float* o = c.ws.get<float>((size_t)P.R * H);
     linear(c, sc.att, H, P.R, m.x_wo, m.x_bo, H, H, o, H);

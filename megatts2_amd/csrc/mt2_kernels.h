@@ -64,6 +64,7 @@ struct AttnP {
     const int* q_start; const int* q_len; const int* kv_start; const int* kv_len; const int* o_start;
     int u_qstride, u_qlen, u_kvstride, u_kvlen, u_ostride;
     int B, H, D, max_qlen; float scale;
+    int max_kvlen;   // ragged launches: longest key range (0 = unknown), sizes the split-KV width
 };
 hipError_t launch_attention(const AttnP& p, hipStream_t s);
 

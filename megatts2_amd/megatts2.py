@@ -151,6 +151,12 @@ class MegaG:
         _, codes = self.native.vqpe_forward(mel_vqpe)
         return self.native.tc_latent(phone, mel_mrte, phone_lens), codes
 
+    def extract_latent(self, path: str, phone, phone_lens, mel_mrte, mel_vqpe) -> None:
+        """One item of `prepare_ds.py --stage 2` (prepare_ds.py:224-258): s2_latent of a batch-1 item saved as
+        the reference's `{spk}/{id}.npy` pickle: {'tc_latent': [1, Np, 512] f32, 'p_code': [1, 1, Tq] int64}."""
+        tc, codes = self.s2_latent(phone, phone_lens, mel_mrte, mel_vqpe)
+        np.save(path, {"tc_latent": tc.cpu().numpy(), "p_code": codes.cpu().numpy()})
+
     def eval(self):
         return self
 

@@ -356,3 +356,19 @@ def test_tiny_forward_from_wav_dir(tmp_path):
     assert O.rel_l2(mel[0, :lens[0]].cpu().numpy(), ref["mel"]) < NORTH_STAR
     y, sr = A.read_wav(out_wav)
     assert sr == 16000 and y.size == (mels[0].shape[0] + int(lens[0])) * h.hop
+
+
+def test_tiny_s2_latent_extraction(tiny_batch, tmp_path):
+    """Row f2: MegaG.s2_latent (models/megatts2.py:75-84) and the latents/{spk}/{id}.npy record of
+    prepare_ds.py:224-258 - tc_latent within tolerance, prosody codes bit-exact."""
+    tts = model("tiny")
+    z = tiny_batch[1]
+    phone, pm, tm = dev(z["phone"][None]), dev(z["prompt_mel"][None]), dev(z["target_mel"][None])
+    tc, codes = tts.generator.s2_latent(phone, np.asarray([z["phone"].size], np.int32), pm, tm)
+    assert O.rel_l2(tc[0].cpu().numpy(), z["tc_latent"]) < TIGHT
+    assert np.array_equal(codes[0, 0].cpu().numpy(), z["vqpe_codes"])
+    f = str(tmp_path / "utt.npy")
+    tts.generator.extract_latent(f, phone, np.asarray([z["phone"].size], np.int32), pm, tm)
+    rec = np.load(f, allow_pickle=True).item()
+    assert set(rec) == {"tc_latent", "p_code"} and rec["p_code"].dtype == np.int64
+    assert np.array_equal(rec["p_code"][0, 0], z["vqpe_codes"]) and rec["tc_latent"].shape == (1,) + z["tc_latent"].shape

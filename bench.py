@@ -103,6 +103,7 @@ def main() -> None:
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--thresh", default="", help="debug: tile-choice thresholds 'ks4_tiles,ks2_tiles,m32_rows'")
     ap.add_argument("--ar-groups", type=int, default=0, help="AR stream groups (default: the library's, 2)")
+    ap.add_argument("--no-splitk", action="store_true", help="debug: disable split-K through the LayerNorm")
     args = ap.parse_args()
 
     import torch
@@ -137,6 +138,8 @@ def main() -> None:
     model = NativeModel(g, p, a, h, sd_g, sd_p, sd_a, sd_h)
     if args.ar_groups:
         model.set_ar_groups(args.ar_groups)
+    if args.no_splitk:
+        model.lib.mt2_debug_set_splitk(0)
     if args.thresh:
         t = [int(v) for v in args.thresh.split(",")]
         model.lib.mt2_debug_set_thresholds(t[0], t[1], t[2])

@@ -156,13 +156,16 @@ struct AttnGeom {
     const int* start = nullptr; const int* len = nullptr;
     int u_stride = 0, u_len = 0, B = 0, max_len = 0;
 };
-struct EncScratch { float *h, *qkv, *att, *f; };
+struct EncScratch { float *h, *qkv, *att, *f, *parts; };
+static bool g_no_splitk = false;
 static EncScratch enc_scratch(const Ctx& c, const EncW& e, int M) {
     EncScratch s;
     s.h = c.ws.get<float>((size_t)M * e.d);
     s.qkv = c.ws.get<float>((size_t)M * 3 * e.d);
     s.att = c.ws.get<float>((size_t)M * e.d);
     s.f = c.ws.get<float>((size_t)M * e.ff);
+    // split-K slabs: choose_split keeps tiles(32x64) * S <= 256, i.e. S * M * d <= 256 * 32 * 64 * (d / 64 tiles)
+    s.parts = c.ws.get<float>((size_t)256 * 32 * 64 + (size_t)16 * 32 * e.d);
     return s;
 }
 static void attention_self(const Ctx& c, const EncW& e, const AttnGeom& g, const float* qkv, float* att) {
@@ -196,18 +199,86 @@ static void encoder_layer(const Ctx& c, const EncW& e, const EncLayerW& w, float
     }
 }
 
-// ---- autoregressive-step forms of the encoder layer (Linear-FF encoders only).  Both are exact
-// identities of TransformerEncoderLayer.forward, not approximations:
+// ---- autoregressive-step forms of the encoder layer (Linear-FF encoders only).  All of them are exact
+// identities of TransformerEncoderLayer.forward (modules/transformer.py:88-102), not approximations.
 //
+// Split-K through the LayerNorm.  A GEMM of the early / middle steps has too few tiles for the chip, and a
+// tile's serial K chain is its latency floor (K = 4096 in the PLM's second feed-forward: 45 us at any M).
+// Such a GEMM runs as S independent K slices (GemmP groups: slice g reads columns [g*K/S, (g+1)*K/S) of both
+// operands and writes a raw partial slab) and the NEXT LayerNorm - a launch the layer has anyway - sums the
+// slabs in fixed order, adds bias and residual, writes the residual stream and its normalisation
+// (launch_ln_reduce).  Deterministic, no extra launch, no inter-workgroup hand-off.
+struct Pending {              // a residual update not yet applied: x += bias + sum_g parts[g]
+    const float* parts = nullptr; long long pstride = 0; int S = 0; const float* bias = nullptr;
+};
+static int choose_split(int M, int N, int K) {
+    if (g_no_splitk) return 1;
+    const long long tiles = (long long)((M + 31) / 32) * ((N + 63) / 64);
+    int S = 1;
+    while (S < 16 && tiles * (S * 2) <= 256 && K % (S * 2) == 0 && K / (S * 2) >= 256 && (K / (S * 2)) % 32 == 0) S *= 2;
+    return S;
+}
+// y_parts[g] = x[:, gK/S:(g+1)K/S] @ W[:, gK/S:(g+1)K/S]^T, g < S  (raw partial slabs [S][M, N])
+static void linear_splitk(const Ctx& c, const float* x, int ldx, int M, const float* W, int N, int K, int S,
+                          float* parts) {
+    GemmP p{};
+    p.X = x; p.strideX = K / S; p.ldx = ldx; p.Rx = M; p.Cin = K / S; p.W = W; p.strideW = K / S; p.ldw = K;
+    p.C = parts; p.strideC = (long long)M * N; p.ldc = N; p.M = M; p.N = N; p.groups = S;
+    gemm(c, p);
+}
+// h = LayerNorm(x) after applying a pending update to x (in place)
+static void ln_pending(const Ctx& c, float* x, int d, int M, const Pending& in, const float* g, const float* b,
+                       float* h) {
+    if (in.S == 0) { layernorm(c, x, d, g, b, M, d, h, d); return; }
+    LnReduceP p{};
+    p.parts = in.parts; p.pstride = in.pstride; p.S = in.S; p.bias = in.bias; p.R = x; p.ldr = d;
+    p.gamma = g; p.beta = b; p.xout = x; p.ldx = d; p.hout = h; p.ldh = d; p.M = M; p.C = d; p.eps = 1e-5f;
+    MT2_HIP(launch_ln_reduce(p, c.s));
+}
+// everything after attention for M full rows: x += out_proj(att); h = LN2(x); f = relu(ff0(h));
+// x += ff1(f) - the last update is returned as pending when it was split
+static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int M, const float* att,
+                             const EncScratch& s) {
+    const int d = e.d;
+    const int S1 = choose_split(M, d, d);
+    if (S1 > 1) {
+        linear_splitk(c, att, d, M, w.wo, d, d, S1, s.parts);
+        Pending p1{s.parts, (long long)M * d, S1, w.bo};
+        ln_pending(c, x, d, M, p1, w.ln2g, w.ln2b, s.h);
+    } else {
+        linear(c, att, d, M, w.wo, w.bo, d, d, x, d, x, d);
+        layernorm(c, x, d, w.ln2g, w.ln2b, M, d, s.h, d);
+    }
+    linear(c, s.h, d, M, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, nullptr, 0, nullptr, ACT_RELU);
+    const int S2 = choose_split(M, d, e.ff);
+    if (S2 > 1) {
+        linear_splitk(c, s.f, e.ff, M, w.ff1w, d, e.ff, S2, s.parts);
+        return Pending{s.parts, (long long)M * d, S2, w.ff1b};
+    }
+    linear(c, s.f, e.ff, M, w.ff1w, w.ff1b, d, e.ff, x, d, x, d);
+    return Pending{};
+}
+
+// MIDDLE layer over M = A*n compact rows
+static Pending encoder_layer_ar(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int M, const AttnGeom& g,
+                                const EncScratch& s, const Pending& in) {
+    MT2_REQUIRE(!e.conv_ff, "AR step layers use the Linear feed-forward");
+    const int d = e.d;
+    ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
+    linear(c, s.h, d, M, w.wqkv, w.bqkv, 3 * d, d, s.qkv, 3 * d);
+    attention_self(c, e, g, s.qkv, s.att);
+    return ar_layer_tail(c, e, w, x, M, s.att, s);
+}
+
 // LAST layer: only row n-1 of each sequence is consumed downstream (models/megatts2.py:178,272).  LayerNorm
 // and the K/V projections are row-wise and needed for all rows; attention row i depends on query row i only,
 // and out-projection, norm2 and the feed-forward are row-wise - so Q, attention, out-proj, LN2 and FF are
 // evaluated for the A last rows only.  x: [A*n, d] compact step rows; y: [A, d] result rows.
-static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, const float* x, int n, int A,
-                               const EncScratch& s, float* y) {
+static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int n, int A,
+                               const EncScratch& s, float* y, const Pending& in) {
     MT2_REQUIRE(!e.conv_ff, "AR step layers use the Linear feed-forward");
     const int d = e.d, M = A * n, D = d / e.heads;
-    layernorm(c, x, d, w.ln1g, w.ln1b, M, d, s.h, d);
+    ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
     float* kv = s.qkv;                                   // [M, 2d]: K | V
     linear(c, s.h, d, M, w.wqkv + (size_t)d * d, w.bqkv + d, 2 * d, d, kv, 2 * d);
     float* q = s.att;                                    // [A, d]
@@ -235,8 +306,8 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
 // so LN1 -> QKV of position i is computed once, at step i, into a per-sequence cache with a FIXED row
 // stride (slot j owns rows [j*cs, j*cs + n)); every later step only adds row n-1.  Attention reads the
 // cache and writes compact rows; the rest of the layer is the ordinary full-row form.
-static void encoder_layer_first_cached(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int n, int A,
-                                       float* qkv_cache, int cs, const EncScratch& s) {
+static Pending encoder_layer_first_cached(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int n, int A,
+                                          float* qkv_cache, int cs, const EncScratch& s) {
     MT2_REQUIRE(!e.conv_ff, "AR step layers use the Linear feed-forward");
     const int d = e.d, M = A * n, D = d / e.heads;
     // LN1 + QKV of the newest row of every active sequence
@@ -258,10 +329,7 @@ static void encoder_layer_first_cached(const Ctx& c, const EncW& e, const EncLay
     a.u_qstride = cs; a.u_qlen = n; a.u_kvstride = cs; a.u_kvlen = n; a.u_ostride = n;
     a.B = A; a.H = e.heads; a.D = D; a.max_qlen = n; a.scale = 1.0f / std::sqrt((float)D);
     MT2_HIP(launch_attention(a, c.s));
-    linear(c, s.att, d, M, w.wo, w.bo, d, d, x, d, x, d);
-    layernorm(c, x, d, w.ln2g, w.ln2b, M, d, s.h, d);
-    linear(c, s.h, d, M, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, nullptr, 0, nullptr, ACT_RELU);
-    linear(c, s.f, e.ff, M, w.ff1w, w.ff1b, d, e.ff, x, d, x, d);
+    return ar_layer_tail(c, e, w, x, M, s.att, s);
 }
 
 // One AR step of an encoder over A sequences of n positions (x: [A*n, d], overwritten); the rows the head
@@ -271,10 +339,11 @@ static const float* ar_step_layers(const Ctx& c, const EncW& e, float* x, int n,
     const int L = (int)e.layers.size();
     AttnGeom g;
     g.u_stride = n; g.u_len = n; g.B = A; g.max_len = n;
+    Pending pend;
     for (int l = 0; l < L; ++l) {
-        if (l == L - 1) encoder_layer_last(c, e, e.layers[l], x, n, A, sc, ylast);
-        else if (l == 0 && qkv_cache) encoder_layer_first_cached(c, e, e.layers[l], x, n, A, qkv_cache, cs, sc);
-        else encoder_layer(c, e, e.layers[l], x, A * n, g, nullptr, sc);
+        if (l == L - 1) encoder_layer_last(c, e, e.layers[l], x, n, A, sc, ylast, pend);
+        else if (l == 0 && qkv_cache) pend = encoder_layer_first_cached(c, e, e.layers[l], x, n, A, qkv_cache, cs, sc);
+        else pend = encoder_layer_ar(c, e, e.layers[l], x, A * n, g, sc, pend);
     }
     return ylast;
 }

@@ -53,6 +53,17 @@ struct LnP {
 };
 hipError_t launch_layernorm(const LnP& p, hipStream_t s);
 
+// Split-K consumer (rowops.hip): x_new = R + bias + sum_g parts[g] (g = 0..S-1, fixed order);
+// xout = x_new (may alias R; nullable), hout = LayerNorm(x_new) * gamma + beta.  parts[g] = parts + g*pstride, [M, C] dense.
+struct LnReduceP {
+    const float* parts; long long pstride; int S;
+    const float* bias; const float* R; int ldr;
+    const float* gamma; const float* beta;
+    float* xout; int ldx; float* hout; int ldh;
+    int M, C; float eps;
+};
+hipError_t launch_ln_reduce(const LnReduceP& p, hipStream_t s);
+
 // Non-causal multi-head attention over per-utterance row ranges (flash-style, f32 MFMA).
 //   Q rows of utterance b: [q_start[b], q_start[b]+q_len[b]) in Q (ld ldq), head h at column h*D.
 //   K/V likewise with kv_start/kv_len.  If q_start == nullptr the batch is uniform:

@@ -92,6 +92,73 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
     }
 }
 
+// Split-K consumer: x_new[m, :] = R[m, :] + bias + sum_{g < S} parts[g][m, :]  (fixed order g = 0..S-1),
+// xout = x_new (the residual stream), hout = LayerNorm(x_new).  The GEMM that produced `parts` ran as S
+// independent K slices (GemmP groups) and skipped its epilogue; the kernel boundary is the only
+// synchronisation, the reduction is deterministic, and no launch is added: this IS the layer's LayerNorm.
+__global__ __launch_bounds__(256) void ln_reduce_kernel(LnReduceP p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= p.M) return;
+    const int C = p.C;
+    float4 x[4];
+    float s = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+            for (int g = 0; g < p.S; ++g) {
+                const float4 q = *reinterpret_cast<const float4*>(p.parts + (long long)g * p.pstride + (long long)m * C + c);
+                a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+            }
+            if (p.bias) {
+                const float4 q = *reinterpret_cast<const float4*>(p.bias + c);
+                a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+            }
+            if (p.R) {   // residual last, as the fused GEMM epilogue does: (acc + bias) + R
+                const float4 q = *reinterpret_cast<const float4*>(p.R + (long long)m * p.ldr + c);
+                a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+            }
+            if (p.xout) *reinterpret_cast<float4*>(p.xout + (long long)m * p.ldx + c) = a;
+        }
+        x[v] = a;
+        s += (a.x + a.y) + (a.z + a.w);
+    }
+    const float inv_c = 1.0f / (float)C;
+    const float mean = wave_sum(s) * inv_c;
+    float q2 = 0.0f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < C) {
+            x[v].x -= mean; x[v].y -= mean; x[v].z -= mean; x[v].w -= mean;
+            q2 += (x[v].x * x[v].x + x[v].y * x[v].y) + (x[v].z * x[v].z + x[v].w * x[v].w);
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q2) * inv_c + p.eps);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int c = (v * 64 + lane) * 4;
+        if (c < C) {
+            const float4 gv = *reinterpret_cast<const float4*>(p.gamma + c);
+            const float4 bv = *reinterpret_cast<const float4*>(p.beta + c);
+            float4 y;
+            y.x = x[v].x * rstd * gv.x + bv.x;
+            y.y = x[v].y * rstd * gv.y + bv.y;
+            y.z = x[v].z * rstd * gv.z + bv.z;
+            y.w = x[v].w * rstd * gv.w + bv.w;
+            *reinterpret_cast<float4*>(p.hout + (long long)m * p.ldh + c) = y;
+        }
+    }
+}
+hipError_t launch_ln_reduce(const LnReduceP& p, hipStream_t s) {
+    if (p.M <= 0) return hipSuccess;
+    if (p.C > 1024 || (p.C & 3) || (p.ldx & 3) || (p.ldh & 3) || (p.ldr & 3) || p.S < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3((p.M + 3) / 4), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_layernorm(const LnP& p, hipStream_t s) {
     if (p.M <= 0) return hipSuccess;
     if (p.C > 1024 || (p.C & 3) || (p.ldx & 3) || (p.ldo & 3)) return hipErrorInvalidValue;

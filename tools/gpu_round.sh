@@ -60,19 +60,25 @@ probe)
   echo "probe rc=$?"; grep -v "^W2026\|amdgpu.ids" gpurun_out/probe.log | tail -14
   python tools/pmc_probe_summary.py gpurun_out/probe | tee gpurun_out/probe_summary.txt | cut -c1-400
   find gpurun_out/probe -name "*.csv" -size +4M -delete ;;
+splitk)
+  for w in C2 C3; do for f in "" "--no-splitk"; do
+    timeout 600 python bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-roofline $f > gpurun_out/bench_sk.log 2>&1
+    echo "splitk $w '$f' rc=$?"; tail -1 gpurun_out/bench_sk.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+  done; done ;;
 thresh)
   for t in 0,0,0 512,1024,32; do
     timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --thresh $t > gpurun_out/bench_t_$t.log 2>&1
     echo "thresh $t rc=$?"; tail -1 gpurun_out/bench_t_$t.log | cut -c1-400
   done ;;
 pmc)
-  for c in FETCH_SIZE WRITE_SIZE; do
-    rm -rf gpurun_out/pmc_$c
-    (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline) > gpurun_out/pmc_$c.log 2>&1
-    echo "pmc $c rc=$?"; tail -1 gpurun_out/pmc_$c.log | cut -c1-300
-    f=$(find gpurun_out/pmc_$c -name "*counter_collection.csv" | head -1)
-    [ -n "$f" ] && python tools/pmc_summary.py "$f" 2 gpurun_out/pmc_$c.md | tail -8
-    find gpurun_out/pmc_$c -name "*.csv" -size +8M -delete
+  for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES"; do
+    t=$(echo $c | cut -d" " -f1)
+    rm -rf gpurun_out/pmc_$t
+    (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$t -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline) > gpurun_out/pmc_$t.log 2>&1
+    echo "pmc $t rc=$?"; tail -1 gpurun_out/pmc_$t.log | cut -c1-300
+    f=$(find gpurun_out/pmc_$t -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python tools/pmc_summary.py "$f" 2 gpurun_out/pmc_$t.md | tail -8
+    find gpurun_out/pmc_$t -name "*.csv" -size +8M -delete
   done ;;
 esac
 done

@@ -640,12 +640,8 @@ static const TileCfg* choose_cfg(const GemmP& p, int* idx_out) {
     return &kCfgs[bi];
 }
 
-static int g_debug_mode = 0;
-extern "C" void mt2_debug_gemm_mode(int mode) { g_debug_mode = mode; }
-
 hipError_t launch_gemm(const GemmP& p_in, hipStream_t s) {
     GemmP p = p_in;
-    p.debug = g_debug_mode;
     if (p.M <= 0 || p.N <= 0 || p.groups <= 0) return hipSuccess;
     if ((p.Cin & 3) || (p.ldx & 3) || (p.ldw & 3) || p.K != p.taps * p.Cin) return hipErrorInvalidValue;
     int idx = 0;

@@ -32,8 +32,7 @@ struct GemmP {
     const int* valid;
     float* C; long long strideC; int ldc;
     int M, N, K, groups;
-    int pro_act; float pro_slope; int epi_act; float out_scale;
-    int debug;   // measurement only (v2 kernel): 1 = skip the in-loop operand DMA, 2 = skip the MFMAs
+    int pro_act; float pro_slope; int epi_act; float out_scale;   // pro_slope doubles as the epilogue parameter (ACT_LOGCLAMP)
 };
 hipError_t launch_gemm(const GemmP& p, hipStream_t s);
 const char* gemm_last_config();     // name of the tile configuration the last launch used

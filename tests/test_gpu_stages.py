@@ -372,3 +372,37 @@ def test_tiny_s2_latent_extraction(tiny_batch, tmp_path):
     rec = np.load(f, allow_pickle=True).item()
     assert set(rec) == {"tc_latent", "p_code"} and rec["p_code"].dtype == np.int64
     assert np.array_equal(rec["p_code"][0, 0], z["vqpe_codes"]) and rec["tc_latent"].shape == (1,) + z["tc_latent"].shape
+
+
+def test_error_behaviour_matches_reference_exceptions(tiny_batch):
+    """The C ABI never throws and never falls back: conditions on which the reference asserts / raises come
+    back as an error code + message (NativeError), and the handle stays usable afterwards."""
+    from megatts2_amd.runtime import NativeError, NativeModel
+    from megatts2_amd import config as C, weights
+    tts = model("tiny")
+    z = tiny_batch[0]
+    phone, mel = dev(z["phone"][None]), dev(z["prompt_mel"][None])
+    with pytest.raises(NativeError, match="length"):                       # length beyond the padded tensor
+        tts.native.tc_latent(phone, mel, phone_lens=np.asarray([phone.shape[1] + 1], np.int32))
+    with pytest.raises(NativeError, match="length"):
+        tts.native.adm_infer(dev(z["tc_latent"][None]), np.asarray([0], np.int32))
+    dur = z["forced_dur"][None].astype(np.int32)
+    with pytest.raises(NativeError, match="Tm_max"):                       # output smaller than sum(durations)
+        B, Np, D = 1, dur.shape[1], 64
+        out = torch.empty(1, 3, D, device="cuda")
+        from megatts2_amd import runtime as rt
+        x = dev(z["tc_latent"][None])
+        rt._check(tts.native.lib.mt2_length_regulate(tts.native.h, rt._stream(), rt._ptr(x), rt._iptr(dur),
+                                                     rt._iptr(np.asarray([Np], np.int32)), Np, D, 1, rt._ptr(out), 3))
+    with pytest.raises(NativeError, match="PLM"):                          # component not loaded into the handle
+        g = C.tiny_g()
+        only_g = NativeModel(g_cfg=g, plm_cfg=C.tiny_plm(), adm_cfg=C.tiny_adm(), hg_cfg=C.tiny_hifigan(),
+                             sd_g=synth_models("tiny")[1][0])
+        only_g.plm_infer(dev(z["plm_cond"][None]))
+    with pytest.raises(NativeError, match="missing tensor|shape mismatch"):  # load_state_dict(strict=True)
+        bad = dict(synth_models("tiny")[1][2])
+        bad.pop("layers.0.norm1.weight")
+        NativeModel(g_cfg=C.tiny_g(), plm_cfg=C.tiny_plm(), adm_cfg=C.tiny_adm(), hg_cfg=C.tiny_hifigan(), sd_adm=bad)
+    # the shared handle still works
+    out = tts.native.tc_latent(phone, mel).cpu().numpy()
+    assert O.rel_l2(out[0], z["tc_latent"]) < TIGHT

@@ -104,6 +104,9 @@ def main() -> None:
     ap.add_argument("--thresh", default="", help="debug: tile-choice thresholds 'ks4_tiles,ks2_tiles,m32_rows'")
     ap.add_argument("--ar-groups", type=int, default=0, help="AR stream groups (default: the library's, 2)")
     ap.add_argument("--no-splitk", action="store_true", help="debug: disable split-K through the LayerNorm")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="test hook: exercise the launch / sharding / all-gather / reporting logic of this script on "
+                         "CPU (gloo) with a stand-in engine - measures nothing")
     args = ap.parse_args()
 
     import torch
@@ -112,13 +115,19 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    dry = args.dry_run_cpu
+    if dry:
+        dev = torch.device("cpu")
+        sync = lambda: None                                              # noqa: E731
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group("gloo" if dry else "nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     import megatts2_oracle as O
     from megatts2_amd import config as C
@@ -127,22 +136,30 @@ def main() -> None:
     from megatts2_amd.runtime import NativeModel, gemm_trace_begin, gemm_trace_end
 
     g, p, a, h = C.production_g(), C.production_plm(), C.production_adm(), C.production_hifigan()
-    sd_g = weights.synth_state_dict(weights.inventory_g(g), 0, "G.")
-    emb = np.load(os.path.join(ROOT, "tests", "golden", "codebook_prod.npy"))
-    sd_g[O.CODEBOOK] = emb
-    sd_g[O.CODEBOOK.replace("embed", "embed_avg")] = emb.copy()
-    sd_a = weights.synth_state_dict(weights.inventory_adm(a), 0, "adm.")
     full = args.workload in ("C3", "C5")
-    sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.") if full else None
-    sd_h = weights.synth_state_dict(weights.inventory_hifigan(h), 0, "hifigan.") if full else None
-    model = NativeModel(g, p, a, h, sd_g, sd_p, sd_a, sd_h)
-    if args.ar_groups:
-        model.set_ar_groups(args.ar_groups)
-    if args.no_splitk:
-        model.lib.mt2_debug_set_splitk(0)
-    if args.thresh:
-        t = [int(v) for v in args.thresh.split(",")]
-        model.lib.mt2_debug_set_thresholds(t[0], t[1], t[2])
+    sd_g = sd_p = sd_a = sd_h = None
+    if dry:
+        class _StandIn:                                                  # shapes only; never used for a measurement
+            def synthesize_batch(self, phone, pl, mel_in, ml, forced_dur=None, tm_cap=None, **_):
+                lens = forced_dur.sum(axis=1).astype(np.int32)
+                return torch.zeros(phone.shape[0], tm_cap, g.mrte.mel_bins), lens
+        model = _StandIn()
+    else:
+        sd_g = weights.synth_state_dict(weights.inventory_g(g), 0, "G.")
+        emb = np.load(os.path.join(ROOT, "tests", "golden", "codebook_prod.npy"))
+        sd_g[O.CODEBOOK] = emb
+        sd_g[O.CODEBOOK.replace("embed", "embed_avg")] = emb.copy()
+        sd_a = weights.synth_state_dict(weights.inventory_adm(a), 0, "adm.")
+        sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.") if full else None
+        sd_h = weights.synth_state_dict(weights.inventory_hifigan(h), 0, "hifigan.") if full else None
+        model = NativeModel(g, p, a, h, sd_g, sd_p, sd_a, sd_h)
+        if args.ar_groups:
+            model.set_ar_groups(args.ar_groups)
+        if args.no_splitk:
+            model.lib.mt2_debug_set_splitk(0)
+        if args.thresh:
+            t = [int(v) for v in args.thresh.split(",")]
+            model.lib.mt2_debug_set_thresholds(t[0], t[1], t[2])
 
     shape = synth.SHAPES[args.workload]
     B = args.batch or shape.B
@@ -167,17 +184,17 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -203,7 +220,9 @@ def main() -> None:
                 "sr22050": round(elapsed / args.steps / (total_frames * 256 / 22050), 6)},
     }
 
-    if rank == 0 and not args.no_roofline:
+    if dry:
+        result["data"] = "DRY RUN on CPU with a stand-in engine: not a measurement"
+    if rank == 0 and not args.no_roofline and not dry:
         # one traced step: HIP events around every GEMM/conv launch on the launch stream
         model.set_profiling(True)
         gemm_trace_begin()
@@ -242,7 +261,7 @@ def main() -> None:
                             "tflops": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2)} for r in tr],
         }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         # the oracle (numpy port of the reference path) on ONE utterance of the same workload
         try:
             from threadpoolctl import threadpool_info

@@ -158,7 +158,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f32_kernel(GemmP p) {
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    // an XCD's contiguous run of tiles walks the LARGER operand's tiles slowest, so that each of the 8 L2s
+    // streams only its slice of it and re-reads the smaller one (AR steps: M rows < N weight rows -> n-major)
+    const bool nmajor = p.M < p.N;
+    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
 
     const float* __restrict__ X = p.X + (long long)g * p.strideX;
     const float* __restrict__ W = p.W + (long long)g * p.strideW;
@@ -315,7 +318,10 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    // an XCD's contiguous run of tiles walks the LARGER operand's tiles slowest, so that each of the 8 L2s
+    // streams only its slice of it and re-reads the smaller one (AR steps: M rows < N weight rows -> n-major)
+    const bool nmajor = p.M < p.N;
+    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
 
     const float* __restrict__ X = p.X + (long long)g * p.strideX;
     const float* __restrict__ W = p.W + (long long)g * p.strideW;

@@ -401,7 +401,7 @@ def test_error_behaviour_matches_reference_exceptions(tiny_batch):
         only_g.plm_infer(dev(z["plm_cond"][None]))
     with pytest.raises(NativeError, match="missing tensor|shape mismatch"):  # load_state_dict(strict=True)
         bad = dict(synth_models("tiny")[1][2])
-        bad.pop("layers.0.norm1.weight")
+        bad.pop("adm.layers.0.norm1.weight")
         NativeModel(g_cfg=C.tiny_g(), plm_cfg=C.tiny_plm(), adm_cfg=C.tiny_adm(), hg_cfg=C.tiny_hifigan(), sd_adm=bad)
     # the shared handle still works
     out = tts.native.tc_latent(phone, mel).cpu().numpy()

@@ -302,6 +302,33 @@ def test_prod_c2_properties():
     assert O.rel_l2(out[5, :lens[5]], ref["mel"]) < NORTH_STAR
 
 
+def test_prod_plm_batched_vs_alone_decisions():
+    """Free-running PLM at production size, ragged batch: every sequence of the batch must take the same
+    greedy decisions as when it runs alone.  Tile configurations (hence fp32 summation orders) differ between
+    the two runs, so a divergence is tolerated only where the stand-alone run's top-2 logit margin is below
+    1e-4 of the logit range (a genuine near-tie); none is expected with these seeds."""
+    tts = model("prod")
+    rng = np.random.default_rng(21)
+    lens = np.asarray([54, 41, 54, 7, 33, 1], np.int32)
+    cond = np.zeros((len(lens), 54, 512), np.float32)
+    for i, n in enumerate(lens):
+        cond[i, :n] = np.maximum(rng.standard_normal((n, 512)), 0).astype(np.float32)     # tc_latent is post-ReLU
+    codes_b, logits_b = tts.native.plm_infer(dev(cond), lens, return_logits=True)
+    codes_b = codes_b.cpu().numpy()
+    for i in (0, 1, 3, 5):
+        n = int(lens[i])
+        c1, l1 = tts.native.plm_infer(dev(cond[i:i + 1, :n]), return_logits=True)
+        c1, l1 = c1.cpu().numpy()[0], l1.cpu().numpy()[0]
+        diff = np.nonzero(c1 != codes_b[i, :n])[0]
+        if diff.size:
+            t = int(diff[0])
+            top = np.sort(l1[t])[-2:]
+            assert (top[1] - top[0]) < 1e-4 * (l1[t].max() - l1[t].min()), f"seq {i} diverges at step {t} without a near-tie"
+        else:
+            assert O.rel_l2(logits_b[i, :n].cpu().numpy(), l1) < 1e-4
+        assert not codes_b[i, n:].any()
+
+
 # ---------------------------------------------------------------------------------------------------
 # row f3: mel front-end on the GPU (extract_mel_spec, modules/tokenizer.py:107-125)
 

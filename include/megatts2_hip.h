@@ -191,10 +191,11 @@ int mt2_op_attention(void* stream, const float* Q, int ldq, const float* K, int 
  * returns the number of entries written (<= cap). */
 int mt2_gemm_trace_begin(void);
 int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches, double* flops, double* ms);
-/* time `iters` back-to-back launches of one GEMM with HIP events on `stream`, cycling through `w_copies`
- * copies of the weight matrix (> 1: weights are not L2-resident from the previous launch); average ms */
-int mt2_bench_gemm(void* stream, int M, int N, int K, int taps, int force_cfg, int iters, int w_copies,
-                   float* avg_ms, char* cfg_name, int cfg_name_cap);
+/* time `iters` back-to-back launches of one GEMM / conv (taps, dilation) with HIP events on `stream`, cycling
+ * through `w_copies` copies of the weight matrix (> 1: weights are not L2-resident from the previous launch);
+ * flags bit0: leaky-ReLU prologue, bit1: bias + residual + row-mask epilogue; average ms */
+int mt2_bench_gemm(void* stream, int M, int N, int K, int taps, int dil, int flags, int force_cfg, int iters,
+                   int w_copies, float* avg_ms, char* cfg_name, int cfg_name_cap);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v, float slope) {
     if (ACT == ACT_RELU) return fmaxf(v, 0.0f);
-    if (ACT == ACT_LRELU) return v >= 0.0f ? v : v * slope;
+    if (ACT == ACT_LRELU) return fmaxf(v, v * slope);   // 0 < slope < 1: identical to v >= 0 ? v : v*slope, one VALU op less
     if (ACT == ACT_TANH) return tanhf(v);
     return v;
 }
@@ -131,6 +131,68 @@ __device__ __forceinline__ void epilogue_pre(const GemmP& p, const float (&acc)[
             if (q.v[i] == 0) v = 0.0f;
             C[(long long)m * p.ldc + n] = v;
         }
+    }
+}
+
+// The same for TM x TN tiles per wave (no K split): residual, row mask and bias of the whole wave tile are
+// requested before the K loop.  On the vocoder's residual convolutions the un-prefetched epilogue cost 11-25 %
+// of the launch (1 workgroup per CU: nothing else covers the residual read).
+template <int TM, int TN> struct EpiPreT { float r[TM][TN][16]; int v[TM][16]; float b[TN]; };
+template <int TM, int TN>
+__device__ __forceinline__ void epi_prefetch_t(const GemmP& p, EpiPreT<TM, TN>& q, int g, int mw, int nw, int lane) {
+    const float* __restrict__ bias0 = p.bias ? p.bias + (long long)g * p.strideB : g_zero16;
+    const float* __restrict__ R0 = p.R ? p.R + (long long)g * p.strideR : g_zero16;
+    const long long ldr = p.R ? p.ldr : 0;
+    const int* __restrict__ vp = p.valid ? p.valid : g_one_i;
+    const int vs = p.valid ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 32 + (lane & 31);
+        const int nc = (n < p.N && (p.bias || p.R)) ? n : 0;
+        q.b[j] = bias0[p.bias ? nc : 0];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                m = m < p.M ? m : 0;
+                q.r[i][j][e] = R0[m * ldr + (p.R ? nc : 0)];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            m = m < p.M ? m : 0;
+            q.v[i][e] = vp[m * vs];
+        }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_pre_t(const GemmP& p, f32x16 (&acc)[TM][TN], const EpiPreT<TM, TN>& q, int g,
+                                               int mw, int nw, int lane) {
+    float* __restrict__ C = p.C + (long long)g * p.strideC;
+    const int epi_act = p.epi_act;
+    const float epi_par = p.pro_slope;
+    const float out_scale = p.out_scale;
+    const bool hasR = p.R != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 32 + (lane & 31);
+        const bool nok = n < p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (nok && m < p.M) {
+                    float v = acc[i][j][e] + q.b[j];
+                    v = act_rt(epi_act, v, epi_par) * out_scale;
+                    if (hasR) v += q.r[i][j][e];
+                    if (q.v[i][e] == 0) v = 0.0f;
+                    C[(long long)m * p.ldc + n] = v;
+                }
+            }
     }
 }
 
@@ -357,7 +419,10 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     constexpr bool PRE = TM * TN == 1;          // epilogue operands in flight during the K loop
     constexpr int EPGK = 16 / KS;
     EpiPre<PRE ? EPGK : 1> pre;
+    constexpr bool PRET = !PRE && TM * TN <= 2;  // 2 tiles per wave: 49 registers; 4 tiles would spill (64x64 per wave)
+    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
     if constexpr (PRE) epi_prefetch<EPGK>(p, pre, g, m0 + wm * WTM, n0 + wn * WTN, lane, kg * EPGK);
+    else if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 
     float* ring = smem + kg * (NST * STAGE);
     auto issue = [&](int rd, int st) {
@@ -483,6 +548,8 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
 #pragma unroll
         for (int e = 0; e < 16; ++e) out[e] = acc[0][0][e];
         epilogue_pre<16>(p, out, pre, g, m0 + wm * WTM, n0 + wn * WTN, lane, 0);
+    } else if constexpr (PRET) {
+        epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     } else {
         epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     }
@@ -543,6 +610,9 @@ static const TileCfg kCfgs[] = {
     // 64-wide outputs (HiFi-GAN stage 3): a 128-wide tile would idle half of its MFMAs
     MT2_DMA(256, 64, 4, 2, 3),      // 23: 8 waves, 64x32 per wave, 120 KiB
     MT2_DMA(128, 64, 4, 2, 4),      // 24: 8 waves, 32x32 per wave,  96 KiB
+    MT2_DMA(128, 64, 4, 2, 2),      // 25: the same with a 2-deep ring: 48 KiB -> 3 workgroups per CU
+    MT2_DMA(64, 64, 2, 2, 2),       // 26: 4 waves, 2-deep ring: 32 KiB -> 5 workgroups per CU
+    MT2_DMAK(128, 64, 4, 2, 2, 2),  // 27: 16 waves (2 K groups of 4x2), 96 KiB
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 

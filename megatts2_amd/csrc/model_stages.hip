@@ -888,8 +888,10 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
             const float* h = up;
             for (int n = 0; n < 3; ++n) {
                 float* out = n == 2 ? rb[j] : (n == 0 ? ha : hb);
-                conv_same(c, h, ch, (int)R, r.c1[n], t1, ch, valid, ACT_LRELU, slope, ACT_NONE, nullptr, 0, r.dil[n]);
-                conv_same(c, t1, ch, (int)R, r.c2[n], out, ch, valid, ACT_LRELU, slope, ACT_NONE, h, ch, 1);
+                // x + conv2(lrelu(conv1(lrelu(x)))): the inner leaky ReLU has ONE consumer, so it is applied once in
+                // conv1's epilogue instead of on every operand fragment of conv2 (same values, no VALU in that loop)
+                conv_same(c, h, ch, (int)R, r.c1[n], t1, ch, valid, ACT_LRELU, slope, ACT_LRELU, nullptr, 0, r.dil[n]);
+                conv_same(c, t1, ch, (int)R, r.c2[n], out, ch, valid, ACT_NONE, slope, ACT_NONE, h, ch, 1);
                 h = out;
             }
         }

@@ -32,7 +32,7 @@ def rt():
     return runtime
 
 
-@pytest.mark.parametrize("cfg", list(range(25)) + [-1])
+@pytest.mark.parametrize("cfg", list(range(28)) + [-1])
 @pytest.mark.parametrize("M,N,K", [(77, 96, 100), (300, 512, 256), (128, 32, 64), (33, 1024, 512)])
 def test_gemm_linear_all_tile_configs(rt, cfg, M, N, K):
     rng = np.random.default_rng(M * 7 + N + K)

@@ -15,14 +15,22 @@ for M in (32, 64, 128, 256, 512, 768, 1024, 1536, 2240):
 for M in (32, 128, 512, 1024, 1728):
     for N, K in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)):
         shapes.append(("plm", M, N, K, 1))
-cfgs = list(range(25))
+cfgs = list(range(28))
+if mode == "vocx":     # the vocoder's real launches: dilation, leaky-ReLU prologue, bias + residual + mask epilogue
+    for name, M, N, K, taps in [("hifi_s1", 111000, 256, 1792, 7), ("hifi_s2", 888000, 128, 896, 7),
+                                ("hifi_s3", 1776000, 64, 448, 7), ("hifi_s4", 3552000, 32, 224, 7)]:
+        for dil, flags in ((1, 0), (1, 1), (1, 2), (1, 3), (5, 3)):
+            ms, cn = rt.bench_gemm(M, N, K, taps=taps, iters=6, dil=dil, flags=flags)
+            print(f"{name} dil={dil} prologue={flags & 1} epilogue={flags >> 1}: {cn} {ms * 1e3:.1f} us {2.0 * M * N * K / ms / 1e9:.1f} TF/s", flush=True)
+    sys.exit(0)
 if mode == "voc":
     cfgs = [3, 12, 15, 16, 17, 23, 24]
     shapes = [("hifi_s1", 111000, 256, 1792, 7), ("hifi_s2", 888000, 128, 896, 7), ("hifi_s3", 1776000, 64, 448, 7),
               ("hifi_s3k11", 1776000, 64, 704, 11), ("hifi_s4", 3552000, 32, 224, 7), ("hifi_s4k11", 3552000, 32, 352, 11),
               ("hifi_s4k3", 3552000, 32, 96, 3)]
 elif mode == "ar":
-    cfgs = [3, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22]
+    cfgs = [12, 17, 18, 20, 22, 24, 25, 26, 27]
+    shapes = [x for x in shapes if x[1] >= 512]
 else:
     shapes += [("mrte_stack", 14064, 512, 1536, 3), ("decoder", 13858, 512, 2560, 5), ("vqpe", 13858, 384, 1920, 5),
                ("mrte_1/16", 928, 512, 1536, 3), ("hifi_s4", 200000, 32, 352, 11), ("hifi_s1", 111000, 256, 1792, 7)]

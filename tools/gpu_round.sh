@@ -20,6 +20,9 @@ bench)
 bench5)
   timeout 900 python bench.py --workload C5 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_c5.log 2>&1
   echo "bench5 rc=$?"; tail -1 gpurun_out/bench_c5.log | cut -c1-1500 ;;
+sweep_vocx)
+  timeout 600 python tools/gemm_sweep.py vocx > gpurun_out/gemm_sweep_vocx.txt 2>&1
+  echo "sweep_vocx rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_vocx.txt ;;
 sweep_voc)
   timeout 600 python tools/gemm_sweep.py voc > gpurun_out/gemm_sweep_voc.txt 2>&1
   echo "sweep_voc rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_voc.txt ;;

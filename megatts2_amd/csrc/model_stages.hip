@@ -124,6 +124,7 @@ static float* run_stack(const Ctx& c, const StackW& w, const float* x_in, bool s
     for (int st = 0; st < w.nstack; ++st) {
         const float* bin = cur;
         bool bin_shared = cur_shared;
+        bool bin_relued = false;    // a block output with ONE consumer (the next block's conv) is stored ReLU'd
         for (int blk = 0; blk < w.nblock; ++blk) {
             const size_t e = w.idx(st, blk);
             GemmP p{};
@@ -132,16 +133,17 @@ static float* run_stack(const Ctx& c, const StackW& w, const float* x_in, bool s
             p.W = w.w + e * wsz; p.strideW = (long long)wsz;
             p.bias = w.b + e * C; p.strideB = C;
             p.valid = valid; p.C = T; p.strideC = (long long)per; p.ldc = C; p.M = R; p.N = C; p.groups = G;
-            p.pro_act = ACT_RELU;
+            p.pro_act = bin_relued ? ACT_NONE : ACT_RELU;
             gemm(c, p);
             const bool last = blk == w.nblock - 1;
             if (last)
                 layernorm(c, T, C, w.g + e * C, w.be + e * C, R * G, C, nxt, C, valid, R, cur, C,
                           cur_shared ? R : 0, R);
-            else
-                layernorm(c, T, C, w.g + e * C, w.be + e * C, R * G, C, Y, C, valid, R, nullptr, 0, 0, R);
+            else   // next ConvBlock starts with ReLU (convnet.py:24): fold it into this LayerNorm's store
+                layernorm(c, T, C, w.g + e * C, w.be + e * C, R * G, C, Y, C, valid, R, nullptr, 0, 0, R, ACT_RELU);
             bin = Y;
             bin_shared = false;
+            bin_relued = !last;
         }
         cur = nxt;
         cur_shared = false;

@@ -80,6 +80,43 @@ def test_tiny_each_utterance_alone_equals_batched(tiny_batch):
         assert O.rel_l2(alone, batched[i, :pl[i]]) < 2e-6
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_tiny_random_ragged_batches_against_oracle(seed):
+    """Seeded random ragged batches (1-phone utterances, minimum-length prompts, equal lengths, up to 9
+    utterances): the whole pipeline with forced durations and the vocoder, every utterance against the
+    oracle run alone - mel within tolerance, ADM durations and PLM codes bit-exact, padding zero."""
+    from megatts2_amd import synth
+    tts = model("tiny")
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("tiny")
+    rng = np.random.Generator(np.random.PCG64(100 + seed))
+    B = int(rng.integers(2, 10))
+    utts = []
+    for i in range(B):
+        n_ph = 1 if i == 0 else int(rng.integers(1, 14))
+        n_pr = 17 if i == 1 else int(rng.integers(17, 80))          # >= 17 frames: one stride-16 window + 1
+        n_fr = n_ph * int(rng.integers(1, 6)) + int(rng.integers(0, n_ph))
+        utts.append(synth.make_utterance(rng, n_ph, n_pr, max(n_fr, n_ph), g.mrte.phone_vocab_size))
+    if B > 3:
+        utts[3] = synth.make_utterance(rng, utts[2].phone.size, utts[2].prompt_mel.shape[0], int(utts[2].durations.sum()),
+                                       g.mrte.phone_vocab_size)    # two utterances of identical geometry
+    phone, pl = pad_stack([u.phone for u in utts])
+    mel, ml = pad_stack([u.prompt_mel for u in utts])
+    dur, _ = pad_stack([u.durations for u in utts])
+    out, lens, aux = tts.native.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, vocoder=True,
+                                                 return_aux=True)
+    out = out.cpu().numpy()
+    for i, u in enumerate(utts):
+        ref = O.synthesize(sd_g, sd_p, sd_a, g, p, a, u.phone, u.prompt_mel, forced_durations=u.durations)
+        n = ref["mel"].shape[0]
+        assert lens[i] == n
+        assert np.array_equal(aux["dur"][i, :pl[i]].cpu().numpy(), ref["adm_dur"])
+        assert np.array_equal(aux["codes"][i, :ref["p_codes"].size].cpu().numpy(), ref["p_codes"])
+        assert O.rel_l2(out[i, :n], ref["mel"]) < NORTH_STAR
+        assert not out[i, n:].any()
+        wav = O.hifigan(sd_h, h, ref["mel"])
+        assert O.rel_l2(aux["wav"][i, :wav.size].cpu().numpy(), wav) < NORTH_STAR
+
+
 def test_tiny_adm(tiny_batch):
     tts = model("tiny")
     tc, ln = pad_stack([z["tc_latent"] for z in tiny_batch])

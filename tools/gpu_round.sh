@@ -26,9 +26,20 @@ sweep_vocx)
 sweep_voc)
   timeout 600 python tools/gemm_sweep.py voc > gpurun_out/gemm_sweep_voc.txt 2>&1
   echo "sweep_voc rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_voc.txt ;;
+s2)
+  timeout 300 python tools/bench_s2.py > gpurun_out/bench_s2.log 2>&1
+  echo "s2 rc=$?"; tail -1 gpurun_out/bench_s2.log | cut -c1-700 ;;
 frontend)
   timeout 300 python tools/bench_frontend.py > gpurun_out/bench_frontend.log 2>&1
   echo "frontend rc=$?"; tail -1 gpurun_out/bench_frontend.log | cut -c1-700 ;;
+profstage)
+  for st in ${STAGES:-mrte}; do
+    rm -rf gpurun_out/ps_$st
+    (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/ps_$st -o st -- python $GRAFT_REPO_ROOT/tools/prof_stage.py $st 3) > gpurun_out/ps_$st.log 2>&1
+    echo "profstage $st rc=$?"; grep "ms per call" gpurun_out/ps_$st.log
+    f=$(find gpurun_out/ps_$st -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/ps_${st}_stats.csv && head -16 "$f" | cut -c1-170
+    find gpurun_out/ps_$st -name "*kernel_trace.csv" -size +8M -delete
+  done ;;
 bench1)
   timeout 600 python bench.py --workload C1 --steps 5 --warmup 2 > gpurun_out/bench_c1.log 2>&1
   echo "bench1 rc=$?"; tail -1 gpurun_out/bench_c1.log | cut -c1-1200 ;;

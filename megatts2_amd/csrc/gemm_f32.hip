@@ -5,15 +5,19 @@
 // reference computes in fp32 and its discrete decisions (VQ argmin, PLM argmax, ADM rounding) must
 // be reproduced bit-for-bit, so reduced-precision MFMA is not used.  Roofline: 157.3 TFLOP/s.
 //
-// Tiling (wave64): a workgroup of WGM x WGN waves owns a BM x BN output tile; each wave owns
+// Tiling (wave64): a workgroup of WGM x WGN (x KS) waves owns a BM x BN output tile; each wave owns
 // (BM/WGM) x (BN/WGN) as TM x TN MFMA tiles of 32x32 (16 accumulator VGPRs each).  K is walked in
 // chunks of 32: both operands are K-contiguous in HBM (activations [rows, C] time-major, weights
-// [N, taps*Cin]), loaded as coalesced float4 (one 128-B line per 8 lanes), staged in LDS with a row
-// stride of 36 floats so that the MFMA operand fetch - one ds_read_b128 per lane giving 4 k-values
-// of one row - is bank-conflict free (36*r mod 64 is distinct for 16 consecutive rows).  The MFMA
-// k index is a free permutation (lanes 0-31 take k = 8j+e, lanes 32-63 take k = 8j+4+e), so one
-// b128 read feeds four MFMAs.  Global loads of chunk c+1 are issued before the MFMAs of chunk c
-// and written to the other LDS buffer afterwards: one barrier per chunk.
+// [N, taps*Cin]).  The MFMA k index is a free permutation (lanes 0-31 take k = 8j+e, lanes 32-63 take
+// k = 8j+4+e), so one ds_read_b128 per lane feeds four MFMAs.
+//
+// Two kernels share the epilogue and the tile map:
+//   gemm_f32_kernel      (v1, tile configurations 0-7) stages operands through registers into a padded,
+//                        double-buffered LDS tile.  Kept as the simple reference implementation for A/B
+//                        runs and kernel tests; never chosen by choose_cfg.
+//   gemm_f32_dma_kernel  (v2, configurations 8+, what the model runs) moves operands global -> LDS with
+//                        LDS-DMA into a swizzled ring, optionally splits K over wave groups of the
+//                        workgroup, and prefetches the epilogue operands (description at the kernel).
 //
 // Conv1d is the same GEMM with a virtual A: A[m, tap*Cin + c] = X[src(m) + tap*dil, c]; gap rows
 // between utterances supply the zero padding (mt2_kernels.h).  Epilogue: bias, activation, scale,

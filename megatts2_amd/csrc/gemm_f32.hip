@@ -368,7 +368,7 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW);   // 1-KiB DMA pieces per wave per chunk
     constexpr int L = A_IT + B_IT;
     constexpr int STAGE = (BM + BN) * BK;                       // floats per ring stage (of one K group)
-    static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "piece/wave mismatch");
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "piece/wave mismatch");
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64, "config");
     static_assert(KS == 1 || (TM == 1 && TN == 1 && 16 % KS == 0), "K split: one 32x32 tile per wave");
     static_assert(KS * NW <= 16, "at most 16 waves per workgroup");
@@ -398,7 +398,8 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
 
     // DMA coordinates of this lane: piece row lane>>3, physical 16-B slot lane&7, logical slot = phys ^ swz(row)
     const int lrow = lane >> 3;
-    const int kslot = ((lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7)) * 4;   // k offset inside the chunk
+    // k offset of this lane inside a chunk for piece j: row = (j*NW + wave)*8 + lrow, swz = (row >> 1) & 7
+    auto kslot_of = [&](int j) { return ((lane & 7) ^ (((j * NW + wave) * 4 + (lane >> 4)) & 7)) * 4; };
     int abase[A_IT];
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
@@ -430,24 +431,25 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
 
     float* ring = smem + kg * (NST * STAGE);
     auto issue = [&](int rd, int st) {
-        const int k = (rd * KS + kg) * BK + kslot;
-        const bool kok = k < Kt;
-        int tap = 0, c = k;
-        if (multi_tap) { tap = k / Cin; c = k - tap * Cin; }
-        const int shift = tap * dil;
+        const int kchunk = (rd * KS + kg) * BK;
         float* As = ring + st * STAGE + wave * 256;            // + j*NW*256 floats per piece
         float* Bs = As + BM * BK;
+        // with an even number of waves per K group the slot does not depend on the piece (j*NW*4 = 0 mod 8)
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
-            const int src = abase[j] + shift;
-            const bool ok = kok & ((unsigned)src < (unsigned)Rx);
+            const int k = kchunk + kslot_of(NW % 2 == 0 ? 0 : j);
+            int tap = 0, c = k;
+            if (multi_tap) { tap = k / Cin; c = k - tap * Cin; }
+            const int src = abase[j] + tap * dil;
+            const bool ok = (k < Kt) & ((unsigned)src < (unsigned)Rx);
             const long long off = ok ? (long long)src * ldx + c : zoff_x;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
                                              (__attribute__((address_space(3))) void*)(As + j * NW * 256), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
-            const bool ok = kok & (wofs[j] >= 0);
+            const int k = kchunk + kslot_of(NW % 2 == 0 ? 0 : j);
+            const bool ok = (k < Kt) & (wofs[j] >= 0);
             const long long off = ok ? wofs[j] + k : zoff_w;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + off),
                                              (__attribute__((address_space(3))) void*)(Bs + j * NW * 256), 16, 0, 0);
@@ -617,6 +619,8 @@ static const TileCfg kCfgs[] = {
     MT2_DMA(128, 64, 4, 2, 2),      // 25: the same with a 2-deep ring: 48 KiB -> 3 workgroups per CU
     MT2_DMA(64, 64, 2, 2, 2),       // 26: 4 waves, 2-deep ring: 32 KiB -> 5 workgroups per CU
     MT2_DMAK(128, 64, 4, 2, 2, 2),  // 27: 16 waves (2 K groups of 4x2), 96 KiB
+    MT2_DMAK(32, 32, 1, 1, 8, 2),   // 28: 8 waves = 8 K groups of one wave, 128 KiB: the shortest K chain (M*N <= 256 tiles)
+    MT2_DMAK(32, 32, 1, 1, 4, 3),   // 29: 4 waves, 96 KiB
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -693,8 +697,9 @@ extern "C" int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches
 //     CU at best, and a 4-wave tile then runs at the pace of ONE wave per SIMD: serial chain K/2 x 64 cycles
 //     plus an exposed barrier + DMA-issue + ds_read bubble per chunk (measured ~1 us per 32-wide chunk vs
 //     0.43 us of MFMA).  The K-split tiles put 2-4 waves on each SIMD of the same CU instead.
-static int g_t_ks4 = 256, g_t_ks2 = 640, g_t32 = 256;   // thresholds in tiles, from tools/gemm_sweep.py
+static int g_t_ks4 = 256, g_t_ks2 = 640, g_t32 = 256, g_t32x32 = 256;   // thresholds in tiles, from tools/gemm_sweep.py
 extern "C" void mt2_debug_set_thresholds(int t_ks4, int t_ks2, int t32) { g_t_ks4 = t_ks4; g_t_ks2 = t_ks2; g_t32 = t32; }
+extern "C" void mt2_debug_set_t32x32(int t) { g_t32x32 = t; }
 
 // A CU retires one 64x64 tile of K=768 in ~12 us whatever the launch looks like, so for the AR-step shapes the
 // choice is about how many CUs get a tile and how many tiles the busiest CU gets (profiles/r01_gemm_sweep_ar_*):
@@ -704,6 +709,7 @@ extern "C" void mt2_debug_set_thresholds(int t_ks4, int t_ks2, int t32) { g_t_ks
 static const TileCfg* choose_cfg(const GemmP& p, int* idx_out) {
     int bi = 12;                                                        // dma64x64_2x2_s3
     const long long t32 = (long long)((p.M + 31) / 32) * ((p.N + 63) / 64) * p.groups;
+    const long long t32x32 = (long long)((p.M + 31) / 32) * ((p.N + 31) / 32) * p.groups;
     const long long t64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.groups;
     const long long t128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.groups;
     const long long t256 = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.groups;
@@ -712,6 +718,7 @@ static const TileCfg* choose_cfg(const GemmP& p, int* idx_out) {
     else if (p.N <= 256 && t128 >= 400) bi = 17;                        // two n-tiles: 128x128 beats 256x128 (vocoder)
     else if (t256 >= 400 || (t256 >= 200 && t256 <= 256)) bi = 16;      // dma256x128_4x2_s3
     else if (t128 >= 400 || (t128 >= 200 && t128 <= 256)) bi = 17;      // dma128x128_4x2_s4
+    else if (t32x32 <= g_t32x32 && p.K >= 512) bi = 28;                 // dma32x32_1x1_k8_s2
     else if (t32 <= g_t32) bi = 22;                                     // dma32x64_1x2_k4_s2
     else if (t64 <= g_t_ks4) bi = 20;                                   // dma64x64_2x2_k4_s2
     else if (t64 <= g_t_ks2) bi = 18;                                   // dma64x64_2x2_k2_s2

@@ -32,7 +32,7 @@ def rt():
     return runtime
 
 
-@pytest.mark.parametrize("cfg", list(range(28)) + [-1])
+@pytest.mark.parametrize("cfg", list(range(30)) + [-1])
 @pytest.mark.parametrize("M,N,K", [(77, 96, 100), (300, 512, 256), (128, 32, 64), (33, 1024, 512)])
 def test_gemm_linear_all_tile_configs(rt, cfg, M, N, K):
     rng = np.random.default_rng(M * 7 + N + K)
@@ -56,7 +56,7 @@ def test_gemm_is_transpose_detecting(rt):
     assert not out[K:].any()
 
 
-@pytest.mark.parametrize("cfg", [-1, 3, 8, 11, 13, 15, 18, 20, 21, 23])
+@pytest.mark.parametrize("cfg", [-1, 3, 8, 11, 13, 15, 18, 20, 21, 23, 28])
 @pytest.mark.parametrize("k,dil,cin,cout", [(3, 1, 80, 64), (5, 1, 64, 96), (17, 1, 32, 32), (11, 5, 32, 32),
                                             (7, 3, 64, 64), (5, 1, 20, 96)])
 def test_gemm_conv1d_with_gaps(rt, k, dil, cin, cout, cfg):
@@ -88,7 +88,7 @@ def test_gemm_conv1d_with_gaps(rt, k, dil, cin, cout, cfg):
     assert not out[valid == 0].any()                                             # gap rows stay zero
 
 
-@pytest.mark.parametrize("cfg", [-1, 3, 9, 12, 14, 19, 22, 24])
+@pytest.mark.parametrize("cfg", [-1, 3, 9, 12, 14, 19, 22, 24, 29])
 def test_gemm_strided_conv_rowbase(rt, cfg):
     """MRTE middle layer: Conv1d(k=17, stride 16, pad 8) through per-row base indices."""
     rng = np.random.default_rng(5)

@@ -15,7 +15,7 @@ for M in (32, 64, 128, 256, 512, 768, 1024, 1536, 2240):
 for M in (32, 128, 512, 1024, 1728):
     for N, K in ((3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)):
         shapes.append(("plm", M, N, K, 1))
-cfgs = list(range(28))
+cfgs = list(range(30))
 if mode == "vocx":     # the vocoder's real launches: dilation, leaky-ReLU prologue, bias + residual + mask epilogue
     for name, M, N, K, taps in [("hifi_s1", 111000, 256, 1792, 7), ("hifi_s2", 888000, 128, 896, 7),
                                 ("hifi_s3", 1776000, 64, 448, 7), ("hifi_s4", 3552000, 32, 224, 7)]:
@@ -29,8 +29,8 @@ if mode == "voc":
               ("hifi_s3k11", 1776000, 64, 704, 11), ("hifi_s4", 3552000, 32, 224, 7), ("hifi_s4k11", 3552000, 32, 352, 11),
               ("hifi_s4k3", 3552000, 32, 96, 3)]
 elif mode == "ar":
-    cfgs = [12, 17, 18, 20, 22, 24, 25, 26, 27]
-    shapes = [x for x in shapes if x[1] >= 512]
+    cfgs = [18, 20, 21, 22, 28, 29]
+    shapes = [x for x in shapes if x[1] <= 512]
 else:
     shapes += [("mrte_stack", 14064, 512, 1536, 3), ("decoder", 13858, 512, 2560, 5), ("vqpe", 13858, 384, 1920, 5),
                ("mrte_1/16", 928, 512, 1536, 3), ("hifi_s4", 200000, 32, 352, 11), ("hifi_s1", 111000, 256, 1792, 7)]

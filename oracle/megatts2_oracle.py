@@ -511,3 +511,61 @@ def mel_spectrogram(wav: np.ndarray, sample_rate: int = 16000, n_fft: int = 1024
     mag = stft_magnitude(wav, n_fft, hop, win)
     fb = melscale_fbanks(n_fft // 2 + 1, f_min, f_max, n_mels, sample_rate)
     return np.log(np.maximum(mag @ fb, clip)).astype(F32)
+
+
+# ------------------------------------------------------------------------------------------------
+# optional ATen backend for the dense primitives (timing leg of bench.py's cpu_baseline)
+
+_NUMPY_PRIMS = {}
+
+
+def enable_torch_kernels(threads: Optional[int] = None) -> None:
+    """Route linear / conv1d / layer_norm / attention through ATen on the CPU - the very kernels the
+    reference's path dispatches to (layer L1: F.linear, F.conv1d, F.layer_norm,
+    F.scaled_dot_product_attention; oneDNN / MKL, multi-threaded).  The structure of the port (every
+    function above) is unchanged; only these four primitives are swapped.  The numpy primitives stay
+    the default (parity tests); `disable_torch_kernels()` restores them."""
+    import torch
+    import torch.nn.functional as Fn
+
+    if threads:
+        torch.set_num_threads(int(threads))
+    g = globals()
+    if not _NUMPY_PRIMS:
+        _NUMPY_PRIMS.update({k: g[k] for k in ("linear", "conv1d", "layer_norm", "mha")})
+
+    def t(a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=F32))
+
+    def linear_t(x, w, b=None):
+        with torch.no_grad():
+            return Fn.linear(t(x), t(w), None if b is None else t(b)).numpy()
+
+    def conv1d_t(x, w, b, stride=1, padding=0, dilation=1):
+        with torch.no_grad():
+            y = Fn.conv1d(t(x).T.unsqueeze(0), t(w), None if b is None else t(b), stride=stride, padding=padding,
+                          dilation=dilation)
+            return np.ascontiguousarray(y[0].T.numpy())
+
+    def layer_norm_t(x, gam, bet, eps=1e-5):
+        with torch.no_grad():
+            return Fn.layer_norm(t(x), (x.shape[-1],), t(gam), t(bet), eps).numpy()
+
+    def mha_t(sd, p, q_in, kv_in, n_heads):
+        src = q_in if kv_in is None else kv_in
+        with torch.no_grad():
+            q = Fn.linear(t(q_in), t(sd[f"{p}.w_q.weight"]), t(sd[f"{p}.w_q.bias"]))
+            k = Fn.linear(t(src), t(sd[f"{p}.w_k.weight"]), t(sd[f"{p}.w_k.bias"]))
+            v = Fn.linear(t(src), t(sd[f"{p}.w_v.weight"]), t(sd[f"{p}.w_v.bias"]))
+            hd = q.shape[1] // n_heads
+            sp = lambda z: z.view(1, z.shape[0], n_heads, hd).transpose(1, 2)      # noqa: E731  "b t (h d) -> b h t d"
+            o = Fn.scaled_dot_product_attention(sp(q), sp(k), sp(v))               # transformer.py:52-53, mask None
+            o = o.transpose(1, 2).reshape(q.shape[0], n_heads * hd)
+            return Fn.linear(o, t(sd[f"{p}.out_proj.0.weight"]), t(sd[f"{p}.out_proj.0.bias"])).numpy()
+
+    g.update(linear=linear_t, conv1d=conv1d_t, layer_norm=layer_norm_t, mha=mha_t)
+
+
+def disable_torch_kernels() -> None:
+    if _NUMPY_PRIMS:
+        globals().update(_NUMPY_PRIMS)

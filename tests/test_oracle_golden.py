@@ -111,3 +111,18 @@ def test_mel_frontend_restatement_against_torch_stft():
     assert np.allclose(area[5:], 1.0, atol=0.08)
     mel = O.mel_spectrogram(wav)
     assert mel.shape == (20, 80) and mel.dtype == np.float32 and mel.min() >= np.log(1e-5) - 1e-6
+
+
+def test_aten_backend_of_the_port_equals_numpy_backend(tiny):
+    """bench.py times the port with ATen kernels (what the reference dispatches to); same results."""
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = tiny
+    z = load_golden("tiny_utt0.npz")
+    ref = O.synthesize(sd_g, sd_p, sd_a, g, p, a, z["phone"], z["prompt_mel"], forced_durations=z["forced_dur"])
+    O.enable_torch_kernels(2)
+    try:
+        got = O.synthesize(sd_g, sd_p, sd_a, g, p, a, z["phone"], z["prompt_mel"], forced_durations=z["forced_dur"])
+    finally:
+        O.disable_torch_kernels()
+    assert np.array_equal(got["adm_dur"], ref["adm_dur"]) and np.array_equal(got["p_codes"], ref["p_codes"])
+    assert O.rel_l2(got["mel"], ref["mel"]) < 1e-5
+    assert O.linear.__module__ == O.__name__            # numpy primitives restored

@@ -263,29 +263,24 @@ def main() -> None:
         }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
-        # the oracle (a port of the reference path, dense primitives on ATen = the kernels the reference itself
-        # dispatches to, all host cores) on ONE utterance of the same workload
-        threads = os.cpu_count() or 1
-        O.enable_torch_kernels(threads)
-        if sd_p is None and full:
-            sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.")
-        n_utt, frames, t0 = 0, 0, time.perf_counter()
-        for u in utts[:8]:                       # batch-1 runs like the reference; bounded to ~10-20 s
-            ref = O.synthesize(sd_g, sd_p, sd_a, g, p, a, u.phone, u.prompt_mel, forced_durations=u.durations,
-                               forced_codes=None if full else u.p_codes, run_plm=full)
-            if full:
-                O.hifigan(sd_h, h, ref["mel"])
-            n_utt += 1
-            frames += ref["mel"].shape[0]
-            if time.perf_counter() - t0 > 20.0:
-                break
-        cpu_s = time.perf_counter() - t0
-        O.disable_torch_kernels()
-        result["cpu_baseline"] = {"value": round(frames / cpu_s, 2), "unit": "mel-frames/s",
-                                  "cores": int(threads), "kind": "port",
-                                  "sample": f"{n_utt} of the {B} utterances of {args.workload} (Np={Np}, Tp={Tp}, "
-                                            f"Tm={shape.Tm}) one after the other, oracle port on ATen CPU kernels, "
-                                            f"{cpu_s:.1f} s"}
+        # the oracle (a port of the reference path; dense primitives on ATen = the kernels the reference itself
+        # dispatches to) on the utterances of the same workload for up to ~25 s, in its own process with a hard limit
+        import subprocess
+        threads = min(os.cpu_count() or 1, 16)
+        cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", args.workload,
+               "--threads", str(threads), "--budget", "25", "--max-utts", "32"]
+        base = None
+        for backend, limit in (("aten", 120), ("numpy", 240)):
+            try:
+                out = subprocess.run(cmd + ["--backend", backend], capture_output=True, text=True, timeout=limit)
+                lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+                if out.returncode == 0 and lines:
+                    base = json.loads(lines[-1])
+                    break
+            except subprocess.TimeoutExpired:
+                continue
+        result["cpu_baseline"] = base or {"value": None, "unit": "mel-frames/s", "cores": threads, "kind": "port",
+                                          "sample": "oracle port did not finish within its time limit"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

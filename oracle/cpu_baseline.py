@@ -1,0 +1,71 @@
+"""CPU baseline leg of bench.py (TEST / MEASUREMENT INFRASTRUCTURE, never on the product path).
+
+Times the oracle - the port of the reference's synthesis path - on the host cores, one utterance after the
+other (the reference is batch-1, models/megatts2.py:170-171,262-263), with the dense primitives on ATen
+(F.linear / F.conv1d / F.layer_norm / SDPA: the kernels the reference dispatches to).  Runs as its own
+process so that bench.py can bound it with a timeout; prints ONE JSON line.
+
+    python oracle/cpu_baseline.py --workload C2 --threads 16 --budget 20
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--budget", type=float, default=20.0, help="stop starting new utterances after this many seconds")
+    ap.add_argument("--max-utts", type=int, default=8)
+    ap.add_argument("--backend", default="aten", choices=["aten", "numpy"])
+    a = ap.parse_args()
+    # one pool only: ATen's.  numpy's BLAS pool would busy-wait beside it (measured: 256 + 128 spinning threads
+    # turned a 2 s run into 871 s on the 128-core GPU box)
+    for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+        os.environ[v] = str(a.threads if a.backend == "numpy" and v == "OPENBLAS_NUM_THREADS" else
+                            (a.threads if a.backend == "aten" and v != "OPENBLAS_NUM_THREADS" else 1))
+    import numpy as np
+    import megatts2_oracle as O
+    from megatts2_amd import config as C, synth, weights
+
+    g, p, d, h = C.production_g(), C.production_plm(), C.production_adm(), C.production_hifigan()
+    full = a.workload in ("C3", "C5")
+    sd_g = weights.synth_state_dict(weights.inventory_g(g), 0, "G.")
+    emb = np.load(os.path.join(ROOT, "tests", "golden", "codebook_prod.npy"))
+    sd_g[O.CODEBOOK] = emb
+    sd_a = weights.synth_state_dict(weights.inventory_adm(d), 0, "adm.")
+    sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.") if full else None
+    sd_h = weights.synth_state_dict(weights.inventory_hifigan(h), 0, "hifigan.") if full else None
+    shape = synth.SHAPES[a.workload]
+    utts = synth.make_batch(shape, seed=1000 + int(a.workload[1]), batch=min(shape.B, a.max_utts))
+    if a.backend == "aten":
+        O.enable_torch_kernels(a.threads)
+    n_utt, frames, t0 = 0, 0, time.perf_counter()
+    for u in utts:
+        ref = O.synthesize(sd_g, sd_p, sd_a, g, p, d, u.phone, u.prompt_mel, forced_durations=u.durations,
+                           forced_codes=None if full else u.p_codes, run_plm=full)
+        if full:
+            O.hifigan(sd_h, h, ref["mel"])
+        n_utt += 1
+        frames += ref["mel"].shape[0]
+        if time.perf_counter() - t0 > a.budget:
+            break
+    cpu_s = time.perf_counter() - t0
+    print(json.dumps({"value": round(frames / cpu_s, 2), "unit": "mel-frames/s", "cores": a.threads, "kind": "port",
+                      "sample": f"{n_utt} of the {shape.B} utterances of {a.workload} (Np={shape.Np}, Tp={shape.Tp}, "
+                                f"Tm={shape.Tm}) one after the other, oracle port, dense primitives on "
+                                f"{'ATen' if a.backend == 'aten' else 'numpy/OpenBLAS'}, {a.threads} threads, {cpu_s:.1f} s"}))
+
+
+if __name__ == "__main__":
+    main()

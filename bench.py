@@ -241,18 +241,18 @@ def main() -> None:
         n_launch = sum(r["launches"] for r in tr)
         exe = sum(r["flops"] for r in tr)
         achieved = alg_gemm / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_detail = None, None      # bytes per launch, from the committed rocprofv3 --pmc passes
         pmc_path = os.path.join(ROOT, "profiles", f"r01_pmc_{args.workload.lower()}_latest.json")
         if os.path.exists(pmc_path):
             pm = json.load(open(pmc_path))["gemm_engine"]
-            traffic = {"bytes_per_launch": round((pm["read_gb_per_step_corrected"] + pm["write_gb_per_step"]) * 1e9
-                                                 / pm["launches_per_step"]),
-                       "read_gb_per_step": pm["read_gb_per_step_corrected"], "write_gb_per_step": pm["write_gb_per_step"],
-                       "source": os.path.relpath(pmc_path, ROOT)}
+            traffic = round((pm["read_gb_per_step_corrected"] + pm["write_gb_per_step"]) * 1e9 / pm["launches_per_step"])
+            traffic_detail = {"unit": "bytes per launch (fabric reads, FETCH_SIZE x 2, + writes)",
+                              "read_gb_per_step": pm["read_gb_per_step_corrected"],
+                              "write_gb_per_step": pm["write_gb_per_step"], "source": os.path.relpath(pmc_path, ROOT)}
         result["roofline"] = {
             "bound": "mfma", "kernel": "gemm_f32_dma_kernel<*> (implicit-GEMM conv/linear engine, f32 MFMA)",
             "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
             "launches_per_step": n_launch, "avg_launch_us": round(sum_ms * 1e3 / max(n_launch, 1), 2),
             "algorithmic_gflop_per_step": round(alg_gemm / 1e9, 1), "executed_gflop_per_step": round(exe / 1e9, 1),
             "attention_gflop_per_step": round(alg_attn / 1e9, 1), "gemm_ms_per_step": round(t_ms, 3),

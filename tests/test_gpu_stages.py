@@ -208,6 +208,29 @@ def test_tiny_vqpe(tiny_batch):
     assert len(r) == 4 and r[3].shape[0] == 1
 
 
+def test_tiny_mirror_surfaces_of_the_reference_classes(tiny_batch):
+    """The drop-in classes expose the reference's sub-surfaces with its layouts: MRTE.mel_encoder ("B D T"),
+    MRTE.tc_latent with 2 or 3 positional arguments, RVQ encode/decode ([n_q, B, T] <-> "B D T")."""
+    tts = model("tiny")
+    (g, p, a, h), (sd_g, *_) = synth_models("tiny")
+    z = tiny_batch[2]
+    mel_bdt = dev(z["prompt_mel"].T[None].copy())
+    ctx = tts.generator.mrte.mel_encoder(mel_bdt).cpu().numpy()[0].T
+    assert O.rel_l2(ctx, z["mel_context"]) < TIGHT
+    phone, pm = dev(z["phone"][None]), dev(z["prompt_mel"][None])
+    t2 = tts.generator.mrte.tc_latent(phone, pm)
+    t3 = tts.generator.mrte.tc_latent(phone, np.asarray([z["phone"].size], np.int32), pm)
+    assert torch.equal(t2, t3) and O.rel_l2(t2[0].cpu().numpy(), z["tc_latent"]) < TIGHT
+    ze = dev(z["vqpe_ze"].T[None].copy())                                  # "b d n"
+    codes = tts.generator.vqpe.vq.encode(ze)
+    assert tuple(codes.shape) == (1, 1, z["vqpe_codes"].size) and codes.dtype == torch.int64
+    assert np.array_equal(codes[0, 0].cpu().numpy(), z["vqpe_codes"])
+    zq = tts.generator.vqpe.vq.decode(codes).cpu().numpy()[0].T            # [B, D, T] -> [T, D]
+    assert np.array_equal(zq, sd_g[O.CODEBOOK][z["vqpe_codes"]])
+    w, ws = tts.native.memory()
+    assert w > 0 and ws > 0
+
+
 def test_tiny_vq_quantize_near_ties():
     """L2-argmin with adversarial near-ties and exact ties (lowest index wins)."""
     tts = model("tiny")

@@ -443,6 +443,21 @@ static MelPlan plan_mel(IntPlan& ip, const mt2_config& cfg, const int* mel_lens,
     return mp;
 }
 
+// internal side streams (created once per handle) + fork / join events
+static void ensure_aux(mt2_model& m, int n_streams) {
+    while ((int)m.aux_streams.size() < n_streams) {
+        hipStream_t s;
+        MT2_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        m.aux_streams.push_back(s);
+    }
+    if (!m.ev_fork) MT2_HIP(hipEventCreateWithFlags(&m.ev_fork, hipEventDisableTiming));
+    while ((int)m.ev_join.size() < n_streams) {
+        hipEvent_t e;
+        MT2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m.ev_join.push_back(e);
+    }
+}
+
 // MRTE.tc_latent (modules/mrte.py:154-171) -> packed rows [P.R, hidden] (gap rows zero)
 struct TcResult { float* rows; RowSet P; };
 static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* phone_lens, int Np_max,
@@ -467,6 +482,15 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
     bind_rows(ip, mp.oX, mp.X);
     bind_rows(ip, oP, P);
 
+    // The phone branch (embedding, conv-FF transformer, query projection: ~60 small launches) does not depend on
+    // the mel encoder: it runs on a side stream and fills the CUs the mel stack's big launches leave idle
+    // (220 tiles on 256 CUs); the two meet at the cross attention.
+    ensure_aux(m, 1);
+    hipStream_t side = m.aux_streams[0];
+    MT2_HIP(hipEventRecord(m.ev_fork, c.s));
+    MT2_HIP(hipStreamWaitEvent(side, m.ev_fork, 0));
+    const Ctx cp{m, side, c.ws};
+
     // prompt mel -> rows, mel encoder
     float* xmel = c.ws.get<float>((size_t)mp.F.R * cfg.mel_bins);
     MT2_HIP(launch_pack_rows(mel, cfg.mel_bins, Tp_max, 0, ip.dev(mp.o_rowmapF), xmel, cfg.mel_bins, mp.F.R, c.s));
@@ -474,15 +498,17 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
 
     // phone embedding + PE, conv-FF transformer (mrte.py:159-160,165)
     float* x = c.ws.get<float>((size_t)P.R * H);
-    MT2_HIP(launch_embed_pe(m.phone_emb, H, phone, ip.dev(o_idmap), ip.dev(o_pos), m.pe_mrte, x, H, P.R, c.s));
+    MT2_HIP(launch_embed_pe(m.phone_emb, H, phone, ip.dev(o_idmap), ip.dev(o_pos), m.pe_mrte, x, H, P.R, side));
     EncScratch sc = enc_scratch(c, m.phone_enc, P.R);
     AttnGeom g;
     g.start = P.d_start; g.len = P.d_len; g.B = B; g.max_len = P.maxlen;
-    for (auto& lw : m.phone_enc.layers) encoder_layer(c, m.phone_enc, lw, x, P.R, g, P.d_valid, sc);
+    for (auto& lw : m.phone_enc.layers) encoder_layer(cp, m.phone_enc, lw, x, P.R, g, P.d_valid, sc);
 
     // cross attention, ONE head of width H (mrte.py:131-135,167), LayerNorm, ReLU (:168-169)
     float* q = sc.h;
-    linear(c, x, H, P.R, m.x_wq, m.x_bq, H, H, q, H);
+    linear(cp, x, H, P.R, m.x_wq, m.x_bq, H, H, q, H);
+    MT2_HIP(hipEventRecord(m.ev_join[0], side));
+    MT2_HIP(hipStreamWaitEvent(c.s, m.ev_join[0], 0));
     float* kv = c.ws.get<float>((size_t)mp.X.R * 2 * H);
     linear(c, ctx, H, mp.X.R, m.x_wkv, m.x_bkv, 2 * H, H, kv, 2 * H);
     AttnP a{};
@@ -534,17 +560,7 @@ static ArGroups ar_groups(mt2_model& m, hipStream_t main, const ArOrder& ord, in
     g.G = std::max(1, std::min(m.ar_groups, B));
     g.slots.resize(g.G);
     for (int j = 0; j < B; ++j) g.slots[j % g.G].push_back(j);
-    while ((int)m.aux_streams.size() < g.G - 1) {
-        hipStream_t s;
-        MT2_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        m.aux_streams.push_back(s);
-    }
-    if (!m.ev_fork) MT2_HIP(hipEventCreateWithFlags(&m.ev_fork, hipEventDisableTiming));
-    while ((int)m.ev_join.size() < g.G - 1) {
-        hipEvent_t e;
-        MT2_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        m.ev_join.push_back(e);
-    }
+    ensure_aux(m, g.G - 1);
     g.stream.push_back(main);
     for (int i = 1; i < g.G; ++i) g.stream.push_back(m.aux_streams[i - 1]);
     return g;

@@ -160,6 +160,7 @@ struct AttnGeom {
 };
 struct EncScratch { float *h, *qkv, *att, *f, *parts; };
 static bool g_no_splitk = false;
+static int g_voc_streams = 3;   // resblock chains of a vocoder stage in flight (1 = serial)
 static EncScratch enc_scratch(const Ctx& c, const EncW& e, int M) {
     EncScratch s;
     s.h = c.ws.get<float>((size_t)M * e.d);
@@ -894,24 +895,37 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
         R *= s;
         ch = co;
         // multi-receptive-field fusion: mean of the resblocks (ResBlock1: x += conv2(lrelu(conv1(lrelu(x)))) x3)
+        // The three resblocks of a stage only share their input: each runs on its own stream (the caller's + two
+        // side streams), so that one chain's launch tails (868 tiles on 256 CUs at stage 1) are filled by the others.
         const size_t per = (size_t)R * ch;
-        float* t1 = c.ws.get<float>(per);
-        float* ha = c.ws.get<float>(per);
-        float* hb = c.ws.get<float>(per);
         float* rb[3] = {nullptr, nullptr, nullptr};
         MT2_REQUIRE(cfg.hg_n_res == 3, "HiFi-GAN V1 uses three resblocks per stage");
+        const int nside = g_voc_streams > 1 ? 2 : 0;
+        ensure_aux(m, nside);
+        if (nside) {
+            MT2_HIP(hipEventRecord(m.ev_fork, c.s));
+            for (int j = 0; j < nside; ++j) MT2_HIP(hipStreamWaitEvent(m.aux_streams[j], m.ev_fork, 0));
+        }
         for (int j = 0; j < 3; ++j) {
             const ResW& r = m.hg_res[i * 3 + j];
+            const Ctx cj{m, (nside && j > 0) ? m.aux_streams[j - 1] : c.s, c.ws};
+            float* t1 = c.ws.get<float>(per);
+            float* ha = c.ws.get<float>(per);
+            float* hb = c.ws.get<float>(per);
             rb[j] = c.ws.get<float>(per);
             const float* h = up;
             for (int n = 0; n < 3; ++n) {
                 float* out = n == 2 ? rb[j] : (n == 0 ? ha : hb);
                 // x + conv2(lrelu(conv1(lrelu(x)))): the inner leaky ReLU has ONE consumer, so it is applied once in
                 // conv1's epilogue instead of on every operand fragment of conv2 (same values, no VALU in that loop)
-                conv_same(c, h, ch, (int)R, r.c1[n], t1, ch, valid, ACT_LRELU, slope, ACT_LRELU, nullptr, 0, r.dil[n]);
-                conv_same(c, t1, ch, (int)R, r.c2[n], out, ch, valid, ACT_NONE, slope, ACT_NONE, h, ch, 1);
+                conv_same(cj, h, ch, (int)R, r.c1[n], t1, ch, valid, ACT_LRELU, slope, ACT_LRELU, nullptr, 0, r.dil[n]);
+                conv_same(cj, t1, ch, (int)R, r.c2[n], out, ch, valid, ACT_NONE, slope, ACT_NONE, h, ch, 1);
                 h = out;
             }
+        }
+        for (int j = 0; j < nside; ++j) {
+            MT2_HIP(hipEventRecord(m.ev_join[j], m.aux_streams[j]));
+            MT2_HIP(hipStreamWaitEvent(c.s, m.ev_join[j], 0));
         }
         x = c.ws.get<float>(per);
         MT2_HIP(launch_avg3(rb[0], rb[1], rb[2], 1.0f / 3.0f, x, (long long)per, c.s));

@@ -179,6 +179,11 @@ int mt2_op_gemm(void* stream, const float* X, int ldx, int Rx, const int32_t* ro
                 int taps, int dil, int Cin, const float* W, int ldw, const float* bias, const float* R, int ldr,
                 const int32_t* valid, float* C, int ldc, int M, int N, int pro_act, float pro_slope, int epi_act,
                 float out_scale, int force_cfg);
+/* C[M,N] = act(LayerNorm(X rows m*a_mul + shift0; gamma, beta, eps) @ W^T + bias): the LayerNorm-prologue form of
+ * the engine (AR steps: LN1 -> QKV, LN2 -> ff.0 in one launch).  K <= 1024; force_cfg -1 or a 2-deep-ring config. */
+int mt2_op_ln_gemm(void* stream, const float* X, int ldx, int Rx, int a_mul, int shift0, const float* gamma,
+                   const float* beta, float eps, const float* W, const float* bias, float* C, int ldc, int M, int N, int K,
+                   int epi_act, int force_cfg);
 int mt2_op_layernorm(void* stream, const float* x, int ldx, const float* gamma, const float* beta, const float* R1,
                      int ldr1, const int32_t* valid, float* out, int ldo, int M, int C, float eps, int act);
 int mt2_op_attention(void* stream, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,

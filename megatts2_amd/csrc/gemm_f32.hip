@@ -201,6 +201,7 @@ __device__ __forceinline__ void epilogue_pre_t(const GemmP& p, f32x16 (&acc)[TM]
 }
 
 constexpr int BK = 32;   // K chunk (floats)
+constexpr int PRO_LN = 3;   // prologue kind: LayerNorm of the A rows (value of GemmP::pro_act)
 constexpr int LS = 36;   // LDS row stride (floats): 144 B = 9 x 16 B -> conflict-free ds_read_b128
 
 template <int BM, int BN, int WGM, int WGN>
@@ -367,7 +368,10 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW);   // 1-KiB DMA pieces per wave per chunk
     constexpr int L = A_IT + B_IT;
-    constexpr int STAGE = (BM + BN) * BK;                       // floats per ring stage (of one K group)
+    constexpr bool LNP = PRO == PRO_LN;                         // LayerNorm prologue (see below)
+    constexpr int GBF = LNP ? 256 : 0;                          // + one 1-KiB piece per stage: gamma | beta chunk
+    constexpr int STAGE = (BM + BN) * BK + GBF;                 // floats per ring stage (of one K group)
+    static_assert(!LNP || (NST == 2 && TM == 1 && TN == 1), "LayerNorm prologue: 2-deep ring, one tile per wave");
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "piece/wave mismatch");
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64, "config");
     static_assert(KS == 1 || (TM == 1 && TN == 1 && 16 % KS == 0), "K split: one 32x32 tile per wave");
@@ -421,6 +425,55 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     // retire the rowbase loads HERE: once DMAs are in flight hipcc can only wait for an ordinary load
     // with vmcnt(0), which would drain the ring in the prologue
     wait_vmcnt<0>();
+    // ---- LayerNorm prologue (PRO_LN): C = LN(X) W^T without a separate LayerNorm launch.  Every workgroup first
+    // computes mean / rstd of ITS BM rows (two passes in registers, like layernorm_kernel; the rows come from L2,
+    // the other column tiles read the same ones), keeps them in LDS, and the K loop then normalises the A
+    // fragments on the fly: a' = (a - mean) * (rstd * gamma_k) + beta_k, gamma / beta travelling through the ring
+    // as one extra DMA piece per chunk.  Linear layers only (taps = 1), K <= 1024.
+    float ln_mu = 0.0f, ln_rs = 0.0f;
+    if constexpr (LNP) {
+        float* stat = smem + KS * NST * STAGE;                  // [BM][2]
+        constexpr int NWALL = NW * KS;
+        const int Kf = p.K;
+        const float inv_k = 1.0f / (float)Kf;
+        for (int r0 = wave_all; r0 < BM; r0 += NWALL) {
+            const int m = m0 + r0;
+            int src = -1;
+            if (m < p.M) src = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
+            float4 xv[4];
+            float sum = 0.0f;
+            const bool ok = (unsigned)src < (unsigned)Rx;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int c = (v * 64 + lane) * 4;
+                xv[v] = (ok && c < Kf) ? *reinterpret_cast<const float4*>(X + (long long)src * ldx + c)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                sum += (xv[v].x + xv[v].y) + (xv[v].z + xv[v].w);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum * inv_k;
+            float q2 = 0.0f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int c = (v * 64 + lane) * 4;
+                if (c < Kf) {
+                    const float a = xv[v].x - mean, b = xv[v].y - mean, cc = xv[v].z - mean, d = xv[v].w - mean;
+                    q2 += (a * a + b * b) + (cc * cc + d * d);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
+            if (lane == 0) {
+                stat[2 * r0] = ok ? mean : 0.0f;
+                stat[2 * r0 + 1] = ok ? 1.0f / sqrtf(q2 * inv_k + p.ln_eps) : 0.0f;
+            }
+        }
+        __syncthreads();
+        ln_mu = stat[2 * (wm * WTM + (lane & 31))];
+        ln_rs = stat[2 * (wm * WTM + (lane & 31)) + 1];
+        wait_vmcnt<0>();
+    }
     constexpr bool PRE = TM * TN == 1;          // epilogue operands in flight during the K loop
     constexpr int EPGK = 16 / KS;
     EpiPre<PRE ? EPGK : 1> pre;
@@ -453,6 +506,15 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
             const long long off = ok ? wofs[j] + k : zoff_w;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + off),
                                              (__attribute__((address_space(3))) void*)(Bs + j * NW * 256), 16, 0, 0);
+        }
+        if constexpr (LNP) {   // piece rows 0 / 1 = gamma / beta of this chunk (rows 0,1 have swizzle 0), rest zero
+            if (wave == 0) {
+                const int k = kchunk + (lane & 7) * 4;
+                const float* srcp = (lrow < 2 && k < Kt) ? (lrow == 0 ? p.ln_g : p.ln_b) + k : g_zero16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcp,
+                                                 (__attribute__((address_space(3))) void*)(ring + st * STAGE + (BM + BN) * BK),
+                                                 16, 0, 0);
+            }
         }
     };
 
@@ -490,11 +552,13 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
         // first operand fetch of this round goes out BEFORE the address arithmetic of the next DMA issue, so
         // its LDS latency is covered by that VALU work instead of adding to it
         const unsigned sa = a_lane + (unsigned)st * (STAGE * 4), sb = b_lane + (unsigned)st * (STAGE * 4);
-        f32x4 fa[2][TM], fb[2][TN];
+        const unsigned sg = lds0 + (unsigned)st * (STAGE * 4) + (BM + BN) * BK * 4 + half * 16;   // gamma row; beta +128
+        f32x4 fa[2][TM], fb[2][TN], fg[2], fbt[2];
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128(sa + koff[0] + i * 32 * BK * 4);
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128(sb + koff[0] + j * 32 * BK * 4);
+        if constexpr (LNP) { fg[0] = lds_read_b128(sg); fbt[0] = lds_read_b128(sg + 128); }
         if (rd + NST - 1 < nr) issue(rd + NST - 1, st == 0 ? NST - 1 : st - 1);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
@@ -509,11 +573,18 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
                 for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read_b128(sa + koff[kk + 1] + i * 32 * BK * 4);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128(sb + koff[kk + 1] + j * 32 * BK * 4);
+                if constexpr (LNP) {
+                    fg[nxt] = lds_read_b128(sg + (kk + 1) * 32);
+                    fbt[nxt] = lds_read_b128(sg + 128 + (kk + 1) * 32);
+                }
             }
             // pin the fetch of group kk+1 ABOVE the MFMAs of group kk (hipcc otherwise sinks the asm reads below
             // them and the s_waitcnt of the next group then exposes the whole LDS latency, every group)
             __builtin_amdgcn_sched_barrier(0);
-            if (PRO != ACT_NONE) {
+            if constexpr (LNP) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) fa[cur][0][e] = (fa[cur][0][e] - ln_mu) * (ln_rs * fg[cur][e]) + fbt[cur][e];
+            } else if (PRO != ACT_NONE) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -568,23 +639,29 @@ struct TileCfg {
     int bm, bn, threads;
     size_t lds;
     const char* name;
-    void (*fn[3])(GemmP);     // indexed by the prologue activation (none / relu / leaky relu)
+    void (*fn[4])(GemmP);     // indexed by the prologue: none / relu / leaky relu / LayerNorm (nullptr: no variant)
 };
 
 #define MT2_CFG(BM_, BN_, WM_, WN_)                                                                    \
     { BM_, BN_, WM_* WN_ * 64, 2ull * (BM_ + BN_) * LS * sizeof(float), #BM_ "x" #BN_ "_" #WM_ "x" #WN_, \
       { gemm_f32_kernel<BM_, BN_, WM_, WN_>, gemm_f32_kernel<BM_, BN_, WM_, WN_>,                        \
-        gemm_f32_kernel<BM_, BN_, WM_, WN_> } }
+        gemm_f32_kernel<BM_, BN_, WM_, WN_>, nullptr } }
 #define MT2_DMA(BM_, BN_, WM_, WN_, NST_)                                              \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (BM_ + BN_) * BK * sizeof(float),          \
       "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                   \
       { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_RELU>, \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_LRELU> } }
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_LRELU>, nullptr } }
 #define MT2_DMAK(BM_, BN_, WM_, WN_, KS_, NST_)                                                        \
     { BM_, BN_, WM_* WN_ * KS_ * 64, (size_t)KS_ * NST_ * (BM_ + BN_) * BK * sizeof(float),              \
       "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "_s" #NST_,                                        \
       { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_RELU>, \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_LRELU> } }
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_LRELU>, nullptr } }
+// 2-deep ring, one 32x32 tile per wave: also built with the LayerNorm prologue
+#define MT2_DMAL(BM_, BN_, WM_, WN_, KS_)                                                               \
+    { BM_, BN_, WM_* WN_ * KS_ * 64, (size_t)KS_ * 2 * (BM_ + BN_) * BK * sizeof(float),                 \
+      "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "_s2",                                             \
+      { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_RELU>, \
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_LRELU>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, PRO_LN> } }
 
 static const TileCfg kCfgs[] = {
     // v1: register-staged double buffer (kept for A/B runs and as the reference implementation)
@@ -608,18 +685,18 @@ static const TileCfg kCfgs[] = {
     MT2_DMA(256, 128, 4, 2, 3),   // 16: 8 waves (2 per SIMD), 64x64 per wave, 43 FLOP per operand byte
     MT2_DMA(128, 128, 4, 2, 4),   // 17: 8 waves, 32x64 per wave
     // v2 + in-workgroup K split (one 32x32 tile per wave, KS waves per SIMD)
-    MT2_DMAK(64, 64, 2, 2, 2, 2),   // 18:  8 waves,  64 KiB LDS (2 workgroups per CU)
+    MT2_DMAL(64, 64, 2, 2, 2),      // 18:  8 waves,  64 KiB LDS (2 workgroups per CU)
     MT2_DMAK(64, 64, 2, 2, 2, 4),   // 19:  8 waves, 128 KiB
-    MT2_DMAK(64, 64, 2, 2, 4, 2),   // 20: 16 waves, 128 KiB
+    MT2_DMAL(64, 64, 2, 2, 4),      // 20: 16 waves, 128 KiB
     MT2_DMAK(32, 64, 1, 2, 4, 3),   // 21:  8 waves, 144 KiB, 32-row tiles for the first AR steps
-    MT2_DMAK(32, 64, 1, 2, 4, 2),   // 22:  8 waves,  96 KiB
+    MT2_DMAL(32, 64, 1, 2, 4),      // 22:  8 waves,  96 KiB
     // 64-wide outputs (HiFi-GAN stage 3): a 128-wide tile would idle half of its MFMAs
     MT2_DMA(256, 64, 4, 2, 3),      // 23: 8 waves, 64x32 per wave, 120 KiB
     MT2_DMA(128, 64, 4, 2, 4),      // 24: 8 waves, 32x32 per wave,  96 KiB
     MT2_DMA(128, 64, 4, 2, 2),      // 25: the same with a 2-deep ring: 48 KiB -> 3 workgroups per CU
-    MT2_DMA(64, 64, 2, 2, 2),       // 26: 4 waves, 2-deep ring: 32 KiB -> 5 workgroups per CU
+    MT2_DMAL(64, 64, 2, 2, 1),      // 26: 4 waves, 2-deep ring: 32 KiB -> 5 workgroups per CU
     MT2_DMAK(128, 64, 4, 2, 2, 2),  // 27: 16 waves (2 K groups of 4x2), 96 KiB
-    MT2_DMAK(32, 32, 1, 1, 8, 2),   // 28: 8 waves = 8 K groups of one wave, 128 KiB: the shortest K chain (M*N <= 256 tiles)
+    MT2_DMAL(32, 32, 1, 1, 8),      // 28: 8 waves = 8 K groups of one wave, 128 KiB: the shortest K chain (M*N <= 256 tiles)
     MT2_DMAK(32, 32, 1, 1, 4, 3),   // 29: 4 waves, 96 KiB
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -630,7 +707,7 @@ const char* gemm_last_config() { return g_last_cfg; }
 static int g_force_cfg = -1;
 extern "C" void mt2_debug_force_gemm_config(int idx) { g_force_cfg = idx; }
 
-static bool g_attr_done[kNumCfgs][3] = {};
+static bool g_attr_done[kNumCfgs][4] = {};
 
 // ---- launch trace (measurement only): HIP events around every GEMM launch, on the launch stream
 struct TraceRec { int cfg; double flops; hipEvent_t e0, e1; };
@@ -733,8 +810,15 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s) {
     if ((p.Cin & 3) || (p.ldx & 3) || (p.ldw & 3) || p.K != p.taps * p.Cin) return hipErrorInvalidValue;
     int idx = 0;
     const TileCfg* c = choose_cfg(p, &idx);
-    const size_t lds = c->lds;
-    if (p.pro_act < 0 || p.pro_act > ACT_LRELU) return hipErrorInvalidValue;
+    if (p.pro_act < 0 || p.pro_act > PRO_LN) return hipErrorInvalidValue;
+    size_t lds = c->lds;
+    if (p.pro_act == PRO_LN) {
+        if (p.taps != 1 || p.K > 1024 || !p.ln_g || !p.ln_b) return hipErrorInvalidValue;
+        if (idx == 12 && g_force_cfg < 0) { idx = 26; c = &kCfgs[26]; }     // plain 64x64: its 2-deep-ring twin
+        if (!c->fn[PRO_LN]) return hipErrorNotSupported;                    // big tiles: caller falls back to LN + GEMM
+        const int ks = c->threads / 64 / ((c->bm / 32) * (c->bn / 32));     // one 32x32 tile per wave
+        lds = c->lds + (size_t)ks * 2 * 256 * sizeof(float) + (size_t)c->bm * 2 * sizeof(float);
+    }
     void (*fn)(GemmP) = c->fn[p.pro_act];
     if (!g_attr_done[idx][p.pro_act]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),

@@ -84,6 +84,28 @@ static void linear(const Ctx& c, const float* x, int ldx, int M, const float* W,
     gemm(c, p);
 }
 
+// y[M, N] = act(LN(x_rows)[M, K] @ W^T + b), x_rows[m] = x + (m * a_mul + shift0) * ldx: LayerNorm fused into the
+// GEMM as its prologue (gemm_f32.hip, PRO_LN) - one launch instead of two.  When the tile configuration chosen
+// for this shape has no such variant (big tiles), falls back to launch_layernorm into `h_scratch` + a plain GEMM.
+static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, int shift0, int M, const float* lng,
+                      const float* lnb, const float* W, const float* b, int N, int K, float* y, int ldy,
+                      float* h_scratch, int epi_act = ACT_NONE) {
+    GemmP p{};
+    p.X = x; p.ldx = ldx; p.Rx = Rx; p.a_mul = a_mul ? a_mul : 1; p.shift0 = shift0; p.taps = 1; p.dil = 1; p.Cin = K;
+    p.K = K; p.W = W; p.ldw = K; p.bias = b; p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.groups = 1; p.out_scale = 1.0f;
+    p.epi_act = epi_act; p.pro_act = 3; p.ln_g = lng; p.ln_b = lnb; p.ln_eps = 1e-5f;
+    if (!g_no_lnfuse && K <= 1024) {
+        const hipError_t e = launch_gemm(p, c.s);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotSupported) MT2_HIP(e);
+    }
+    LnP q{};
+    q.x = x + (long long)shift0 * ldx; q.ldx = ldx * p.a_mul; q.gamma = lng; q.beta = lnb; q.out = h_scratch; q.ldo = K;
+    q.M = M; q.C = K; q.eps = 1e-5f; q.act = ACT_NONE;
+    MT2_HIP(launch_layernorm(q, c.s));
+    linear(c, h_scratch, K, M, W, b, N, K, y, ldy, nullptr, 0, nullptr, epi_act);
+}
+
 // nn.Conv1d(k, stride 1, padding (k-1)/2 * dil, dilation dil) over gap-padded rows
 static void conv_same(const Ctx& c, const float* x, int ldx, int R, const ConvW& w, float* y, int ldy,
                       const int* valid, int pro_act = ACT_NONE, float slope = 0.f, int epi_act = ACT_NONE,
@@ -160,6 +182,7 @@ struct AttnGeom {
 };
 struct EncScratch { float *h, *qkv, *att, *f, *parts; };
 static bool g_no_splitk = false;
+static bool g_no_lnfuse = false;   // A/B switch: LayerNorm as a GEMM prologue in the AR layers (ln_linear)
 static int g_voc_streams = 3;   // resblock chains of a vocoder stage in flight (1 = serial)
 static EncScratch enc_scratch(const Ctx& c, const EncW& e, int M) {
     EncScratch s;
@@ -216,6 +239,9 @@ struct Pending {              // a residual update not yet applied: x += bias + 
 };
 static int choose_split(int M, int N, int K) {
     if (g_no_splitk) return 1;
+    // a split GEMM hands its reduction to a stand-alone LayerNorm launch, which the LayerNorm-prologue GEMM
+    // (ln_linear) otherwise removes: worth it only for the long K chains (PLM ff.3, K = 4096)
+    if (!g_no_lnfuse && K < 2048) return 1;
     const long long tiles = (long long)((M + 31) / 32) * ((N + 63) / 64);
     int S = 1;
     while (S < 16 && tiles * (S * 2) <= 256 && K % (S * 2) == 0 && K / (S * 2) >= 256 && (K / (S * 2)) % 32 == 0) S *= 2;
@@ -248,11 +274,11 @@ static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, fl
         linear_splitk(c, att, d, M, w.wo, d, d, S1, s.parts);
         Pending p1{s.parts, (long long)M * d, S1, w.bo};
         ln_pending(c, x, d, M, p1, w.ln2g, w.ln2b, s.h);
+        linear(c, s.h, d, M, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, nullptr, 0, nullptr, ACT_RELU);
     } else {
         linear(c, att, d, M, w.wo, w.bo, d, d, x, d, x, d);
-        layernorm(c, x, d, w.ln2g, w.ln2b, M, d, s.h, d);
+        ln_linear(c, x, d, M, 1, 0, M, w.ln2g, w.ln2b, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, s.h, ACT_RELU);   // LN2 -> ff.0
     }
-    linear(c, s.h, d, M, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, nullptr, 0, nullptr, ACT_RELU);
     const int S2 = choose_split(M, d, e.ff);
     if (S2 > 1) {
         linear_splitk(c, s.f, e.ff, M, w.ff1w, d, e.ff, S2, s.parts);
@@ -267,8 +293,12 @@ static Pending encoder_layer_ar(const Ctx& c, const EncW& e, const EncLayerW& w,
                                 const EncScratch& s, const Pending& in) {
     MT2_REQUIRE(!e.conv_ff, "AR step layers use the Linear feed-forward");
     const int d = e.d;
-    ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
-    linear(c, s.h, d, M, w.wqkv, w.bqkv, 3 * d, d, s.qkv, 3 * d);
+    if (in.S) {
+        ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
+        linear(c, s.h, d, M, w.wqkv, w.bqkv, 3 * d, d, s.qkv, 3 * d);
+    } else {
+        ln_linear(c, x, d, M, 1, 0, M, w.ln1g, w.ln1b, w.wqkv, w.bqkv, 3 * d, d, s.qkv, 3 * d, s.h);     // LN1 -> QKV
+    }
     attention_self(c, e, g, s.qkv, s.att);
     return ar_layer_tail(c, e, w, x, M, s.att, s);
 }
@@ -281,16 +311,19 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
                                const EncScratch& s, float* y, const Pending& in) {
     MT2_REQUIRE(!e.conv_ff, "AR step layers use the Linear feed-forward");
     const int d = e.d, M = A * n, D = d / e.heads;
-    ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
     float* kv = s.qkv;                                   // [M, 2d]: K | V
-    linear(c, s.h, d, M, w.wqkv + (size_t)d * d, w.bqkv + d, 2 * d, d, kv, 2 * d);
     float* q = s.att;                                    // [A, d]
     float* att = s.att + (size_t)A * d;                  // [A, d]
-    {
+    if (in.S) {
+        ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
+        linear(c, s.h, d, M, w.wqkv + (size_t)d * d, w.bqkv + d, 2 * d, d, kv, 2 * d);
         GemmP p{};
         p.X = s.h; p.ldx = d; p.Rx = M; p.a_mul = n; p.shift0 = n - 1; p.Cin = d; p.W = w.wqkv; p.bias = w.bqkv;
         p.C = q; p.ldc = d; p.M = A; p.N = d;
         gemm(c, p);
+    } else {   // LN1 fused into both consumers: K|V of all rows, Q of the last row of each sequence
+        ln_linear(c, x, d, M, 1, 0, M, w.ln1g, w.ln1b, w.wqkv + (size_t)d * d, w.bqkv + d, 2 * d, d, kv, 2 * d, s.h);
+        ln_linear(c, x, d, M, n, n - 1, A, w.ln1g, w.ln1b, w.wqkv, w.bqkv, d, d, q, d, s.f);
     }
     AttnP a{};
     a.Q = q; a.ldq = d; a.K = kv; a.ldk = 2 * d; a.V = kv + d; a.ldv = 2 * d; a.O = att; a.ldo = d;
@@ -299,9 +332,7 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
     MT2_HIP(launch_attention(a, c.s));
     // y = x[last rows] + out_proj(att): the residual rows sit n*d floats apart starting at row n-1
     linear(c, att, d, A, w.wo, w.bo, d, d, y, d, x + (size_t)(n - 1) * d, n * d);
-    float* h2 = s.h;                                     // [A, d] (LN1 output no longer needed)
-    layernorm(c, y, d, w.ln2g, w.ln2b, A, d, h2, d);
-    linear(c, h2, d, A, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, nullptr, 0, nullptr, ACT_RELU);
+    ln_linear(c, y, d, A, 1, 0, A, w.ln2g, w.ln2b, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, s.h, ACT_RELU);   // LN2 -> ff.0
     linear(c, s.f, e.ff, A, w.ff1w, w.ff1b, d, e.ff, y, d, y, d);
 }
 
@@ -313,19 +344,9 @@ static Pending encoder_layer_first_cached(const Ctx& c, const EncW& e, const Enc
                                           float* qkv_cache, int cs, const EncScratch& s) {
     MT2_REQUIRE(!e.conv_ff, "AR step layers use the Linear feed-forward");
     const int d = e.d, M = A * n, D = d / e.heads;
-    // LN1 + QKV of the newest row of every active sequence
-    {
-        LnP p{};
-        p.x = x + (size_t)(n - 1) * d; p.ldx = n * d; p.gamma = w.ln1g; p.beta = w.ln1b;
-        p.out = s.h; p.ldo = d; p.M = A; p.C = d; p.eps = 1e-5f; p.act = ACT_NONE;
-        MT2_HIP(launch_layernorm(p, c.s));
-    }
-    {
-        GemmP p{};
-        p.X = s.h; p.ldx = d; p.Rx = A; p.Cin = d; p.W = w.wqkv; p.bias = w.bqkv;
-        p.C = qkv_cache + (size_t)(n - 1) * 3 * d; p.ldc = cs * 3 * d; p.M = A; p.N = 3 * d;
-        gemm(c, p);
-    }
+    // LN1 -> QKV of the newest row of every active sequence, written into the cache at row stride cs
+    ln_linear(c, x, d, M, n, n - 1, A, w.ln1g, w.ln1b, w.wqkv, w.bqkv, 3 * d, d,
+              qkv_cache + (size_t)(n - 1) * 3 * d, cs * 3 * d, s.h);
     AttnP a{};
     a.Q = qkv_cache; a.ldq = 3 * d; a.K = qkv_cache + d; a.ldk = 3 * d; a.V = qkv_cache + 2 * d; a.ldv = 3 * d;
     a.O = s.att; a.ldo = d;

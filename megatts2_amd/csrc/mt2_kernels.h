@@ -33,6 +33,10 @@ struct GemmP {
     float* C; long long strideC; int ldc;
     int M, N, K, groups;
     int pro_act; float pro_slope; int epi_act; float out_scale;   // pro_slope doubles as the epilogue parameter (ACT_LOGCLAMP)
+    // pro_act == 3 (LayerNorm prologue, linear layers with K <= 1024 only): A rows are normalised on the fly,
+    // C = LN(X; ln_g, ln_b, ln_eps) W^T ...  launch_gemm returns hipErrorNotSupported when the tile configuration
+    // it would choose has no such variant (big tiles) - callers then run launch_layernorm + a plain GEMM.
+    const float* ln_g; const float* ln_b; float ln_eps;
 };
 hipError_t launch_gemm(const GemmP& p, hipStream_t s);
 const char* gemm_last_config();     // name of the tile configuration the last launch used

@@ -473,6 +473,17 @@ def op_gemm(X, W, bias=None, R=None, valid=None, rowbase=None, a_mul=1, shift0=0
     return out
 
 
+def op_ln_gemm(X, gamma, beta, W, bias=None, M=None, a_mul=1, shift0=0, eps=1e-5, epi_act=ACT_NONE, force_cfg=-1):
+    import torch
+    lib = load_library()
+    K, N = X.shape[1], W.shape[0]
+    M = M or X.shape[0]
+    out = torch.empty(M, N, device=X.device, dtype=torch.float32)
+    _check(lib.mt2_op_ln_gemm(_stream(), _ptr(X), K, X.shape[0], a_mul, shift0, _ptr(gamma), _ptr(beta), C.c_float(eps),
+                              _ptr(W), _ptr(bias), _ptr(out), N, M, N, K, epi_act, force_cfg))
+    return out
+
+
 def op_layernorm(x, gamma, beta, R1=None, valid=None, eps=1e-5, act=ACT_NONE):
     import torch
     lib = load_library()

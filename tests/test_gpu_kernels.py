@@ -120,6 +120,29 @@ def test_gemm_strided_conv_rowbase(rt, cfg):
         assert rel(out[r0:r0 + t], O.conv1d(u, w, b, stride=s, padding=s // 2)) < 3e-6
 
 
+@pytest.mark.parametrize("cfg", [-1, 18, 20, 22, 26, 28])
+@pytest.mark.parametrize("M,N,K", [(70, 2304, 768), (33, 96, 100), (300, 1024, 1024), (5, 64, 64)])
+def test_gemm_with_layernorm_prologue(rt, cfg, M, N, K):
+    """LN(x) @ W^T + b with the LayerNorm folded into the GEMM (AR steps: LN1 -> QKV, LN2 -> ff.0), incl. the
+    strided row gather of the "last row of each sequence" form."""
+    rng = np.random.default_rng(M + N + K)
+    X = (rng.standard_normal((M, K)) * 2.0 + 0.7).astype(np.float32)
+    g = rng.standard_normal(K).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    x64 = X.astype(np.float64)
+    ln = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * g + b
+    ref = np.maximum(ln @ W.T.astype(np.float64) + bias, 0)
+    out = rt.op_ln_gemm(dev(X), dev(g), dev(b), dev(W), dev(bias), epi_act=rt.ACT_RELU, force_cfg=cfg).cpu().numpy()
+    assert rel(out, ref) < 3e-6
+    if M >= 6:       # rows 2, 5, 8, ...: a_mul = 3, shift0 = 2
+        Ms = (M - 3) // 3 + 1
+        out2 = rt.op_ln_gemm(dev(X), dev(g), dev(b), dev(W), dev(bias), M=Ms, a_mul=3, shift0=2, epi_act=rt.ACT_RELU,
+                             force_cfg=cfg).cpu().numpy()
+        assert rel(out2, ref[2::3][:Ms]) < 3e-6
+
+
 @pytest.mark.parametrize("C", [32, 64, 384, 512, 768, 1024])
 def test_layernorm(rt, C):
     rng = np.random.default_rng(C)

@@ -106,7 +106,7 @@ def main() -> None:
     ap.add_argument("--ar-groups", type=int, default=0, help="AR stream groups (default: the library's, 2)")
     ap.add_argument("--no-splitk", action="store_true", help="debug: disable split-K through the LayerNorm")
     ap.add_argument("--voc-streams", type=int, default=0, help="debug: 1 = serial vocoder resblocks")
-    ap.add_argument("--no-lnfuse", action="store_true", help="debug: separate LayerNorm launches in the AR layers")
+    ap.add_argument("--lnfuse", action="store_true", help="debug: LayerNorm as a GEMM prologue in the AR layers (slower)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="test hook: exercise the launch / sharding / all-gather / reporting logic of this script on "
                          "CPU (gloo) with a stand-in engine - measures nothing")
@@ -160,8 +160,8 @@ def main() -> None:
             model.set_ar_groups(args.ar_groups)
         if args.no_splitk:
             model.lib.mt2_debug_set_splitk(0)
-        if args.no_lnfuse:
-            model.lib.mt2_debug_set_lnfuse(0)
+        if args.lnfuse:
+            model.lib.mt2_debug_set_lnfuse(1)
         if args.voc_streams:
             model.lib.mt2_debug_set_voc_streams(args.voc_streams)
         if args.thresh:

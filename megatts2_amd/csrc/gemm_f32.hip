@@ -814,8 +814,11 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s) {
     size_t lds = c->lds;
     if (p.pro_act == PRO_LN) {
         if (p.taps != 1 || p.K > 1024 || !p.ln_g || !p.ln_b) return hipErrorInvalidValue;
-        if (idx == 12 && g_force_cfg < 0) { idx = 26; c = &kCfgs[26]; }     // plain 64x64: its 2-deep-ring twin
-        if (!c->fn[PRO_LN]) return hipErrorNotSupported;                    // big tiles: caller falls back to LN + GEMM
+        // Measured (C2 / C3, profiles/r01_lnfuse_ab.txt): the prologue costs ~2 us of row statistics plus ~30 % of the
+        // K loop (12 VALU per 4 MFMAs, one more DMA piece) - a win only while a launch sits at its latency floor,
+        // i.e. for the two smallest tile configurations; everything larger runs LN + GEMM as two launches.
+        if (g_force_cfg < 0 && idx != 28 && idx != 22) return hipErrorNotSupported;
+        if (!c->fn[PRO_LN]) return hipErrorNotSupported;
         const int ks = c->threads / 64 / ((c->bm / 32) * (c->bn / 32));     // one 32x32 tile per wave
         lds = c->lds + (size_t)ks * 2 * 256 * sizeof(float) + (size_t)c->bm * 2 * sizeof(float);
     }

@@ -12,6 +12,12 @@
 
 namespace mt2 {
 
+static bool g_no_splitk = false;   // A/B switch: split-K through the LayerNorm
+// LayerNorm as a GEMM prologue in the AR layers (ln_linear).  OFF: measured slower than LN + GEMM as two launches at
+// every size (profiles/r01_lnfuse_ab.txt: C2 90.8 vs 89.8 ms even when restricted to the latency-floor launches,
+// 99.9 vs 89.4 ms when applied everywhere); mt2_debug_set_lnfuse(1) turns it on for A/B runs.
+static bool g_no_lnfuse = true;
+
 // ---------------------------------------------------------------------------------------------------
 // planning helpers
 
@@ -181,8 +187,6 @@ struct AttnGeom {
     int u_stride = 0, u_len = 0, B = 0, max_len = 0;
 };
 struct EncScratch { float *h, *qkv, *att, *f, *parts; };
-static bool g_no_splitk = false;
-static bool g_no_lnfuse = false;   // A/B switch: LayerNorm as a GEMM prologue in the AR layers (ln_linear)
 static int g_voc_streams = 3;   // resblock chains of a vocoder stage in flight (1 = serial)
 static EncScratch enc_scratch(const Ctx& c, const EncW& e, int M) {
     EncScratch s;

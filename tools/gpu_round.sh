@@ -1,5 +1,12 @@
 #!/bin/bash
-# One GPU-box session.  usage: bash tools/gpu_round.sh [tests] [smoke] [bench] [prof] [sweep]
+# One GPU-box session (run through gpurun).  usage: bash tools/gpu_round.sh <mode> [<mode> ...]
+#   tests smoke                      parity suites (-m gpu) and __graft_entry__.smoke()
+#   bench bench1 bench3 bench5       bench.py on C2 (default) / C1 / C3 / C5
+#   groups thresh splitk             A/B switches of bench.py (AR stream groups, tile thresholds, split-K through LN)
+#   prof prof3 profstage pmc probe   rocprofv3 kernel stats (C2 / C3 / one stage), PMC passes, per-launch PMC probe
+#   sweep sweep_ar sweep_voc sweep_vocx   GEMM engine sweeps (all / AR shapes / vocoder shapes / vocoder launch variants)
+#   frontend s2                      rows f3 / f2 measurements
+# everything is written under gpurun_out/ (scratch); summaries worth keeping are copied to profiles/ by hand.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 WHAT="${@:-tests smoke bench}"

@@ -173,9 +173,90 @@ def make_hifigan(kind: str) -> dict:
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# production-size fixtures beyond C1 (run with `python oracle/make_golden.py --extra`): one utterance at the
+# C2/C3/C4 geometry (70 phones / 431-frame prompt / 431 frames), a prompt-conditioned PLM case (row f1) and
+# long-shape stage fixtures at the C5 geometry (834 phones, 2584-frame prompt, 5168 frames).  Long inputs are
+# NOT stored: they are re-derived from `long_inputs(seed)` (numpy PCG64, identical on every machine).
+
+from fixtures import ADM_STEPS, LONG_SEED, PLM_STEPS, long_inputs  # noqa: E402
+
+
+def make_prod_extra() -> None:
+    ref = ref_shim.load()
+    G, plm, adm, sd_g, sd_p, sd_a = build_reference("prod")
+    g = cfgs("prod")[0]
+    emb = np.load(os.path.join(GOLDEN, "codebook_prod.npy"))
+    install_codebook(G, sd_g, emb)
+    # ---- C3 geometry, whole pipeline
+    rng = np.random.Generator(np.random.PCG64(3003))
+    utt = synth.make_utterance(rng, 70, 431, 431, g.mrte.phone_vocab_size, g.mrte.mel_bins, g.vqpe.vq_bins)
+    target = synth.make_utterance(rng, 1, 431, 431).prompt_mel
+    res = run_utterance(ref, G, plm, adm, utt, target)
+    res.pop("decoder_in")                                   # = [tc_expand | codebook[p_codes] x8]: rebuilt in the tests
+    np.savez_compressed(os.path.join(GOLDEN, "prod_utt1.npz"), **res)
+    print("prod_utt1", {k: v.shape for k, v in res.items()})
+    print("   dur", res["adm_dur"][:16], "codes", res["p_codes"][:12], "vq distinct", len(set(res["vqpe_codes"].tolist())))
+    # ---- prompt-conditioned PLM (row f1): training layout of modules/datamodule.py:201-212 at inference
+    P, TQ = 21, 33
+    cond = np.maximum(rng.standard_normal((P + TQ, 512)), 0).astype(np.float32)
+    prefix = rng.integers(0, 1024, P).astype(np.int64)
+    logits_all = []
+    with torch.no_grad():
+        tc = torch.from_numpy(cond)[None]
+        p_code = torch.cat([torch.tensor([1024]), torch.from_numpy(prefix)])[None]       # BOS, then the prompt's codes
+        for t in range(P, P + TQ):                                                       # models/megatts2.py:172-179
+            pc_emb = plm.pc_embedding(p_code)
+            x_pos = plm.pos(torch.cat([tc[:, 0:t + 1, :], pc_emb], dim=-1))
+            logits = plm.predict_layer(plm.plm(x_pos))[:, -1:, :]
+            logits_all.append(logits[0, 0].numpy().copy())
+            p_code = torch.cat([p_code, logits.argmax(dim=-1)], dim=1)
+    np.savez_compressed(os.path.join(GOLDEN, "prod_plm_prefix.npz"), cond=cond, prefix=prefix,
+                        codes=p_code[0, 1 + P:].numpy(), logits=np.stack(logits_all).astype(np.float32))
+    print("prod_plm_prefix codes", p_code[0, 1 + P:].numpy()[:16])
+    # ---- long shapes (C5 geometry), stage by stage
+    li = long_inputs(emb)
+    out = {"seed": np.asarray(LONG_SEED)}
+    with torch.no_grad():
+        mel = torch.from_numpy(li["prompt_mel"])[None]
+        out["mel_context"] = G.mrte.mel_encoder(mel.transpose(1, 2))[0].transpose(0, 1).numpy()          # [162, 512]
+        x = torch.from_numpy(li["decoder_in"])[None]
+        out["mel"] = G.decoder(x.transpose(1, 2))[0].transpose(0, 1).numpy()                              # [5168, 80]
+        tm = torch.from_numpy(li["target_mel"])[None]
+        ze = G.vqpe.convnet(tm[..., :G.vqpe.mel_bins].transpose(1, 2))
+        out["vqpe_ze"] = ze[0].transpose(0, 1).numpy()                                                    # [646, 256]
+        _, _, _, codes2 = G.vqpe(tm)
+        out["vqpe_codes"] = codes2[0, 0].numpy()
+        # single ADM steps on a forced float history (models/megatts2.py:264-273, step t = n - 1)
+        tc = torch.from_numpy(li["adm_tc"])[None]
+        for n in ADM_STEPS:
+            p_code = torch.cat([torch.zeros(1), torch.from_numpy(li["adm_hist"][:n - 1])])[None, :, None]   # [1, n, 1]
+            dt_emb = adm.dt_linear_emb(p_code)
+            tc_emb = adm.tc_linear_emb(tc[:, 0:n, :])
+            x_pos = adm.pos_emb(torch.cat([tc_emb, dt_emb], dim=-1))
+            h = adm.adm(x_pos)
+            out[f"adm_pred_{n}"] = adm.predict_layer(h)[0, -1, 0].numpy().astype(np.float32)
+            out[f"adm_hid_{n}"] = h[0, -1].numpy()
+        cond = torch.from_numpy(li["plm_cond"])[None]
+        for n in PLM_STEPS:
+            p_code = torch.cat([torch.tensor([1024]), torch.from_numpy(li["plm_hist"][:n - 1])])[None]
+            pc_emb = plm.pc_embedding(p_code)
+            x_pos = plm.pos(torch.cat([cond[:, 0:n, :], pc_emb], dim=-1))
+            h = plm.plm(x_pos)
+            out[f"plm_logits_{n}"] = plm.predict_layer(h)[0, -1].numpy()
+            out[f"plm_hid_{n}"] = h[0, -1].numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "prod_long.npz"), **out)
+    print("prod_long", {k: v.shape for k, v in out.items()})
+    print("   adm preds", [float(out[f"adm_pred_{n}"]) for n in ADM_STEPS],
+          "plm argmax", [int(out[f"plm_logits_{n}"].argmax()) for n in PLM_STEPS])
+
+
 def main() -> None:
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
+    if "--extra" in sys.argv:
+        make_prod_extra()
+        return
     # vocoder fixtures FIRST: transformers must be imported before ref_shim puts its torchaudio /
     # librosa stand-ins into sys.modules (its availability probes trip over them otherwise)
     for kind in ("tiny", "prod"):

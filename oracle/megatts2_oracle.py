@@ -283,14 +283,24 @@ def length_regulate(x: np.ndarray, durations: Sequence[int]) -> np.ndarray:
 # models/megatts2.py: ADM / PLM autoregressive inference
 
 
-def adm_infer(sd: SD, cfg, tc_latent: np.ndarray, return_float: bool = False):
+def adm_infer(sd: SD, cfg, tc_latent: np.ndarray, return_float: bool = False,
+              p_prefix: Optional[np.ndarray] = None, steps: Optional[int] = None):
     """MegaADM.infer (models/megatts2.py:257-275): for t in range(Np) re-encode ALL t+1 positions
     NON-causally (mask None), append the un-rounded float prediction of the last
-    position (N3), finally trunc(x + 0.5).clamp(1, 128) as int32."""
+    position (N3), finally trunc(x + 0.5).clamp(1, 128) as int32.
+
+    `p_prefix` (test hook, no reference counterpart): float predictions of the first P positions are
+    GIVEN (teacher forcing); the loop continues from position P for `steps` positions (default: to the
+    end).  With P = n - 1 and steps = 1 this is exactly the reference's step t = n - 1 on a forced
+    history - how the long-shape parity tests reach n = 834 without running 834 steps."""
     n = tc_latent.shape[0]
     p_code = np.zeros((1, 1), F32)                              # :262-263
+    if p_prefix is not None:
+        p_code = np.concatenate([p_code, np.asarray(p_prefix, F32).reshape(-1, 1)], axis=0)
+    t0 = p_code.shape[0] - 1
+    t1 = n if steps is None else min(n, t0 + steps)
     tc_emb_all = linear(tc_latent, sd["tc_linear_emb.weight"])  # row-wise; slicing commutes
-    for t in range(n):
+    for t in range(t0, t1):
         dt_emb = linear(p_code, sd["dt_linear_emb.weight"])     # [t+1, emb]
         x = np.concatenate([tc_emb_all[:t + 1], dt_emb], axis=-1)
         x = add_pe(x, sd["pos_emb.alpha"])
@@ -302,14 +312,25 @@ def adm_infer(sd: SD, cfg, tc_latent: np.ndarray, return_float: bool = False):
     return (dur, flt) if return_float else dur
 
 
-def plm_infer(sd: SD, cfg, cond: np.ndarray, return_logits: bool = False):
+def plm_infer(sd: SD, cfg, cond: np.ndarray, return_logits: bool = False,
+              prefix_codes: Optional[np.ndarray] = None, steps: Optional[int] = None):
     """MegaPLM.infer (models/megatts2.py:165-181): BOS = 1024 (hard-coded literal at :170, equal to
     vq_bins in the shipped config), greedy argmax over vq_bins logits of the LAST position after a
-    NON-causal re-encode of all t+1 positions."""
+    NON-causal re-encode of all t+1 positions.
+
+    `prefix_codes`: prompt-conditioned decoding in the layout the PLM is TRAINED on
+    (modules/datamodule.py:201-212: the same-speaker prompt's pooled tc_latents and VQ-PE codes are
+    concatenated IN FRONT of the target's, BOS first).  `cond` then holds P prompt rows followed by the
+    target rows, the code history starts as [BOS, prefix_codes...] and decoding continues from
+    position P; the returned codes / logits are those of the target positions only."""
     tq = cond.shape[0]
     codes: List[int] = [PLM_BOS]
+    if prefix_codes is not None:
+        codes += [int(c) for c in np.asarray(prefix_codes).reshape(-1)]
+    t0 = len(codes) - 1
+    t1 = tq if steps is None else min(tq, t0 + steps)
     logits_all = []
-    for t in range(tq):
+    for t in range(t0, t1):
         pc = sd["pc_embedding.weight"][np.asarray(codes, np.int64)]
         x = np.concatenate([cond[:t + 1], pc], axis=-1).astype(F32)
         x = add_pe(x, sd["pos.alpha"])
@@ -317,7 +338,7 @@ def plm_infer(sd: SD, cfg, cond: np.ndarray, return_logits: bool = False):
         logits = linear(x[-1:], sd["predict_layer.weight"])[0]
         logits_all.append(logits)
         codes.append(int(np.argmax(logits)))                    # first index on ties (torch.argmax)
-    out = np.asarray(codes[1:], np.int64)
+    out = np.asarray(codes[1 + t0:], np.int64)
     return (out, np.stack(logits_all)) if return_logits else out
 
 

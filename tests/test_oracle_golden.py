@@ -126,3 +126,86 @@ def test_aten_backend_of_the_port_equals_numpy_backend(tiny):
     assert np.array_equal(got["adm_dur"], ref["adm_dur"]) and np.array_equal(got["p_codes"], ref["p_codes"])
     assert O.rel_l2(got["mel"], ref["mel"]) < 1e-5
     assert O.linear.__module__ == O.__name__            # numpy primitives restored
+
+
+# ---------------------------------------------------------------------------------------------------
+# production-size fixtures beyond C1 (oracle/make_golden.py --extra): C2/C3/C4 geometry, prompt-conditioned
+# PLM, and the long shapes of C5 - all produced by the LIVE reference modules.
+
+
+def test_prod_c3_geometry(prod):
+    """One utterance of 70 phones / 431-frame prompt / 431 frames (BASELINE configs[1..3]) through every
+    stage with teacher forcing."""
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = prod
+    z = load_golden("prod_utt1.npz")
+    O.enable_torch_kernels()            # ATen backend of the same port: minutes -> seconds at this size
+    try:
+        assert O.rel_l2(O.mrte_mel_context(sd_g, g, z["prompt_mel"]), z["mel_context"]) < TOL
+        assert O.rel_l2(O.mrte_tc_latent(sd_g, g, z["phone"], z["prompt_mel"]), z["tc_latent"]) < TOL
+        dur, flt = O.adm_infer(sd_a, a, z["tc_latent"], return_float=True)
+        assert np.allclose(flt, z["adm_float"], rtol=1e-4, atol=1e-4)
+        assert np.array_equal(dur, z["adm_dur"]) and dur.max() > 1            # not the trivial all-1 case
+        tce = O.length_regulate(z["tc_latent"], z["forced_dur"])
+        assert np.array_equal(O.max_pool1d_ceil(tce, 8), z["plm_cond"])
+        codes, logits = O.plm_infer(sd_p, p, z["plm_cond"], return_logits=True)
+        assert np.array_equal(codes, z["p_codes"])
+        assert O.rel_l2(logits, z["plm_logits"]) < 1e-4
+        assert O.rel_l2(O.mel_decoder(sd_g, g, O.decoder_input(sd_g, g, tce, z["p_codes"])), z["mel"]) < TOL
+        zq, vcodes, ze = O.vqpe_forward(sd_g, g, z["target_mel"])
+        assert O.rel_l2(ze, z["vqpe_ze"]) < TOL
+        assert np.array_equal(vcodes, z["vqpe_codes"]) and np.array_equal(zq, z["vqpe_zq"])
+    finally:
+        O.disable_torch_kernels()
+
+
+def test_prod_plm_prompt_prefix(prod):
+    """Row f1: prompt-conditioned decoding (training layout of modules/datamodule.py:201-212 at inference)."""
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = prod
+    z = load_golden("prod_plm_prefix.npz")
+    O.enable_torch_kernels()
+    try:
+        codes, logits = O.plm_infer(sd_p, p, z["cond"], return_logits=True, prefix_codes=z["prefix"])
+    finally:
+        O.disable_torch_kernels()
+    assert codes.shape == z["codes"].shape == (z["cond"].shape[0] - z["prefix"].size,)
+    assert np.array_equal(codes, z["codes"])
+    assert O.rel_l2(logits, z["logits"]) < 1e-4
+
+
+def test_prod_long_shapes(prod):
+    """C5 geometry (834 phones, 2584-frame prompt, 5168 frames), stage by stage: mel encoder, decoder, VQ-PE
+    (indices bit-exact) and single AR steps on forced histories at n = 71/417/834 (ADM), 128/646 (PLM)."""
+    import fixtures
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = prod
+    z = load_golden("prod_long.npz")
+    li = fixtures.long_inputs(sd_g[O.CODEBOOK], int(z["seed"]))
+    O.enable_torch_kernels()
+    try:
+        assert O.rel_l2(O.mrte_mel_context(sd_g, g, li["prompt_mel"]), z["mel_context"]) < TOL
+        assert O.rel_l2(O.mel_decoder(sd_g, g, li["decoder_in"]), z["mel"]) < TOL
+        zq, vcodes, ze = O.vqpe_forward(sd_g, g, li["target_mel"])
+        assert O.rel_l2(ze, z["vqpe_ze"]) < TOL
+        assert np.array_equal(vcodes, z["vqpe_codes"])
+        for n in fixtures.ADM_STEPS:
+            _, flt = O.adm_infer(sd_a, a, li["adm_tc"][:n], return_float=True, p_prefix=li["adm_hist"][:n - 1], steps=1)
+            assert flt.shape == (n,) and np.array_equal(flt[:n - 1], li["adm_hist"][:n - 1])
+            assert abs(float(flt[-1]) - float(z[f"adm_pred_{n}"])) < 1e-4 * max(1.0, abs(float(z[f"adm_pred_{n}"])))
+        for n in fixtures.PLM_STEPS:
+            codes, logits = O.plm_infer(sd_p, p, li["plm_cond"][:n], return_logits=True,
+                                        prefix_codes=li["plm_hist"][:n - 1], steps=1)
+            assert O.rel_l2(logits[0], z[f"plm_logits_{n}"]) < 1e-4
+            assert int(codes[0]) == int(z[f"plm_logits_{n}"].argmax())
+    finally:
+        O.disable_torch_kernels()
+
+
+def test_mel_filterbank_pinned_against_transformers():
+    """Row f3: the slaney filterbank restatement against an independent implementation that ships in the image
+    (transformers.audio_utils.mel_filter_bank, norm="slaney", mel_scale="slaney")."""
+    au = pytest.importorskip("transformers.audio_utils")
+    for n_freq, fmin, fmax, n_mels, sr in ((513, 0.0, 8000.0, 80, 16000), (257, 50.0, 7600.0, 40, 16000),
+                                           (513, 0.0, 11025.0, 80, 22050)):
+        ref = au.mel_filter_bank(num_frequency_bins=n_freq, num_mel_filters=n_mels, min_frequency=fmin,
+                                 max_frequency=fmax, sampling_rate=sr, norm="slaney", mel_scale="slaney")
+        got = O.melscale_fbanks(n_freq, fmin, fmax, n_mels, sr)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-12

@@ -15,9 +15,12 @@
  *    their host synchronisation.
  *  - Return value: 0 = ok, < 0 = error; `mt2_last_error()` gives the message (thread-local).
  *    Nothing throws across the boundary.
- *  - A model handle is immutable after `mt2_model_finalize`; one call at a time per handle (it owns
- *    the activation workspace).  Batch semantics: every utterance is computed exactly as if it were
- *    alone (the reference is batch-1).
+ *  - A model handle's weights are immutable after `mt2_model_finalize`.  The handle owns ONE activation
+ *    workspace and its internal streams: calls on one handle are serialised (a mutex makes concurrent host
+ *    threads safe; a call on a different stream than the previous call first waits, on the device, for that
+ *    call's end).  For concurrency use one handle per thread / stream.  Apart from the handle there is no
+ *    mutable global state in the library.  Batch semantics: every utterance is computed exactly as if it
+ *    were alone (the reference is batch-1).
  */
 #ifndef MEGATTS2_HIP_H
 #define MEGATTS2_HIP_H
@@ -50,6 +53,9 @@ typedef struct mt2_config {
     int32_t hg_n_res, hg_res_kernels[4], hg_res_dilations[4][3];
     float hg_slope;
     int32_t max_positions;   /* rows of the sine positional tables (embedding.py:66 builds 4000) */
+    /* speechbrain HifiganGenerator.inference(): the mel is replicate-padded by this many frames on both sides
+     * before the generator (hub model: 5), so decode_batch returns (T + 2*pad)*hop samples; 0 = plain forward */
+    int32_t hg_inference_padding;
 } mt2_config;
 
 const char* mt2_last_error(void);
@@ -71,6 +77,14 @@ int mt2_model_finalize(mt2_model* m);
 void mt2_model_destroy(mt2_model* m);
 /* bytes of device memory held (weights, workspace) */
 int mt2_model_memory(const mt2_model* m, size_t* weight_bytes, size_t* workspace_bytes);
+/* ---- activation workspace.  The handle owns a bump arena over persistent hipMalloc chunks, reset by every call.
+ * mt2_workspace_query: upper bound (bytes) of what ONE mt2_synthesize_batch call of this geometry takes (every
+ * utterance at the maxima; flags as for mt2_synthesize_batch) - so that a server can pre-size the arena with
+ * mt2_workspace_reserve and no hipMalloc happens on the hot path.  mt2_workspace_high_water: most bytes any call
+ * has had in use so far. */
+int mt2_workspace_query(const mt2_model* m, int B, int Np_max, int Tp_max, int Tm_cap, int flags, size_t* bytes);
+int mt2_workspace_reserve(mt2_model* m, size_t bytes);
+int mt2_workspace_high_water(const mt2_model* m, size_t* bytes);
 
 /* ---- MRTE.tc_latent(phone, mel) (modules/mrte.py:154-171)
  * phone int64 [B, Np_max], mel f32 [B, Tp_max, mel_bins] -> out f32 [B, Np_max, hidden]. */
@@ -87,6 +101,13 @@ int mt2_mrte_mel_context(mt2_model* m, void* stream, const float* mel, const int
  * be NULL) receives the un-rounded predictions.  Asynchronous on `stream`. */
 int mt2_adm_infer(mt2_model* m, void* stream, const float* tc_latent, const int32_t* lens /*host*/, int Np_max,
                   int B, int32_t* dur, float* dur_float);
+/* The same loop started from a FORCED history (no reference counterpart; parity tests of long sequences): the
+ * un-rounded predictions of the first P positions of every sequence are given (p_prefix f32 [B, P], device), the
+ * loop continues at position P for `max_steps` positions (0 = to the end).  P = n-1, max_steps = 1 is exactly the
+ * reference's step t = n-1 (models/megatts2.py:264-273) on that history. */
+int mt2_adm_infer_forced(mt2_model* m, void* stream, const float* tc_latent, const int32_t* lens /*host*/,
+                         int Np_max, int B, const float* p_prefix, int P, int max_steps, int32_t* dur,
+                         float* dur_float);
 
 /* ---- LengthRegulator.forward(x, duration_tokens) (modules/mrte.py:42-60)
  * x f32 [B, Np_max, D], dur int32 (HOST) [B, Np_max] -> out f32 [B, Tm_max, D] (zero rows beyond sum(dur_b)).
@@ -105,6 +126,14 @@ int mt2_max_pool_ceil(mt2_model* m, void* stream, const float* x, const int32_t*
  * f32 [B, Tq_max, bins] receives the logits of every step's last position. */
 int mt2_plm_infer(mt2_model* m, void* stream, const float* cond, const int32_t* lens /*host*/, int Tq_max, int B,
                   int64_t* codes, float* last_logits);
+/* Prompt-conditioned decoding in the layout the PLM is trained on (modules/datamodule.py:201-212: the prompt's
+ * pooled tc_latents and VQ-PE prosody codes in FRONT of the target's, BOS first): cond f32 [B, P + Tq_max, tc_dim]
+ * holds P prompt rows then the target rows, prefix_codes int64 [B, P] (device) the prompt's codes; the history
+ * starts as [BOS, prefix...] and decoding continues at position P for `max_steps` positions (0 = all).  lens =
+ * TARGET lengths; codes / last_logits receive the target positions only.  P = 0 is mt2_plm_infer. */
+int mt2_plm_infer_prompted(mt2_model* m, void* stream, const float* cond, const int32_t* lens /*host*/, int Tq_max,
+                           int B, const int64_t* prefix_codes, int P, int max_steps, int64_t* codes,
+                           float* last_logits);
 
 /* ---- generator.vqpe.vq.decode(codes) (modules/quantization/vq.py:109-113)
  * codes int64 [n_q=1, B, Tq_max] -> out f32 [B, vq_dim, Tq_max]. */
@@ -126,7 +155,9 @@ int mt2_mel_decoder(mt2_model* m, void* stream, const float* x, const int32_t* l
                     float* mel);
 
 /* ---- hifi_gan.decode_batch(mel) (speechbrain; models/megatts2.py:370): HiFi-GAN V1 generator
- * mel f32 [B, in_dim, T_max] -> wav f32 [B, 1, hop*T_max]. */
+ * mel f32 [B, in_dim, T_max] -> wav f32 [B, 1, hop*(T_max + 2*hg_inference_padding)]; utterance b holds
+ * hop*(len_b + 2*pad) samples (its own first / last frame replicated `pad` times, as
+ * HifiganGenerator.inference does for a batch-1 call), zeros beyond. */
 int mt2_hifigan(mt2_model* m, void* stream, const float* mel, const int32_t* lens /*host*/, int T_max, int B,
                 float* wav);
 
@@ -151,8 +182,12 @@ int mt2_mel_spectrogram(mt2_model* m, void* stream, const mt2_audio_config* ac, 
  *   forced_codes (device, optional) int64 [B, Tq_cap]: replaces the PLM (config C2).
  *   flags: bit0 run the PLM (ignored when forced_codes given), bit1 run the vocoder, bit2 skip the ADM.
  * Outputs: mel f32 [B, Tm_cap, mel_bins] (time-major), mel_lens (host) int32 [B], optional
- * dur_out int32 [B, Np_max] (device), codes_out int64 [B, Tq_cap] (device), wav f32 [B, hop*Tm_cap].
- * Tm_cap / Tq_cap are capacities; an utterance longer than Tm_cap is an error. */
+ * dur_out int32 [B, Np_max] (device), codes_out int64 [B, Tq_cap] (device),
+ * wav f32 [B, hop*(Tm_cap + 2*hg_inference_padding)].
+ * Tm_cap / Tq_cap are capacities; an utterance longer than Tm_cap is an error.
+ * Phone ids and forced codes (the whole zero-padded [B, Tq_cap] tensor) are range-checked on the device before
+ * use - one stream synchronisation at the start of the call; an id outside its table is an error (the reference
+ * raises IndexError from nn.Embedding), never an out-of-bounds read. */
 #define MT2_RUN_PLM 1
 #define MT2_RUN_VOCODER 2
 #define MT2_SKIP_ADM 4
@@ -162,9 +197,13 @@ int mt2_synthesize_batch(mt2_model* m, void* stream, const int64_t* phone, const
                          int flags, float* mel, int Tm_cap, int32_t* mel_lens /*host*/, int32_t* dur_out,
                          int64_t* codes_out, float* wav);
 
-/* ---- tuning: the sequences of an autoregressive run (mt2_adm_infer / mt2_plm_infer / the AR stages of
- * mt2_synthesize_batch) are dealt into `groups` independent kernel chains on internal HIP streams that fork
- * from and join back into `stream` (default 2; 1 = everything on `stream`).  Results do not depend on it. */
+/* ---- tuning.  Every switch lives in the handle (no process-global state): two handles do not see each other's
+ * settings.  Names: "ar_groups" (1..8, default 2: the sequences of an autoregressive run are dealt into that many
+ * independent kernel chains on internal HIP streams that fork from and join back into `stream`; results do not
+ * depend on it), "splitk" (1), "lnfuse" (0), "voc_streams" (3), "voc_fused" (1), "force_gemm_config" (-1),
+ * "t_ks4", "t_ks2", "t32", "t32x32" (tile-choice thresholds).  Unknown names are an error. */
+int mt2_set_option(mt2_model* m, const char* name, int value);
+int mt2_get_option(mt2_model* m, const char* name, int* value);
 int mt2_set_ar_groups(mt2_model* m, int groups);
 
 /* ---- measurement support: time (ms, HIP events on `stream`) spent in each stage of the last
@@ -194,8 +233,10 @@ int mt2_op_attention(void* stream, const float* Q, int ldq, const float* K, int 
  * launches, the executed FLOPs (2*M*N*K*groups) and the summed kernel time in ms, plus a last entry named
  * "union" = length of the union of all launch intervals (launches on different internal streams overlap);
  * returns the number of entries written (<= cap). */
-int mt2_gemm_trace_begin(void);
-int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches, double* flops, double* ms);
+int mt2_gemm_trace_begin(mt2_model* m);
+int mt2_gemm_trace_end(mt2_model* m, int cap, const char** names, int64_t* launches, double* flops, double* ms);
+int mt2_gemm_config_count(void);
+const char* mt2_gemm_config_name(int idx);
 /* time `iters` back-to-back launches of one GEMM / conv (taps, dilation) with HIP events on `stream`, cycling
  * through `w_copies` copies of the weight matrix (> 1: weights are not L2-resident from the previous launch);
  * flags bit0: leaky-ReLU prologue, bit1: bias + residual + row-mask epilogue; average ms */

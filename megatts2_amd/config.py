@@ -133,6 +133,10 @@ class HifiGanConfig:
     resblock_dilation_sizes: List[List[int]] = field(
         default_factory=lambda: [[1, 3, 5], [1, 3, 5], [1, 3, 5]])
     leaky_relu_slope: float = 0.1
+    # speechbrain's HifiganGenerator.inference() replicate-pads the mel by `inference_padding` frames on both
+    # sides before forward() (hub model: 5) - decode_batch then returns (T + 2*pad) * hop samples.  0 = plain
+    # forward (what transformers.SpeechT5HifiGan, the stand-in oracle, computes).
+    inference_padding: int = 0
 
     @property
     def hop(self) -> int:
@@ -142,8 +146,23 @@ class HifiGanConfig:
         return h
 
 
+# Keys of the reference constructors that are NOT hyper-parameters of the inference kernels: they may appear in a
+# YAML with any value (dropout is identity under .eval(); the rest configure training / the front-end).
+_INERT = {"dropout", "duration_token_ms", "max_duration_token", "mel_frames", "sample_rate"}   # mrte.py:64-84
+# Keys the kernels hard-code: another value in a checkpoint's config would load fine and compute something else,
+# so it is an error (reference modules/convnet.py:14,88 / modules/mrte.py:75-76: `getattr(nn, activation)`).
+_FIXED = {"activation": "ReLU", "mel_activation": "ReLU"}
+
+
 def _pick(cls, init_args: dict):
     names = {f for f in cls.__dataclass_fields__}
+    for k, v in init_args.items():
+        if k in _FIXED and v != _FIXED[k]:
+            raise ValueError(f"{cls.__name__}: {k}={v!r} is not supported - the HIP kernels implement {_FIXED[k]} "
+                             f"(reference default); a checkpoint trained with another activation cannot be served")
+        if k not in names and k not in _FIXED and k not in _INERT:
+            raise ValueError(f"{cls.__name__}: unknown hyper-parameter {k!r} in the model config "
+                             f"(known: {sorted(names)})")
     return cls(**{k: v for k, v in init_args.items() if k in names})
 
 
@@ -156,6 +175,10 @@ def g_config_from_yaml(path: str) -> GConfig:
     rest = {k: v for k, v in g.items() if k not in ("mrte", "vqpe")}
     cfg = _pick(GConfig, rest)
     cfg.mrte, cfg.vqpe = mrte, vqpe
+    if vqpe.stride != 8:
+        # Megatts.forward pools and repeats by the LITERAL 8 (models/megatts2.py:357,363), whatever vqpe.stride says
+        raise ValueError(f"vqpe.stride={vqpe.stride}: the synthesis path of the reference hard-codes 8 "
+                         "(models/megatts2.py:357,363)")
     return cfg
 
 

@@ -25,6 +25,7 @@
 #include "mt2_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <utility>
 #include <vector>
 
@@ -701,43 +702,34 @@ static const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-static thread_local const char* g_last_cfg = "";
-const char* gemm_last_config() { return g_last_cfg; }
+int gemm_num_configs() { return kNumCfgs; }
+const char* gemm_config_name(int idx) { return idx >= 0 && idx < kNumCfgs ? kCfgs[idx].name : ""; }
 
-static int g_force_cfg = -1;
-extern "C" void mt2_debug_force_gemm_config(int idx) { g_force_cfg = idx; }
+// hipFuncSetAttribute is process-wide state of the code object: a "done" cache per (configuration, prologue) only
+// saves the call; the benign race (two threads both setting the same value) is harmless.
+static std::atomic<bool> g_attr_done[kNumCfgs][4];
 
-static bool g_attr_done[kNumCfgs][4] = {};
-
-// ---- launch trace (measurement only): HIP events around every GEMM launch, on the launch stream
-struct TraceRec { int cfg; double flops; hipEvent_t e0, e1; };
-static bool g_trace_on = false;
-static std::vector<TraceRec> g_trace;
-
-extern "C" int mt2_gemm_trace_begin(void) {
-    for (auto& r : g_trace) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-    g_trace.clear();
-    g_trace_on = true;
-    return 0;
-}
+// ---- launch trace (measurement only): HIP events around every GEMM launch, on the launch stream; the records
+// live in the EngineOpts of whoever asked for the trace (the model handle).
 // Per tile configuration: launches, executed FLOPs (2*M*N*K*groups) and summed kernel time (ms).  When the
 // launches ran on several streams (AR stream groups) their intervals overlap; a last pseudo-entry named
 // "union" carries the length of the UNION of all launch intervals (= time during which at least one engine
 // kernel was running), the right denominator for a whole-engine throughput.
-extern "C" int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches, double* flops, double* ms) {
-    g_trace_on = false;
+int gemm_trace_collect(EngineOpts& o, int cap, const char** names, int64_t* launches, double* flops, double* ms) {
+    o.trace_on = false;
+    auto& tr = o.trace;
     int n = 0;
     std::vector<std::pair<double, double>> iv;
     double fl_all = 0.0;
-    for (int i = 0; i < kNumCfgs && n < cap; ++i) {
+    bool ok = true;
+    for (int i = 0; i < kNumCfgs && n < cap && ok; ++i) {
         int64_t cnt = 0;
         double fl = 0.0, t = 0.0;
-        for (auto& r : g_trace) {
+        for (auto& r : tr) {
             if (r.cfg != i) continue;
-            if (hipEventSynchronize(r.e1) != hipSuccess) return -1;
             float dt = 0.f, t0 = 0.f;
-            if (hipEventElapsedTime(&dt, r.e0, r.e1) != hipSuccess) return -1;
-            if (hipEventElapsedTime(&t0, g_trace.front().e0, r.e0) != hipSuccess) return -1;
+            if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&dt, r.e0, r.e1) != hipSuccess ||
+                hipEventElapsedTime(&t0, tr.front().e0, r.e0) != hipSuccess) { ok = false; break; }
             iv.emplace_back((double)t0, (double)t0 + dt);
             ++cnt; fl += r.flops; t += dt;
         }
@@ -746,7 +738,7 @@ extern "C" int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches
         fl_all += fl;
         ++n;
     }
-    if (n < cap && !iv.empty()) {
+    if (ok && n < cap && !iv.empty()) {
         std::sort(iv.begin(), iv.end());
         double uni = 0.0, lo = iv[0].first, hi = iv[0].second;
         for (auto& x : iv) {
@@ -757,9 +749,9 @@ extern "C" int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches
         names[n] = "union"; launches[n] = (int64_t)iv.size(); flops[n] = fl_all; ms[n] = uni;
         ++n;
     }
-    for (auto& r : g_trace) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-    g_trace.clear();
-    return n;
+    for (auto& r : tr) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    tr.clear();
+    return ok ? n : -1;
 }
 
 // Tile choice, from tools/gemm_sweep.py on MI355X (profiles/r01_gemm_sweep_v3.txt).  Two regimes:
@@ -774,16 +766,14 @@ extern "C" int mt2_gemm_trace_end(int cap, const char** names, int64_t* launches
 //     CU at best, and a 4-wave tile then runs at the pace of ONE wave per SIMD: serial chain K/2 x 64 cycles
 //     plus an exposed barrier + DMA-issue + ds_read bubble per chunk (measured ~1 us per 32-wide chunk vs
 //     0.43 us of MFMA).  The K-split tiles put 2-4 waves on each SIMD of the same CU instead.
-static int g_t_ks4 = 256, g_t_ks2 = 640, g_t32 = 256, g_t32x32 = 256;   // thresholds in tiles, from tools/gemm_sweep.py
-extern "C" void mt2_debug_set_thresholds(int t_ks4, int t_ks2, int t32) { g_t_ks4 = t_ks4; g_t_ks2 = t_ks2; g_t32 = t32; }
-extern "C" void mt2_debug_set_t32x32(int t) { g_t32x32 = t; }
+// (the thresholds, in tiles, are EngineOpts::t_ks4 / t_ks2 / t32 / t32x32)
 
 // A CU retires one 64x64 tile of K=768 in ~12 us whatever the launch looks like, so for the AR-step shapes the
 // choice is about how many CUs get a tile and how many tiles the busiest CU gets (profiles/r01_gemm_sweep_ar_*):
 //   32x64 K-split tiles while they fit one per CU; 64x64 K-split tiles while THEY fit one (k4) / two (k2) per CU;
 //   a big 8-wave tile when its tile count just fills the chip once (200..256); otherwise plain 64x64 tiles
 //   (three workgroups per CU, de-phased) and the 8-wave tiles for the conv stacks and the vocoder.
-static const TileCfg* choose_cfg(const GemmP& p, int* idx_out) {
+static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_out) {
     int bi = 12;                                                        // dma64x64_2x2_s3
     const long long t32 = (long long)((p.M + 31) / 32) * ((p.N + 63) / 64) * p.groups;
     const long long t32x32 = (long long)((p.M + 31) / 32) * ((p.N + 31) / 32) * p.groups;
@@ -795,21 +785,23 @@ static const TileCfg* choose_cfg(const GemmP& p, int* idx_out) {
     else if (p.N <= 256 && t128 >= 400) bi = 17;                        // two n-tiles: 128x128 beats 256x128 (vocoder)
     else if (t256 >= 400 || (t256 >= 200 && t256 <= 256)) bi = 16;      // dma256x128_4x2_s3
     else if (t128 >= 400 || (t128 >= 200 && t128 <= 256)) bi = 17;      // dma128x128_4x2_s4
-    else if (t32x32 <= g_t32x32 && p.K >= 512) bi = 28;                 // dma32x32_1x1_k8_s2
-    else if (t32 <= g_t32) bi = 22;                                     // dma32x64_1x2_k4_s2
-    else if (t64 <= g_t_ks4) bi = 20;                                   // dma64x64_2x2_k4_s2
-    else if (t64 <= g_t_ks2) bi = 18;                                   // dma64x64_2x2_k2_s2
-    if (g_force_cfg >= 0 && g_force_cfg < kNumCfgs) bi = g_force_cfg;
+    else if (t32x32 <= o.t32x32 && p.K >= 512) bi = 28;                 // dma32x32_1x1_k8_s2
+    else if (t32 <= o.t32) bi = 22;                                     // dma32x64_1x2_k4_s2
+    else if (t64 <= o.t_ks4) bi = 20;                                   // dma64x64_2x2_k4_s2
+    else if (t64 <= o.t_ks2) bi = 18;                                   // dma64x64_2x2_k2_s2
+    if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;
     *idx_out = bi;
     return &kCfgs[bi];
 }
 
-hipError_t launch_gemm(const GemmP& p_in, hipStream_t s) {
+hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
+    static const EngineOpts kDefaults;
+    const EngineOpts& o = opts ? *opts : kDefaults;
     GemmP p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.groups <= 0) return hipSuccess;
     if ((p.Cin & 3) || (p.ldx & 3) || (p.ldw & 3) || p.K != p.taps * p.Cin) return hipErrorInvalidValue;
     int idx = 0;
-    const TileCfg* c = choose_cfg(p, &idx);
+    const TileCfg* c = choose_cfg(p, o, &idx);
     if (p.pro_act < 0 || p.pro_act > PRO_LN) return hipErrorInvalidValue;
     size_t lds = c->lds;
     if (p.pro_act == PRO_LN) {
@@ -817,7 +809,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s) {
         // Measured (C2 / C3, profiles/r01_lnfuse_ab.txt): the prologue costs ~2 us of row statistics plus ~30 % of the
         // K loop (12 VALU per 4 MFMAs, one more DMA piece) - a win only while a launch sits at its latency floor,
         // i.e. for the two smallest tile configurations; everything larger runs LN + GEMM as two launches.
-        if (g_force_cfg < 0 && idx != 28 && idx != 22) return hipErrorNotSupported;
+        if (o.force_cfg < 0 && idx != 28 && idx != 22) return hipErrorNotSupported;
         if (!c->fn[PRO_LN]) return hipErrorNotSupported;
         const int ks = c->threads / 64 / ((c->bm / 32) * (c->bn / 32));     // one 32x32 tile per wave
         lds = c->lds + (size_t)ks * 2 * 256 * sizeof(float) + (size_t)c->bm * 2 * sizeof(float);
@@ -831,8 +823,8 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s) {
     }
     const int tiles = ((p.M + c->bm - 1) / c->bm) * ((p.N + c->bn - 1) / c->bn);
     dim3 grid(tiles, 1, p.groups), block(c->threads);
-    g_last_cfg = c->name;
-    if (g_trace_on) {
+    if (opts) opts->last_cfg = c->name;
+    if (opts && opts->trace_on) {
         TraceRec r;
         r.cfg = idx;
         r.flops = 2.0 * p.M * p.N * p.K * p.groups;
@@ -840,7 +832,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s) {
         (void)hipEventRecord(r.e0, s);
         hipLaunchKernelGGL(fn, grid, block, lds, s, p);
         (void)hipEventRecord(r.e1, s);
-        g_trace.push_back(r);
+        opts->trace.push_back(r);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(fn, grid, block, lds, s, p);

@@ -32,6 +32,13 @@ Arena::~Arena() {
 void Arena::reset() {
     for (auto& c : chunks_) c.used = 0;
 }
+void Arena::reserve(size_t bytes) {
+    for (auto& c : chunks_)
+        if (c.size >= bytes) return;
+    char* p = nullptr;
+    MT2_HIP(hipMalloc(reinterpret_cast<void**>(&p), bytes));
+    chunks_.push_back({p, bytes, 0});
+}
 size_t Arena::capacity() const {
     size_t t = 0;
     for (auto& c : chunks_) t += c.size;
@@ -44,12 +51,38 @@ void* Arena::alloc(size_t bytes) {
         if (c.size - c.used >= bytes) {
             void* p = c.p + c.used;
             c.used += bytes;
+            size_t in_use = 0;
+            for (auto& d : chunks_) in_use += d.used;
+            if (in_use > high_) high_ = in_use;
             return p;
         }
     }
     size_t sz = bytes > (size_t(256) << 20) ? bytes : (size_t(256) << 20);
     char* p = nullptr;
     MT2_HIP(hipMalloc(reinterpret_cast<void**>(&p), sz));
+    chunks_.push_back({p, sz, bytes});
+    size_t in_use = 0;
+    for (auto& d : chunks_) in_use += d.used;
+    if (in_use > high_) high_ = in_use;
+    return p;
+}
+
+PinnedPool::~PinnedPool() {
+    for (auto& c : chunks_) (void)hipHostFree(c.p);
+    if (done) (void)hipEventDestroy(done);
+}
+void* PinnedPool::alloc(size_t bytes) {
+    bytes = (bytes + 63) & ~size_t(63);
+    if (bytes == 0) bytes = 64;
+    for (auto& c : chunks_)
+        if (c.size - c.used >= bytes) {
+            void* p = c.p + c.used;
+            c.used += bytes;
+            return p;
+        }
+    const size_t sz = bytes > (size_t(4) << 20) ? bytes : (size_t(4) << 20);
+    char* p = nullptr;
+    MT2_HIP(hipHostMalloc(reinterpret_cast<void**>(&p), sz, hipHostMallocDefault));
     chunks_.push_back({p, sz, bytes});
     return p;
 }
@@ -66,10 +99,12 @@ int IntPlan::add_fill(size_t n, int value) {
     h_.resize(h_.size() + n, value);
     return off;
 }
-void IntPlan::upload(Arena& a, hipStream_t s) {
+void IntPlan::upload(Arena& a, PinnedPool& pin, hipStream_t s) {
     if (h_.empty()) h_.push_back(0);
     d_ = a.get<int>(h_.size());
-    MT2_HIP(hipMemcpyAsync(d_, h_.data(), h_.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    void* stage = pin.alloc(h_.size() * sizeof(int));     // outlives this object: recycled two API calls later
+    std::memcpy(stage, h_.data(), h_.size() * sizeof(int));
+    MT2_HIP(hipMemcpyAsync(d_, stage, h_.size() * sizeof(int), hipMemcpyHostToDevice, s));
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -12,11 +12,10 @@
 
 namespace mt2 {
 
-static bool g_no_splitk = false;   // A/B switch: split-K through the LayerNorm
-// LayerNorm as a GEMM prologue in the AR layers (ln_linear).  OFF: measured slower than LN + GEMM as two launches at
-// every size (profiles/r01_lnfuse_ab.txt: C2 90.8 vs 89.8 ms even when restricted to the latency-floor launches,
-// 99.9 vs 89.4 ms when applied everywhere); mt2_debug_set_lnfuse(1) turns it on for A/B runs.
-static bool g_no_lnfuse = true;
+// Tuning switches (split-K through the LayerNorm, LayerNorm as a GEMM prologue, vocoder stream count, ...) live in
+// the handle: mt2_model::opts (mt2_kernels.h EngineOpts), set through mt2_set_option.  LayerNorm as a GEMM prologue
+// is OFF by default: measured slower than LN + GEMM as two launches at every size (profiles/r01_lnfuse_ab.txt: C2
+// 90.8 vs 89.8 ms even when restricted to the latency-floor launches, 99.9 vs 89.4 ms when applied everywhere).
 
 // ---------------------------------------------------------------------------------------------------
 // planning helpers
@@ -77,7 +76,7 @@ static void gemm(const Ctx& c, GemmP p) {
     if (p.out_scale == 0.0f) p.out_scale = 1.0f;
     p.K = p.taps * p.Cin;
     if (p.ldw == 0) p.ldw = p.K;
-    MT2_HIP(launch_gemm(p, c.s));
+    MT2_HIP(launch_gemm(p, c.s, &c.m.opts));
 }
 
 // y[M, N] = x[M, K] @ W^T + b  (F.linear)
@@ -100,8 +99,8 @@ static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, 
     p.X = x; p.ldx = ldx; p.Rx = Rx; p.a_mul = a_mul ? a_mul : 1; p.shift0 = shift0; p.taps = 1; p.dil = 1; p.Cin = K;
     p.K = K; p.W = W; p.ldw = K; p.bias = b; p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.groups = 1; p.out_scale = 1.0f;
     p.epi_act = epi_act; p.pro_act = 3; p.ln_g = lng; p.ln_b = lnb; p.ln_eps = 1e-5f;
-    if (!g_no_lnfuse && K <= 1024) {
-        const hipError_t e = launch_gemm(p, c.s);
+    if (c.m.opts.lnfuse && K <= 1024) {
+        const hipError_t e = launch_gemm(p, c.s, &c.m.opts);
         if (e == hipSuccess) return;
         if (e != hipErrorNotSupported) MT2_HIP(e);
     }
@@ -187,7 +186,6 @@ struct AttnGeom {
     int u_stride = 0, u_len = 0, B = 0, max_len = 0;
 };
 struct EncScratch { float *h, *qkv, *att, *f, *parts; };
-static int g_voc_streams = 3;   // resblock chains of a vocoder stage in flight (1 = serial)
 static EncScratch enc_scratch(const Ctx& c, const EncW& e, int M) {
     EncScratch s;
     s.h = c.ws.get<float>((size_t)M * e.d);
@@ -241,11 +239,11 @@ static void encoder_layer(const Ctx& c, const EncW& e, const EncLayerW& w, float
 struct Pending {              // a residual update not yet applied: x += bias + sum_g parts[g]
     const float* parts = nullptr; long long pstride = 0; int S = 0; const float* bias = nullptr;
 };
-static int choose_split(int M, int N, int K) {
-    if (g_no_splitk) return 1;
+static int choose_split(const Ctx& c, int M, int N, int K) {
+    if (!c.m.opts.splitk) return 1;
     // a split GEMM hands its reduction to a stand-alone LayerNorm launch, which the LayerNorm-prologue GEMM
     // (ln_linear) otherwise removes: worth it only for the long K chains (PLM ff.3, K = 4096)
-    if (!g_no_lnfuse && K < 2048) return 1;
+    if (c.m.opts.lnfuse && K < 2048) return 1;
     const long long tiles = (long long)((M + 31) / 32) * ((N + 63) / 64);
     int S = 1;
     while (S < 16 && tiles * (S * 2) <= 256 && K % (S * 2) == 0 && K / (S * 2) >= 256 && (K / (S * 2)) % 32 == 0) S *= 2;
@@ -273,7 +271,7 @@ static void ln_pending(const Ctx& c, float* x, int d, int M, const Pending& in, 
 static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int M, const float* att,
                              const EncScratch& s) {
     const int d = e.d;
-    const int S1 = choose_split(M, d, d);
+    const int S1 = choose_split(c, M, d, d);
     if (S1 > 1) {
         linear_splitk(c, att, d, M, w.wo, d, d, S1, s.parts);
         Pending p1{s.parts, (long long)M * d, S1, w.bo};
@@ -283,7 +281,7 @@ static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, fl
         linear(c, att, d, M, w.wo, w.bo, d, d, x, d, x, d);
         ln_linear(c, x, d, M, 1, 0, M, w.ln2g, w.ln2b, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, s.h, ACT_RELU);   // LN2 -> ff.0
     }
-    const int S2 = choose_split(M, d, e.ff);
+    const int S2 = choose_split(c, M, d, e.ff);
     if (S2 > 1) {
         linear_splitk(c, s.f, e.ff, M, w.ff1w, d, e.ff, S2, s.parts);
         return Pending{s.parts, (long long)M * d, S2, w.ff1b};
@@ -345,12 +343,20 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
 // stride (slot j owns rows [j*cs, j*cs + n)); every later step only adds row n-1.  Attention reads the
 // cache and writes compact rows; the rest of the layer is the ordinary full-row form.
 static Pending encoder_layer_first_cached(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int n, int A,
-                                          float* qkv_cache, int cs, const EncScratch& s) {
+                                          float* qkv_cache, int cs, const EncScratch& s, bool fill_all) {
     MT2_REQUIRE(!e.conv_ff, "AR step layers use the Linear feed-forward");
     const int d = e.d, M = A * n, D = d / e.heads;
-    // LN1 -> QKV of the newest row of every active sequence, written into the cache at row stride cs
-    ln_linear(c, x, d, M, n, n - 1, A, w.ln1g, w.ln1b, w.wqkv, w.bqkv, 3 * d, d,
-              qkv_cache + (size_t)(n - 1) * 3 * d, cs * 3 * d, s.h);
+    if (fill_all && n > 1) {
+        // first step of a run that starts from a forced history (prompt prefix, teacher-forced tests): the cache
+        // has no rows yet - LN1 -> QKV of ALL n rows, compact, then one strided copy into the cache layout
+        ln_linear(c, x, d, M, 1, 0, M, w.ln1g, w.ln1b, w.wqkv, w.bqkv, 3 * d, d, s.qkv, 3 * d, s.h);
+        MT2_HIP(launch_copy_2d(s.qkv, (long long)n * 3 * d, qkv_cache, (long long)cs * 3 * d, (long long)n * 3 * d, A,
+                               c.s));
+    } else {
+        // LN1 -> QKV of the newest row of every active sequence, written into the cache at row stride cs
+        ln_linear(c, x, d, M, n, n - 1, A, w.ln1g, w.ln1b, w.wqkv, w.bqkv, 3 * d, d,
+                  qkv_cache + (size_t)(n - 1) * 3 * d, cs * 3 * d, s.h);
+    }
     AttnP a{};
     a.Q = qkv_cache; a.ldq = 3 * d; a.K = qkv_cache + d; a.ldk = 3 * d; a.V = qkv_cache + 2 * d; a.ldv = 3 * d;
     a.O = s.att; a.ldo = d;
@@ -363,14 +369,14 @@ static Pending encoder_layer_first_cached(const Ctx& c, const EncW& e, const Enc
 // One AR step of an encoder over A sequences of n positions (x: [A*n, d], overwritten); the rows the head
 // needs (position n-1 of each sequence) are returned as a [A, d] matrix.
 static const float* ar_step_layers(const Ctx& c, const EncW& e, float* x, int n, int A, float* qkv_cache, int cs,
-                                   const EncScratch& sc, float* ylast) {
+                                   const EncScratch& sc, float* ylast, bool fill_cache = false) {
     const int L = (int)e.layers.size();
     AttnGeom g;
     g.u_stride = n; g.u_len = n; g.B = A; g.max_len = n;
     Pending pend;
     for (int l = 0; l < L; ++l) {
         if (l == L - 1) encoder_layer_last(c, e, e.layers[l], x, n, A, sc, ylast, pend);
-        else if (l == 0 && qkv_cache) pend = encoder_layer_first_cached(c, e, e.layers[l], x, n, A, qkv_cache, cs, sc);
+        else if (l == 0 && qkv_cache) pend = encoder_layer_first_cached(c, e, e.layers[l], x, n, A, qkv_cache, cs, sc, fill_cache);
         else pend = encoder_layer_ar(c, e, e.layers[l], x, A * n, g, sc, pend);
     }
     return ylast;
@@ -385,7 +391,12 @@ struct Stages {
     std::vector<hipEvent_t> ev;
     std::vector<std::string> names;
     explicit Stages(mt2_model& mm, hipStream_t ss) : m(mm), s(ss) {}
+    // marker ids (tools/pmc_stage_summary.py): 0 start, 1 mrte, 2 adm, 3 regulate, 4 plm, 5 decoder, 6 vocoder,
+    // 8 / 9 around mt2_vqpe_forward
+    int nmark = 0;
     void mark(const char* name) {
+        if (m.opts.markers) MT2_HIP(launch_stage_marker(nmark, s));
+        ++nmark;
         if (!m.profiling) return;
         hipEvent_t e;
         MT2_HIP(hipEventCreate(&e));
@@ -484,10 +495,41 @@ static void ensure_aux(mt2_model& m, int n_streams) {
     }
 }
 
+// Range check of caller-supplied indices BEFORE they are used as gather offsets: the reference raises IndexError
+// from nn.Embedding / F.embedding (modules/embedding.py:43-47, core_vq.py:188-190); here an out-of-range id would
+// read HBM out of bounds.  One tiny kernel per id tensor ORs a bit into a device flag; ids_finish copies the flag
+// to the host and synchronises the stream ONCE per API call (the call has enqueued nothing else yet).
+enum IdBit { ID_PHONE = 1, ID_CODE = 2, ID_PREFIX = 4 };
+struct IdCheck { int* flag = nullptr; };
+static IdCheck ids_begin(const Ctx& c) {
+    IdCheck k;
+    k.flag = c.ws.get<int>(4);
+    MT2_HIP(hipMemsetAsync(k.flag, 0, 4 * sizeof(int), c.s));
+    return k;
+}
+static void ids_check(const Ctx& c, const IdCheck& k, const int64_t* ids, const int* map, long long R, long long hi,
+                      int bit) {
+    MT2_REQUIRE(R < (1ll << 31), "id tensor too large");
+    MT2_HIP(launch_check_ids(ids, map, (int)R, hi, k.flag, bit, c.s));
+}
+static void ids_finish(const Ctx& c, const IdCheck& k) {
+    int* h = static_cast<int*>(c.m.pinned().alloc(sizeof(int)));
+    *h = 0;
+    MT2_HIP(hipMemcpyAsync(h, k.flag, sizeof(int), hipMemcpyDeviceToHost, c.s));
+    MT2_HIP(hipStreamSynchronize(c.s));
+    if (*h == 0) return;
+    std::string what = "index out of range in embedding lookup:";
+    if (*h & ID_PHONE) what += " phone id >= phone_vocab_size (or negative);";
+    if (*h & ID_CODE) what += " prosody code >= vq_bins (or negative);";
+    if (*h & ID_PREFIX) what += " prompt prosody code >= vq_bins + 2 (or negative);";
+    throw Error(what);
+}
+
 // MRTE.tc_latent (modules/mrte.py:154-171) -> packed rows [P.R, hidden] (gap rows zero)
 struct TcResult { float* rows; RowSet P; };
 static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* phone_lens, int Np_max,
-                               const float* mel, const int* mel_lens, int Tp_max, int B) {
+                               const float* mel, const int* mel_lens, int Tp_max, int B,
+                               const IdCheck* pending = nullptr) {
     mt2_model& m = c.m;
     const mt2_config& cfg = m.cfg;
     const int H = cfg.mrte_hidden;
@@ -503,10 +545,15 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
         for (int t = 0; t < P.len[b]; ++t) pos[P.off[b] + t] = t;
     }
     const int o_pos = ip.add(pos);
-    ip.upload(c.ws, c.s);
+    ip.upload(c.ws, c.m.pinned(), c.s);
     bind_rows(ip, mp.oF, mp.F);
     bind_rows(ip, mp.oX, mp.X);
     bind_rows(ip, oP, P);
+    {   // phone ids index the embedding table: check them (and whatever the caller queued) before anything runs
+        const IdCheck k = pending ? *pending : ids_begin(c);
+        ids_check(c, k, phone, ip.dev(o_idmap), P.R, cfg.phone_vocab, ID_PHONE);
+        ids_finish(c, k);
+    }
 
     // The phone branch (embedding, conv-FF transformer, query projection: ~60 small launches) does not depend on
     // the mel encoder: it runs on a side stream and fills the CUs the mel stack's big launches leave idle
@@ -603,15 +650,26 @@ static void ar_join(mt2_model& m, const ArGroups& g) {
     }
 }
 
+// A run may start from a FORCED history of P positions per sequence (uniform P): the PLM's prompt prefix (SURVEY 8f
+// row f1: the layout the PLM is trained on, modules/datamodule.py:201-212) and the teacher-forced single steps of
+// the long-shape parity tests.  The loop then starts at t = P and runs `max_steps` steps (0 = to the end).
+struct ArPrefix {
+    int P = 0;
+    const void* data = nullptr;   // ADM: float [B, P] un-rounded predictions; PLM: int64 [B, P] prosody codes
+    int max_steps = 0;
+};
+
 // MegaADM.infer (models/megatts2.py:257-275).  tc: rows buffer (ld), utterance b's first row row0[b].
 static void adm_run(const Ctx& c, const float* tc, int ld_tc, int tc_rows, const std::vector<int>& row0,
-                    const int* lens, int B, int32_t* dur_out, float* flt_out, int dstride) {
+                    const int* lens, int B, int32_t* dur_out, float* flt_out, int dstride,
+                    const ArPrefix& pre = ArPrefix()) {
     mt2_model& m = c.m;
     const mt2_config& cfg = m.cfg;
     const EncW& e = m.adm_enc;
     const int d = e.d, Dc = cfg.adm_tc_emb_dim, De = cfg.adm_emb_dim;
     ArOrder ord = ar_order(lens, B);
     MT2_REQUIRE(ord.nmax <= cfg.max_positions, "ADM sequence longer than the positional table");
+    for (int b = 0; b < B; ++b) MT2_REQUIRE(lens[b] > pre.P, "forced history is not shorter than the sequence");
     ArGroups grp = ar_groups(m, c.s, ord, B);
     struct Grp {
         int B, nmax, A; int o_tcrow, o_len, o_slot;
@@ -633,25 +691,28 @@ static void adm_run(const Ctx& c, const float* tc, int ld_tc, int tc_rows, const
         q.A = q.B;
         q.o_tcrow = ip.add(tcrow); q.o_len = ip.add(q.len); q.o_slot = ip.add(slot);
     }
-    ip.upload(c.ws, c.s);
+    ip.upload(c.ws, c.m.pinned(), c.s);
 
     float* tcemb = c.ws.get<float>((size_t)tc_rows * Dc);
     linear(c, tc, ld_tc, tc_rows, m.adm_wtc, nullptr, Dc, cfg.adm_tc_dim, tcemb, Dc);   // tc_linear_emb (no bias)
     const int pstride = ord.nmax + 1;
     float* p_all = c.ws.get<float>((size_t)B * pstride);
-    MT2_HIP(hipMemsetAsync(p_all, 0, sizeof(float) * B * pstride, c.s));                // p_code starts at 0.0 (:262)
     int pofs = 0;
     for (Grp& q : gs) {
         const int Mmax = q.B * q.nmax;
         q.p = p_all + (size_t)pofs * pstride;
         pofs += q.B;
+        // p_code starts at 0.0 (:262), followed by the forced history if any
+        MT2_HIP(launch_adm_init_hist(q.p, pstride, static_cast<const float*>(pre.data), pre.P, ip.dev(q.o_slot), q.B,
+                                     c.s));
         q.x = c.ws.get<float>((size_t)Mmax * d);
         q.sc = enc_scratch(c, e, std::max(Mmax, 2 * q.B));   // last layer: q | att rows of A sequences
         q.ylast = c.ws.get<float>((size_t)q.B * d);
         q.qkv0 = e.layers.size() >= 2 ? c.ws.get<float>((size_t)Mmax * 3 * d) : nullptr;   // layer-0 QKV cache
     }
     ar_fork(m, grp);
-    for (int t = 0; t < ord.nmax; ++t) {
+    const int t_end = pre.max_steps > 0 ? std::min(ord.nmax, pre.P + pre.max_steps) : ord.nmax;
+    for (int t = pre.P; t < t_end; ++t) {
         const int n = t + 1;
         for (int g = 0; g < grp.G; ++g) {
             Grp& q = gs[g];
@@ -660,7 +721,7 @@ static void adm_run(const Ctx& c, const float* tc, int ld_tc, int tc_rows, const
             Ctx cg{m, grp.stream[g], c.ws};
             MT2_HIP(launch_adm_step_input(tcemb, Dc, ip.dev(q.o_tcrow), m.adm_wdt, q.p, pstride, m.pe_adm, q.x, Dc, De,
                                           n, q.A, cg.s));
-            const float* y = ar_step_layers(cg, e, q.x, n, q.A, q.qkv0, q.nmax, q.sc, q.ylast);
+            const float* y = ar_step_layers(cg, e, q.x, n, q.A, q.qkv0, q.nmax, q.sc, q.ylast, t == pre.P && pre.P > 0);
             MT2_HIP(launch_adm_predict(y, d, m.adm_wpred, q.p, pstride, n, 1, q.A, cg.s));
         }
     }
@@ -672,9 +733,11 @@ static void adm_run(const Ctx& c, const float* tc, int ld_tc, int tc_rows, const
     ar_join(m, grp);
 }
 
-// MegaPLM.infer (models/megatts2.py:165-181).  cond rows buffer (ld), utterance b's first row row0[b].
+// MegaPLM.infer (models/megatts2.py:165-181).  cond rows buffer (ld), utterance b's first row row0[b]; lens[b] =
+// ALL positions of the sequence (prompt prefix + target); codes_out / last_logits receive the target positions.
 static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector<int>& row0, const int* lens, int B,
-                    int64_t* codes_out, int ostride, float* last_logits, int logit_tmax) {
+                    int64_t* codes_out, int ostride, float* last_logits, int logit_tmax,
+                    const ArPrefix& pre = ArPrefix()) {
     mt2_model& m = c.m;
     const mt2_config& cfg = m.cfg;
     const EncW& e = m.plm_enc;
@@ -682,6 +745,7 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
     ArOrder ord = ar_order(lens, B);
     MT2_REQUIRE(ord.nmax <= cfg.max_positions, "PLM sequence longer than the positional table");
     MT2_REQUIRE(1024 < cfg.plm_bins + 2, "pc_embedding too small for the BOS id 1024");
+    for (int b = 0; b < B; ++b) MT2_REQUIRE(lens[b] > pre.P, "prompt prefix is not shorter than the sequence");
     ArGroups grp = ar_groups(m, c.s, ord, B);
     struct Grp {
         int B, nmax, A; int o_crow, o_len, o_slot;
@@ -703,21 +767,18 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
         q.A = q.B;
         q.o_crow = ip.add(crow); q.o_len = ip.add(q.len); q.o_slot = ip.add(q.slot);
     }
-    ip.upload(c.ws, c.s);
+    ip.upload(c.ws, c.m.pinned(), c.s);
 
     const int cstride = ord.nmax + 1;
     int64_t* codes_all = c.ws.get<int64_t>((size_t)B * cstride);
-    {
-        std::vector<int64_t> init((size_t)B * cstride, 0);
-        for (int j = 0; j < B; ++j) init[(size_t)j * cstride] = 1024;   // BOS literal, models/megatts2.py:170
-        MT2_HIP(hipMemcpyAsync(codes_all, init.data(), init.size() * sizeof(int64_t), hipMemcpyHostToDevice, c.s));
-        MT2_HIP(hipStreamSynchronize(c.s));   // `init` is a stack temporary
-    }
     int cofs = 0;
     for (Grp& q : gs) {
         const int Mmax = q.B * q.nmax;
         q.codes = codes_all + (size_t)cofs * cstride;
         cofs += q.B;
+        // BOS literal 1024 (models/megatts2.py:170), then the prompt's codes if any - on the device, no host staging
+        MT2_HIP(launch_plm_init_hist(q.codes, cstride, 1024, static_cast<const int64_t*>(pre.data), pre.P,
+                                     ip.dev(q.o_slot), q.B, c.s));
         q.x = c.ws.get<float>((size_t)Mmax * d);
         q.logits = c.ws.get<float>((size_t)q.B * NB);
         q.sc = enc_scratch(c, e, std::max(Mmax, 2 * q.B));   // last layer: q | att rows of A sequences
@@ -725,7 +786,8 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
         q.qkv0 = e.layers.size() >= 2 ? c.ws.get<float>((size_t)Mmax * 3 * d) : nullptr;   // layer-0 QKV cache
     }
     ar_fork(m, grp);
-    for (int t = 0; t < ord.nmax; ++t) {
+    const int t_end = pre.max_steps > 0 ? std::min(ord.nmax, pre.P + pre.max_steps) : ord.nmax;
+    for (int t = pre.P; t < t_end; ++t) {
         const int n = t + 1;
         for (int g = 0; g < grp.G; ++g) {
             Grp& q = gs[g];
@@ -734,24 +796,25 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
             Ctx cg{m, grp.stream[g], c.ws};
             MT2_HIP(launch_plm_step_input(cond, ld_c, ip.dev(q.o_crow), m.plm_emb, q.codes, cstride, m.pe_plm, q.x, Dc,
                                           De, n, q.A, cg.s));
-            const float* y = ar_step_layers(cg, e, q.x, n, q.A, q.qkv0, q.nmax, q.sc, q.ylast);
+            const float* y = ar_step_layers(cg, e, q.x, n, q.A, q.qkv0, q.nmax, q.sc, q.ylast, t == pre.P && pre.P > 0);
             // predict_layer on the last position of each sequence only (:178 takes [:, -1:]), then argmax
             GemmP p{};
             p.X = y; p.ldx = d; p.Rx = q.A; p.Cin = d; p.W = m.plm_wpred;
             p.C = q.logits; p.ldc = NB; p.M = q.A; p.N = NB;
             gemm(cg, p);
             MT2_HIP(launch_argmax_rows(q.logits, NB, NB, q.codes, cstride, n, q.A, cg.s));
-            if (last_logits)
+            if (last_logits && t - pre.P < logit_tmax)
                 for (int j = 0; j < q.A; ++j)
-                    MT2_HIP(hipMemcpyAsync(last_logits + ((size_t)q.slot[j] * logit_tmax + t) * NB,
+                    MT2_HIP(hipMemcpyAsync(last_logits + ((size_t)q.slot[j] * logit_tmax + (t - pre.P)) * NB,
                                            q.logits + (size_t)j * NB, sizeof(float) * NB, hipMemcpyDeviceToDevice,
                                            cg.s));
         }
     }
     for (int g = 0; g < grp.G; ++g) {
         Grp& q = gs[g];
+        const int nt = q.nmax - pre.P;
         MT2_HIP(launch_plm_finalize(q.codes, cstride, ip.dev(q.o_len), ip.dev(q.o_slot), codes_out, ostride, q.B,
-                                    ostride < q.nmax ? ostride : q.nmax, grp.stream[g]));
+                                    ostride < nt ? ostride : nt, pre.P, grp.stream[g]));
     }
     ar_join(m, grp);
 }
@@ -855,7 +918,7 @@ static VqpeResult vqpe_rows(const Ctx& c, IntPlan& ip, const float* mel, int mel
     }
     const int o_first = ip.add(first), o_cnt = ip.add(cnt);
     r.o_codemapF = ip.add(codemap);
-    ip.upload(c.ws, c.s);
+    ip.upload(c.ws, c.m.pinned(), c.s);
     bind_rows(ip, oF, r.F);
     bind_rows(ip, oQ, r.Q);
 
@@ -925,7 +988,7 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
         const size_t per = (size_t)R * ch;
         float* rb[3] = {nullptr, nullptr, nullptr};
         MT2_REQUIRE(cfg.hg_n_res == 3, "HiFi-GAN V1 uses three resblocks per stage");
-        const int nside = g_voc_streams > 1 ? 2 : 0;
+        const int nside = m.opts.voc_streams > 1 ? 2 : 0;
         ensure_aux(m, nside);
         if (nside) {
             MT2_HIP(hipEventRecord(m.ev_fork, c.s));
@@ -1038,7 +1101,7 @@ static void mel_spectrogram_run(const Ctx& c, const mt2_audio_config& ac, const 
     IntPlan ip;
     const int o_b = ip.add(blk_b), o_t = ip.add(blk_t), o_len = ip.add(len), o_base = ip.add(rowbase),
               o_map = ip.add(rowmap);
-    ip.upload(c.ws, c.s);
+    ip.upload(c.ws, c.m.pinned(), c.s);
     float* xp = c.ws.get<float>((size_t)Rb * hop);
     MT2_HIP(launch_reflect_pad_blocks(wav, L_max, ip.dev(o_b), ip.dev(o_t), ip.dev(o_len), hop, pad, xp, Rb, c.s));
     const int lds = (2 * F + 3) & ~3;

@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace mt2 {
 
 constexpr int kInvalidRow = -(1 << 30);   // rowbase sentinel: "this A row is all zeros"
@@ -38,8 +40,28 @@ struct GemmP {
     // it would choose has no such variant (big tiles) - callers then run launch_layernorm + a plain GEMM.
     const float* ln_g; const float* ln_b; float ln_eps;
 };
-hipError_t launch_gemm(const GemmP& p, hipStream_t s);
-const char* gemm_last_config();     // name of the tile configuration the last launch used
+// Tuning / measurement switches of the engine.  They live in the model handle (mt2_model::opts) or in a local
+// object of a kernel-level entry point - never in process globals: two handles (or two threads) do not see each
+// other's settings.  The defaults are what the product path runs.
+struct TraceRec { int cfg; double flops; hipEvent_t e0, e1; };
+struct EngineOpts {
+    int force_cfg = -1;                                    // >= 0: tile configuration index for every GEMM launch
+    int t_ks4 = 256, t_ks2 = 640, t32 = 256, t32x32 = 256; // tile-choice thresholds in tiles (tools/gemm_sweep.py)
+    bool splitk = true;          // split-K through the LayerNorm in the AR layers
+    bool lnfuse = false;         // LayerNorm as a GEMM prologue in the AR layers (measured slower, profiles/r01_lnfuse_ab.txt)
+    int voc_streams = 3;         // resblock chains of a vocoder stage in flight (1 = serial)
+    bool voc_fused = true;       // fused LDS-resident resblock kernel for the narrow vocoder stages (hifigan_fused.hip)
+    bool markers = false;        // a named no-op kernel at every stage boundary: lets tools/pmc_stage_summary.py attribute
+                                 // the rocprofv3 --pmc rows of one step to stages (measurement only)
+    bool trace_on = false;       // HIP events around every GEMM launch (measurement only)
+    std::vector<TraceRec> trace;
+    const char* last_cfg = "";   // name of the tile configuration the last launch used
+};
+hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
+int gemm_num_configs();
+const char* gemm_config_name(int idx);
+// per tile configuration: launches, executed FLOPs, summed ms; last entry "union" (see gemm_f32.hip); -1 on error
+int gemm_trace_collect(EngineOpts& o, int cap, const char** names, int64_t* launches, double* flops, double* ms);
 
 // Row LayerNorm over C channels (biased variance, eps inside the sqrt), one wave per row:
 //   out[m, :] = mask_m * ( act( LN(x[m, :]) * gamma[g] + beta[g] ) + R1[m, :] + R2[m, :] )
@@ -119,8 +141,22 @@ hipError_t launch_adm_predict(const float* x, int D, const float* w, float* p, i
 // dur[i] = clamp(trunc(p + 0.5), 1, 128)  (models/megatts2.py:275)
 hipError_t launch_adm_finalize(const float* p, int pstride, const int* lens, const int* slot_b, int32_t* dur,
                                float* flt, int dstride, int A, int nmax, hipStream_t s);
+// out[slot_b[j]*ostride + t] = codes[j*cstride + 1 + skip + t] for t < lens[j] - skip (skip = prompt prefix length)
 hipError_t launch_plm_finalize(const int64_t* codes, int cstride, const int* lens, const int* slot_b, int64_t* out,
-                               int ostride, int A, int nmax, hipStream_t s);
+                               int ostride, int A, int nmax, int skip, hipStream_t s);
+// AR history initialisation (one launch instead of a host-staged copy):
+//   ADM  p[j*pstride + 0] = 0 (models/megatts2.py:262), p[j*pstride + 1 + i] = prefix[slot_b[j]*P + i], rest 0
+//   PLM  codes[j*cstride + 0] = bos (:170), codes[j*cstride + 1 + i] = prefix[slot_b[j]*P + i], rest 0
+hipError_t launch_adm_init_hist(float* p, int pstride, const float* prefix, int P, const int* slot_b, int A,
+                                hipStream_t s);
+hipError_t launch_plm_init_hist(int64_t* codes, int cstride, int64_t bos, const int64_t* prefix, int P,
+                                const int* slot_b, int A, hipStream_t s);
+// flag |= bit when an id used by the call is outside [0, hi): ids[map[r]] for map[r] >= 0 (map == nullptr: ids[r])
+hipError_t launch_check_ids(const int64_t* ids, const int* map, int R, long long hi, int* flag, int bit,
+                            hipStream_t s);
+// dst[j*dpitch + c] = src[j*spitch + c], c < width, j < rows (float4 granularity)
+hipError_t launch_copy_2d(const float* src, long long spitch, float* dst, long long dpitch, long long width, int rows,
+                          hipStream_t s);
 hipError_t launch_scatter_i64(const int64_t* src, const int* map, int64_t* out, int R, hipStream_t s);
 hipError_t launch_expand_mask(const int* in, int factor, int* out, long long n, hipStream_t s);
 hipError_t launch_unpack_wav(const float* src, const long long* start, const long long* len, float* out,
@@ -145,5 +181,7 @@ hipError_t launch_reflect_pad_blocks(const float* wav, long long wstride, const 
                                      const int* len, int hop, int pad, float* out, int R, hipStream_t s);
 hipError_t launch_magnitude(const float* spec, int lds_, int F, float* out, int ldo, int M, hipStream_t s);
 hipError_t launch_tanh_col(const float* x, int ldx, float* out, long long n, hipStream_t s);
+// no-op kernel named mt2::stage_marker_kernel<ID> (ID 0..15): stage boundary in a kernel trace
+hipError_t launch_stage_marker(int id, hipStream_t s);
 
 }  // namespace mt2

@@ -5,6 +5,7 @@
 #include "mt2_kernels.h"
 
 #include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -31,6 +32,26 @@ class Arena {
     void* alloc(size_t bytes);
     template <class T> T* get(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
     size_t capacity() const;
+    size_t high_water() const { return high_; }      // most bytes in use at once since construction
+    void reserve(size_t bytes);                      // make sure one chunk of at least `bytes` exists
+
+  private:
+    struct Chunk { char* p; size_t size, used; };
+    std::vector<Chunk> chunks_;
+    size_t high_ = 0;
+};
+
+// Host staging for H2D copies of small plans: PINNED memory owned by the handle.  hipMemcpyAsync from a pageable
+// std::vector that dies before the stream reaches the copy is a use-after-free waiting to happen; everything the
+// hot path uploads is first copied here.  Two pools alternate between API calls; a pool is recycled only after
+// the event recorded at the end of the call that last used it has completed (bounds host run-ahead to 2 calls).
+class PinnedPool {
+  public:
+    ~PinnedPool();
+    void* alloc(size_t bytes);
+    void reset() { for (auto& c : chunks_) c.used = 0; }
+    hipEvent_t done = nullptr;
+    bool recorded = false;
 
   private:
     struct Chunk { char* p; size_t size, used; };
@@ -57,7 +78,7 @@ class IntPlan {
     int add(const std::vector<int>& v);
     int add_fill(size_t n, int value);
     std::vector<int>& host() { return h_; }
-    void upload(Arena& a, hipStream_t s);
+    void upload(Arena& a, PinnedPool& pin, hipStream_t s);
     const int* dev(int offset) const { return d_ + offset; }
 
   private:
@@ -123,6 +144,18 @@ struct mt2_model {
     mt2::ConvW hg_pre, hg_post;
     std::vector<mt2::UpW> hg_up;
     std::vector<mt2::ResW> hg_res;
+
+    // one API call at a time per handle (the handle owns the activation arena): calls from several host threads
+    // are serialised here; calls on different streams are ordered by `ev_call_end` (capi.inc, CallScope)
+    std::mutex call_mutex;
+    mt2::PinnedPool pin[2];
+    int pin_idx = 0;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev_call_end = nullptr;
+    bool call_pending = false;
+    mt2::PinnedPool& pinned() { return pin[pin_idx]; }
+
+    mt2::EngineOpts opts;     // tuning / measurement switches of THIS handle (no process globals)
 
     // AR stream groups (model_stages.hip): sequences are split into `ar_groups` independent kernel chains
     int ar_groups = 2;

@@ -480,20 +480,91 @@ hipError_t launch_adm_finalize(const float* p, int pstride, const int* lens, con
     return hipGetLastError();
 }
 
-// codes_out[slot_b[j]*ostride + t] = codes[j*cstride + 1 + t] for t < lens[j], else 0
+// codes_out[slot_b[j]*ostride + t] = codes[j*cstride + 1 + skip + t] for t < lens[j] - skip, else 0
 __global__ void plm_finalize_kernel(const int64_t* codes, int cstride, const int* lens, const int* slot_b,
-                                    int64_t* out, int ostride, int A, int nmax) {
+                                    int64_t* out, int ostride, int A, int nmax, int skip) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A * nmax) return;
     const int j = i / nmax, t = i % nmax;
     const int b = slot_b ? slot_b[j] : j;
-    out[(long long)b * ostride + t] = t < lens[j] ? codes[(long long)j * cstride + 1 + t] : 0;
+    out[(long long)b * ostride + t] = t < lens[j] - skip ? codes[(long long)j * cstride + 1 + skip + t] : 0;
 }
 hipError_t launch_plm_finalize(const int64_t* codes, int cstride, const int* lens, const int* slot_b, int64_t* out,
-                               int ostride, int A, int nmax, hipStream_t s) {
+                               int ostride, int A, int nmax, int skip, hipStream_t s) {
     if (A * nmax <= 0) return hipSuccess;
     hipLaunchKernelGGL(plm_finalize_kernel, dim3((A * nmax + 255) / 256), dim3(256), 0, s, codes, cstride, lens,
-                       slot_b, out, ostride, A, nmax);
+                       slot_b, out, ostride, A, nmax, skip);
+    return hipGetLastError();
+}
+
+// AR history initialisation (see mt2_kernels.h)
+__global__ void adm_init_hist_kernel(float* p, int pstride, const float* prefix, int P, const int* slot_b, int A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A * pstride) return;
+    const int j = i / pstride, t = i % pstride;
+    float v = 0.0f;
+    if (t >= 1 && t <= P) v = prefix[(long long)(slot_b ? slot_b[j] : j) * P + (t - 1)];
+    p[i] = v;
+}
+hipError_t launch_adm_init_hist(float* p, int pstride, const float* prefix, int P, const int* slot_b, int A,
+                                hipStream_t s) {
+    if (A * pstride <= 0) return hipSuccess;
+    hipLaunchKernelGGL(adm_init_hist_kernel, dim3((A * pstride + 255) / 256), dim3(256), 0, s, p, pstride, prefix, P,
+                       slot_b, A);
+    return hipGetLastError();
+}
+__global__ void plm_init_hist_kernel(int64_t* codes, int cstride, int64_t bos, const int64_t* prefix, int P,
+                                     const int* slot_b, int A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A * cstride) return;
+    const int j = i / cstride, t = i % cstride;
+    int64_t v = 0;
+    if (t == 0) v = bos;
+    else if (t <= P) v = prefix[(long long)(slot_b ? slot_b[j] : j) * P + (t - 1)];
+    codes[i] = v;
+}
+hipError_t launch_plm_init_hist(int64_t* codes, int cstride, int64_t bos, const int64_t* prefix, int P,
+                                const int* slot_b, int A, hipStream_t s) {
+    if (A * cstride <= 0) return hipSuccess;
+    hipLaunchKernelGGL(plm_init_hist_kernel, dim3((A * cstride + 255) / 256), dim3(256), 0, s, codes, cstride, bos,
+                       prefix, P, slot_b, A);
+    return hipGetLastError();
+}
+
+// Range check of caller-supplied ids before they are used as gather indices (nn.Embedding / F.embedding raise
+// IndexError in the reference, modules/embedding.py:43-47, core_vq.py:188-190): flag |= bit on any id outside [0, hi).
+__global__ void check_ids_kernel(const int64_t* ids, const int* map, int R, long long hi, int* flag, int bit) {
+    bool bad = false;
+    for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (long long)gridDim.x * blockDim.x) {
+        const int src = map ? map[r] : (int)r;
+        if (src < 0) continue;
+        const long long v = ids[src];
+        bad |= v < 0 || v >= hi;
+    }
+    if (bad) atomicOr(flag, bit);
+}
+hipError_t launch_check_ids(const int64_t* ids, const int* map, int R, long long hi, int* flag, int bit,
+                            hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(check_ids_kernel, row_grid(R), dim3(256), 0, s, ids, map, R, hi, flag, bit);
+    return hipGetLastError();
+}
+
+__global__ void copy_2d_kernel(const float* src, long long spitch, float* dst, long long dpitch, long long w4,
+                               int rows) {
+    const long long total = w4 * rows;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long j = i / w4, c = (i % w4) * 4;
+        *reinterpret_cast<float4*>(dst + j * dpitch + c) = *reinterpret_cast<const float4*>(src + j * spitch + c);
+    }
+}
+hipError_t launch_copy_2d(const float* src, long long spitch, float* dst, long long dpitch, long long width, int rows,
+                          hipStream_t s) {
+    if (rows <= 0 || width <= 0) return hipSuccess;
+    if ((width & 3) || (spitch & 3) || (dpitch & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(copy_2d_kernel, row_grid((width >> 2) * rows), dim3(256), 0, s, src, spitch, dst, dpitch,
+                       width >> 2, rows);
     return hipGetLastError();
 }
 
@@ -719,6 +790,19 @@ __global__ void magnitude_kernel(const float* spec, int lds_, int F, float* out,
 hipError_t launch_magnitude(const float* spec, int lds_, int F, float* out, int ldo, int M, hipStream_t s) {
     if (M <= 0) return hipSuccess;
     hipLaunchKernelGGL(magnitude_kernel, row_grid((long long)M * ldo), dim3(256), 0, s, spec, lds_, F, out, ldo, M);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage boundary markers for kernel traces (measurement only; EngineOpts::markers)
+template <int ID> __global__ void stage_marker_kernel() {}
+hipError_t launch_stage_marker(int id, hipStream_t s) {
+    switch (id & 15) {
+#define MT2_MARK(I) case I: hipLaunchKernelGGL(stage_marker_kernel<I>, dim3(1), dim3(64), 0, s); break;
+        MT2_MARK(0) MT2_MARK(1) MT2_MARK(2) MT2_MARK(3) MT2_MARK(4) MT2_MARK(5) MT2_MARK(6) MT2_MARK(7)
+        MT2_MARK(8) MT2_MARK(9) MT2_MARK(10) MT2_MARK(11) MT2_MARK(12) MT2_MARK(13) MT2_MARK(14) MT2_MARK(15)
+#undef MT2_MARK
+    }
     return hipGetLastError();
 }
 

@@ -4,7 +4,8 @@ exchange at the end (RCCL all-gather of generated mels over xGMI).
 The reference has no inference-time distribution at all (single process, batch 1); utterances are
 fully independent, so the path shards with NO data-path collective - the all-gather only returns
 every rank's mels to every rank as BASELINE.json's north_star asks.  Payloads are tiny (B=32 x 431 x
-80 f32 = 4.4 MB per rank): latency-bound, one `all_gather` per tensor, no hand-rolled ring.
+80 f32 = 4.4 MB per rank): latency-bound, ONE fixed-capacity `all_gather_into_tensor` per step (mel block,
+lengths and the local count travel in the same buffer), no hand-rolled ring, no host round trip.
 
 Works on any torch.distributed backend: "nccl" (= RCCL on ROCm) with device tensors on the GPU box,
 "gloo" with CPU tensors in the world_size-2 CPU tests.
@@ -39,50 +40,96 @@ def shard_utterances(costs: Sequence[float], world: int) -> List[List[int]]:
     return [sorted(s) for s in shards]
 
 
-def gather_mels(mel, lens) -> Tuple["object", np.ndarray]:
-    """mel [B_local, T_cap, C] (device or CPU tensor), lens [B_local] -> (mel_all [sum B, T_cap_max, C],
-    lens_all) in rank order, on every rank.  Ranks may hold different B_local / T_cap."""
+def _all_gather_flat(buf):
+    """One collective: every rank contributes an equally sized 1-D buffer -> [world, n]."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    out = torch.empty(world * buf.numel(), device=buf.device, dtype=buf.dtype)
+    try:
+        dist.all_gather_into_tensor(out, buf)            # ncclAllGather on RCCL: one ring pass over xGMI
+    except (RuntimeError, NotImplementedError):          # backend without the flat form
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        out = torch.cat(parts)
+    return out.view(world, buf.numel())
+
+
+def gather_mels(mel, lens, b_cap: int = 0, t_cap: int = 0, host_lens: bool = True):
+    """mel [B_local, T, C] (device or CPU tensor), lens [B_local] -> (mel_all [sum B, t_cap, C], lens_all) in
+    rank order, on every rank.  Ranks may hold different B_local / T (also B_local = 0).
+
+    With capacities known BEFORE the step (`b_cap` >= every rank's B_local, `t_cap` >= every rank's T: the
+    serving case - batch size and Tm_cap are fixed) the exchange is ONE fixed-size all-gather and nothing is
+    copied to the host: each rank sends [b_cap * t_cap * C mel floats | b_cap lengths | B_local] as one f32 buffer
+    (the integers bit-cast).  Without capacities one extra tiny all-gather agrees on them first.
+    `host_lens=False` returns lens_all as a device tensor (no synchronisation at all)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size()
     dev = mel.device
     B, T, Cc = mel.shape
-    meta = torch.tensor([B, T], device=dev, dtype=torch.int64)
-    metas = [torch.zeros_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    metas = [m.cpu().tolist() for m in metas]
-    Bmax, Tmax = max(m[0] for m in metas), max(m[1] for m in metas)
-    pad = torch.zeros(Bmax, Tmax, Cc, device=dev, dtype=mel.dtype)
-    pad[:B, :T] = mel
-    lpad = torch.zeros(Bmax, device=dev, dtype=torch.int32)
-    lpad[:B] = torch.as_tensor(np.asarray(lens, np.int32)).to(dev)
-    outs = [torch.empty_like(pad) for _ in range(world)]
-    louts = [torch.empty_like(lpad) for _ in range(world)]
-    dist.all_gather(outs, pad)
-    dist.all_gather(louts, lpad)
-    mel_all = torch.cat([o[:m[0]] for o, m in zip(outs, metas)], dim=0)
-    lens_all = np.concatenate([l[:m[0]].cpu().numpy() for l, m in zip(louts, metas)])
-    return mel_all, lens_all
+    if not (b_cap and t_cap):
+        meta = torch.tensor([B, T], device=dev, dtype=torch.int64)
+        metas = _all_gather_flat(meta).cpu()
+        b_cap, t_cap = max(int(metas[:, 0].max()), 1), max(int(metas[:, 1].max()), 1)
+    assert B <= b_cap and T <= t_cap, "gather_mels: local batch exceeds the agreed capacity"
+    n_mel = b_cap * t_cap * Cc
+    buf = torch.zeros(n_mel + b_cap + 1, device=dev, dtype=torch.float32)
+    if B:
+        buf[:n_mel].view(b_cap, t_cap, Cc)[:B, :T] = mel.to(torch.float32)
+    tail = buf[n_mel:].view(torch.int32)
+    if B:
+        tail[:B] = lens.to(dev, torch.int32) if torch.is_tensor(lens) else torch.as_tensor(np.asarray(lens, np.int32)).to(dev)
+    tail[b_cap] = B
+    allb = _all_gather_flat(buf)
+    mel_pad = allb[:, :n_mel].reshape(world, b_cap, t_cap, Cc)
+    ints = allb[:, n_mel:].contiguous().view(torch.int32)              # [world, b_cap + 1]
+    counts = ints[:, b_cap]
+    if host_lens:
+        counts_h = counts.cpu().tolist()
+        mel_all = torch.cat([mel_pad[r, :counts_h[r]] for r in range(world)], dim=0)
+        lens_all = np.concatenate([ints[r, :counts_h[r]].cpu().numpy() for r in range(world)]).astype(np.int32)
+        return mel_all, lens_all
+    # no host round trip: the padded [world * b_cap, t_cap, C] block and a length vector with 0 in unused slots
+    slot = torch.arange(b_cap, device=dev)[None, :]
+    lens_all = torch.where(slot < counts[:, None], ints[:, :b_cap], torch.zeros_like(ints[:, :b_cap]))
+    return mel_pad.reshape(world * b_cap, t_cap, Cc), lens_all.reshape(-1)
 
 
 def synthesize_sharded(tts, utterances, vocoder: bool = False):
     """Shard a list of `synth.Utterance`-like objects (phone, prompt_mel, optional durations / p_codes)
     over the process group, synthesize the local shard with `tts.synthesize`, all-gather the mels and
-    return them in the ORIGINAL utterance order on every rank: (list of [Tm_i, C] tensors)."""
+    return them in the ORIGINAL utterance order on every rank: (list of [Tm_i, C] tensors).  Fewer
+    utterances than ranks is fine: a rank with an empty shard contributes zero rows to the exchange."""
     import torch
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(), dist.get_rank()
+    if not utterances:
+        return []
     costs = [utterance_cost(u.phone.size, u.prompt_mel.shape[0],
                             int(u.durations.sum()) if getattr(u, "durations", None) is not None else 6 * u.phone.size)
              for u in utterances]
     shards = shard_utterances(costs, world)
     mine = shards[rank]
-    mel, lens = tts.synthesize_list([utterances[i] for i in mine], vocoder=vocoder)
+    if mine:
+        mel, lens = tts.synthesize_list([utterances[i] for i in mine], vocoder=vocoder)
+    else:   # nothing to do on this rank - it still has to take part in the collective
+        dev = getattr(getattr(tts, "native", None), "device", None) or torch.device("cpu")
+        mel, lens = torch.zeros(0, 1, utterances[0].prompt_mel.shape[1], device=dev), np.zeros(0, np.int32)
     mel_all, lens_all = gather_mels(mel, lens)
     order = [i for s in shards for i in s]
     out = [None] * len(utterances)
     for pos, i in enumerate(order):
         out[i] = mel_all[pos, :int(lens_all[pos])]
     return out
+
+
+def shard_imbalance(costs: Sequence[float], shards: Sequence[Sequence[int]]) -> float:
+    """max over ranks of the shard's modelled cost / mean: 1.0 = perfectly balanced (reported by bench.py)."""
+    loads = [sum(costs[i] for i in s) for s in shards]
+    mean = sum(loads) / max(len(loads), 1)
+    return max(loads) / mean if mean > 0 else 1.0

@@ -12,6 +12,8 @@ runs a whole batch with activations resident in HBM between stages.
 from __future__ import annotations
 
 import glob
+import os
+import warnings
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -191,8 +193,21 @@ class MegaPLM:
             self._native = NativeModel(plm_cfg=self.cfg, sd_plm=self.state)
         return self._native
 
-    def infer(self, tc_latent, lens=None):
-        return self.native.plm_infer(tc_latent, lens)
+    def infer(self, tc_latent, lens=None, prompt_tc_latent=None, prompt_codes=None):
+        """models/megatts2.py:165-181.  Optional prompt conditioning, in the layout the PLM is
+        TRAINED on (modules/datamodule.py:201-212): `prompt_tc_latent` [B, P, tc] = the prompt utterance's
+        length-regulated, max-pooled tc_latents, `prompt_codes` int64 [B, P] = its VQ-PE prosody codes
+        (`generator.vqpe(prompt_mel)[3][0]`); both are put in front of the target's and decoding continues
+        after them.  Returns the target's codes [B, Tq]."""
+        if (prompt_tc_latent is None) != (prompt_codes is None):
+            raise ValueError("prompt_tc_latent and prompt_codes go together")
+        if prompt_codes is None:
+            return self.native.plm_infer(tc_latent, lens)
+        import torch
+        if prompt_tc_latent.shape[1] != prompt_codes.shape[-1]:
+            raise ValueError("prompt_tc_latent and prompt_codes must have the same length")   # datamodule.py:207 assert
+        cond = torch.cat([prompt_tc_latent.to(tc_latent.device, torch.float32), tc_latent.to(torch.float32)], dim=1)
+        return self.native.plm_infer(cond, lens, prefix_codes=prompt_codes.to(tc_latent.device))
 
     def eval(self):
         return self
@@ -230,15 +245,36 @@ class MegaADM:
 
 
 class HIFIGAN:
-    """Stand-in for `speechbrain.pretrained.HIFIGAN` (models/megatts2.py:25,321-323): HiFi-GAN V1
-    generator on the HIP engine.  `from_hparams(source=...)` cannot download the hub weights offline;
-    pass a state dict named like transformers.SpeechT5HifiGan (weights.inventory_hifigan)."""
+    """`speechbrain.pretrained.HIFIGAN` (models/megatts2.py:25,321-323) on the HIP engine: HiFi-GAN V1 generator.
+
+    `HIFIGAN.from_hparams(source=<local dir>)` reads a speechbrain model directory (`hyperparams.yaml` +
+    `generator.ckpt`, weight norm folded at load); the hub name of the reference cannot be downloaded offline, so
+    `source` must be a local copy (or `savedir` must already hold one).  A state dict named like
+    transformers.SpeechT5HifiGan (weights.inventory_hifigan) is accepted by the constructor directly."""
 
     def __init__(self, cfg: cfgmod.HifiGanConfig, state_dict, native: Optional[NativeModel] = None):
         self.cfg = cfg
         self.state = _np_sd(state_dict)
         weights.check_strict(self.state, weights.inventory_hifigan(cfg))
         self._native = native
+
+    @classmethod
+    def from_hparams(cls, source: str, savedir: Optional[str] = None, run_opts=None, **_ignored) -> "HIFIGAN":
+        """speechbrain's `Pretrained.from_hparams(source, savedir=...)`: `source` is a directory with the model files;
+        when it is a hub id ("speechbrain/tts-hifigan-libritts-16kHz") the files must already be under `savedir`
+        (default `pretrained_models/<name>`, where speechbrain caches them) or under $MEGATTS2_HIFIGAN_DIR."""
+        cands = [source]
+        if savedir:
+            cands.append(savedir)
+        if os.environ.get("MEGATTS2_HIFIGAN_DIR"):
+            cands.append(os.environ["MEGATTS2_HIFIGAN_DIR"])
+        cands.append(os.path.join("pretrained_models", os.path.basename(source.rstrip("/"))))
+        for d in cands:
+            if d and os.path.isfile(os.path.join(d, "hyperparams.yaml")):
+                cfg, sd = weights.load_speechbrain_hifigan(d)
+                return cls(cfg, sd)
+        raise FileNotFoundError(f"HiFi-GAN model files (hyperparams.yaml, generator.ckpt) not found in any of {cands}: "
+                                "there is no network here, place a local copy of the speechbrain model there")
 
     @property
     def native(self) -> NativeModel:
@@ -247,7 +283,10 @@ class HIFIGAN:
         return self._native
 
     def decode_batch(self, spectrogram, mel_lens=None, hop_len=None):
-        """mel [B, 80, T] -> waveform [B, 1, hop*T]."""
+        """mel [B, 80, T] -> waveform [B, 1, hop * (T + 2 * inference_padding)] (speechbrain pads the mel by
+        `inference_padding` replicated frames on both sides before the generator).  Every utterance is decoded as
+        if alone (its own edge frames are replicated); samples beyond its length are zero - what speechbrain's
+        `mask_noise` leaves when `mel_lens` and `hop_len` are given."""
         return self.native.hifigan(spectrogram, mel_lens)
 
     def eval(self):
@@ -259,24 +298,22 @@ class Megatts:
 
     def __init__(self, g_ckpt: str = None, g_config: str = None, plm_ckpt: str = None, plm_config: str = None,
                  adm_ckpt: str = None, adm_config: str = None, symbol_table: str = None, *,
-                 models: Optional[tuple] = None, hifi_gan: Optional[HIFIGAN] = None):
+                 models: Optional[tuple] = None, hifi_gan: Optional[HIFIGAN] = None,
+                 hifigan_source: Optional[str] = "speechbrain/tts-hifigan-libritts-16kHz"):
         if models is not None:
             self.generator, self.plm, self.adm = models
         else:
             self.generator = MegaG.from_pretrained(g_ckpt, g_config)
             self.plm = MegaPLM.from_pretrained(plm_ckpt, plm_config)
             self.adm = MegaADM.from_pretrained(adm_ckpt, adm_config)
+            if hifi_gan is None and hifigan_source:
+                # :321-323  the reference ALWAYS builds the vocoder.  Offline the hub id resolves to a local copy
+                # (savedir / $MEGATTS2_HIFIGAN_DIR / pretrained_models/<name>); without one there is no audio.
+                try:
+                    hifi_gan = HIFIGAN.from_hparams(source=hifigan_source)
+                except FileNotFoundError as e:
+                    warnings.warn(f"no vocoder: {e}")
         self.hifi_gan = hifi_gan
-        self.native = NativeModel(self.generator.cfg, self.plm.cfg, self.adm.cfg,
-                                  hifi_gan.cfg if hifi_gan else None, self.generator.state, self.plm.state,
-                                  self.adm.state, hifi_gan.state if hifi_gan else None)
-        for part in (self.generator, self.plm, self.adm) + ((hifi_gan,) if hifi_gan else ()):
-            part._native = self.native
-        self.lr = LengthRegulator(HIFIGAN_HOP_LENGTH, 16000, (HIFIGAN_HOP_LENGTH / HIFIGAN_SR * 1000), self.native)
-        self.symbol_table = symbol_table
-        self.tt = None
-        self.ttc = None
-
     def eval(self):
         return self
 
@@ -345,9 +382,11 @@ class Megatts:
         phone_tokens = torch.as_tensor(np.asarray(phone_tokens)).to(torch.int64).reshape(1, -1).cuda()
         mel, mel_lens, aux = self.synthesize(phone_tokens, mels, vocoder=self.hifi_gan is not None, return_aux=True)
         if self.hifi_gan is not None and out_path:
-            # :370-375  prompt audio (vocoded first prompt mel) followed by the generated audio
+            # :370-375  prompt audio (vocoded first prompt mel) followed by the generated audio; decode_batch output
+            # includes the generator's inference padding on both sides, exactly as the reference concatenates it
+            hg = self.hifi_gan.cfg
             prompt = self.hifi_gan.decode_batch(mels_prompt.transpose(0, 1).unsqueeze(0).contiguous())[0, 0]
-            audio = torch.cat([prompt, aux["wav"][0, :int(mel_lens[0]) * self.hifi_gan.cfg.hop]])
+            audio = torch.cat([prompt, aux["wav"][0, :(int(mel_lens[0]) + 2 * hg.inference_padding) * hg.hop]])
             audio_io.write_wav(out_path, audio, HIFIGAN_SR)
         return mel, mel_lens, aux
 

@@ -46,6 +46,7 @@ class MT2Config(C.Structure):
         ("hg_n_res", C.c_int32), ("hg_res_kernels", C.c_int32 * 4), ("hg_res_dilations", (C.c_int32 * 3) * 4),
         ("hg_slope", C.c_float),
         ("max_positions", C.c_int32),
+        ("hg_inference_padding", C.c_int32),
     ]
 
 
@@ -120,6 +121,7 @@ def make_config(g: Optional[cfgmod.GConfig], plm: Optional[cfgmod.PLMConfig], ad
             c.hg_res_dilations[j][n] = d
     c.hg_slope = hg.leaky_relu_slope
     c.max_positions = max_positions
+    c.hg_inference_padding = int(getattr(hg, "inference_padding", 0))
     return c
 
 
@@ -266,14 +268,21 @@ class NativeModel:
         _check(self.lib.mt2_mrte_mel_context(self.h, _stream(), _ptr(mel), _iptr(ml), Tp, B, _ptr(out), Tc))
         return out
 
-    def adm_infer(self, tc_latent, lens=None, return_float=False):
+    def adm_infer(self, tc_latent, lens=None, return_float=False, p_prefix=None, max_steps: int = 0):
+        """MegaADM.infer.  `p_prefix` f32 [B, P] (test hook): forced un-rounded predictions of the first P
+        positions - the loop continues from position P for `max_steps` positions (0 = to the end)."""
         import torch
         B, Np = tc_latent.shape[0], tc_latent.shape[1]
         tc = self._f32(tc_latent)
         ln = self._lens(lens, B, Np)
         dur = torch.empty(B, Np, device=tc.device, dtype=torch.int32)
         flt = torch.empty(B, Np, device=tc.device, dtype=torch.float32) if return_float else None
-        _check(self.lib.mt2_adm_infer(self.h, _stream(), _ptr(tc), _iptr(ln), Np, B, _ptr(dur), _ptr(flt)))
+        P = 0
+        if p_prefix is not None:
+            p_prefix = self._f32(p_prefix).reshape(B, -1)
+            P = p_prefix.shape[1]
+        _check(self.lib.mt2_adm_infer_forced(self.h, _stream(), _ptr(tc), _iptr(ln), Np, B, _ptr(p_prefix), P,
+                                             int(max_steps), _ptr(dur), _ptr(flt)))
         return (dur, flt) if return_float else dur
 
     def length_regulate(self, x, dur, lens=None, mel_max_length=None):
@@ -298,14 +307,24 @@ class NativeModel:
         _check(self.lib.mt2_max_pool_ceil(self.h, _stream(), _ptr(x), _iptr(ln), T, D, B, k, _ptr(out), Tq))
         return out
 
-    def plm_infer(self, cond, lens=None, return_logits=False):
+    def plm_infer(self, cond, lens=None, return_logits=False, prefix_codes=None, max_steps: int = 0):
+        """MegaPLM.infer.  With `prefix_codes` int64 [B, P] the first P rows of `cond` [B, P + Tq, tc] are the
+        prompt's pooled tc_latents and decoding is conditioned on the prompt's prosody codes (training layout of
+        reference modules/datamodule.py:201-212); `lens` are the TARGET lengths, the result covers the target."""
         import torch
-        B, Tq = cond.shape[0], cond.shape[1]
+        B = cond.shape[0]
         cond = self._f32(cond)
+        P = 0
+        if prefix_codes is not None:
+            prefix_codes = prefix_codes.contiguous().to(torch.int64).reshape(B, -1)
+            P = prefix_codes.shape[1]
+        Tq = cond.shape[1] - P
+        assert Tq >= 1, "cond must hold the prompt rows followed by at least one target row"
         ln = self._lens(lens, B, Tq)
         codes = torch.empty(B, Tq, device=cond.device, dtype=torch.int64)
         logits = torch.zeros(B, Tq, self.plm_cfg.vq_bins, device=cond.device, dtype=torch.float32) if return_logits else None
-        _check(self.lib.mt2_plm_infer(self.h, _stream(), _ptr(cond), _iptr(ln), Tq, B, _ptr(codes), _ptr(logits)))
+        _check(self.lib.mt2_plm_infer_prompted(self.h, _stream(), _ptr(cond), _iptr(ln), Tq, B, _ptr(prefix_codes), P,
+                                               int(max_steps), _ptr(codes), _ptr(logits)))
         return (codes, logits) if return_logits else codes
 
     def vq_decode(self, codes):
@@ -353,7 +372,8 @@ class NativeModel:
         B, D, T = mel.shape
         mel = self._f32(mel)
         ln = self._lens(lens, B, T)
-        wav = torch.empty(B, 1, self.hg_cfg.hop * T, device=mel.device, dtype=torch.float32)
+        pad = int(getattr(self.hg_cfg, "inference_padding", 0))
+        wav = torch.empty(B, 1, self.hg_cfg.hop * (T + 2 * pad), device=mel.device, dtype=torch.float32)
         _check(self.lib.mt2_hifigan(self.h, _stream(), _ptr(mel), _iptr(ln), T, B, _ptr(wav)))
         return wav
 
@@ -389,7 +409,8 @@ class NativeModel:
         mel_lens = np.zeros(B, np.int32)
         dur_out = torch.empty(B, Np, device=dev, dtype=torch.int32)
         codes_out = torch.empty(B, tq_cap, device=dev, dtype=torch.int64)
-        wav = torch.empty(B, self.hg_cfg.hop * tm_cap, device=dev, dtype=torch.float32) if vocoder else None
+        pad = int(getattr(self.hg_cfg, "inference_padding", 0))
+        wav = torch.empty(B, self.hg_cfg.hop * (tm_cap + 2 * pad), device=dev, dtype=torch.float32) if vocoder else None
         flags = (MT2_RUN_PLM if run_plm else 0) | (MT2_RUN_VOCODER if vocoder else 0) | (MT2_SKIP_ADM if skip_adm else 0)
         _check(self.lib.mt2_synthesize_batch(self.h, _stream(), _ptr(phone), _iptr(pl), Np, _ptr(prompt_mel), _iptr(ml),
                                              Tp, B, _iptr(fd), _ptr(forced_codes), tq_cap, flags, _ptr(mel), tm_cap,
@@ -398,9 +419,49 @@ class NativeModel:
             return mel, mel_lens, {"dur": dur_out, "codes": codes_out, "wav": wav}
         return mel, mel_lens
 
-    # ---- tuning / measurement
+    # ---- tuning / measurement (every switch lives in THIS handle; the library has no mutable globals)
+    def set_option(self, name: str, value: int) -> None:
+        _check(self.lib.mt2_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int(0)
+        _check(self.lib.mt2_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
     def set_ar_groups(self, groups: int) -> None:
-        _check(self.lib.mt2_set_ar_groups(self.h, int(groups)))
+        self.set_option("ar_groups", groups)
+
+    def workspace_query(self, B: int, Np_max: int, Tp_max: int, Tm_cap: int, run_plm=True, vocoder=False,
+                        skip_adm=False) -> int:
+        """Upper bound (bytes) of the arena one synthesize_batch call of this geometry needs."""
+        flags = (MT2_RUN_PLM if run_plm else 0) | (MT2_RUN_VOCODER if vocoder else 0) | (MT2_SKIP_ADM if skip_adm else 0)
+        n = C.c_size_t(0)
+        _check(self.lib.mt2_workspace_query(self.h, B, Np_max, Tp_max, Tm_cap, flags, C.byref(n)))
+        return n.value
+
+    def workspace_reserve(self, nbytes: int) -> None:
+        _check(self.lib.mt2_workspace_reserve(self.h, C.c_size_t(int(nbytes))))
+
+    def workspace_high_water(self) -> int:
+        n = C.c_size_t(0)
+        _check(self.lib.mt2_workspace_high_water(self.h, C.byref(n)))
+        return n.value
+
+    def gemm_trace_begin(self) -> None:
+        _check(self.lib.mt2_gemm_trace_begin(self.h))
+
+    def gemm_trace_end(self):
+        """-> list of dicts {config, launches, flops, ms} for this handle's GEMM launches since gemm_trace_begin()."""
+        cap = 48
+        names = (C.c_char_p * cap)()
+        launches = (C.c_int64 * cap)()
+        flops = (C.c_double * cap)()
+        ms = (C.c_double * cap)()
+        n = self.lib.mt2_gemm_trace_end(self.h, cap, names, launches, flops, ms)
+        if n < 0:
+            raise NativeError("gemm trace failed")
+        return [{"config": names[i].decode(), "launches": int(launches[i]), "flops": float(flops[i]), "ms": float(ms[i])}
+                for i in range(n)]
 
     def set_profiling(self, on: bool) -> None:
         _check(self.lib.mt2_set_profiling(self.h, 1 if on else 0))
@@ -503,25 +564,6 @@ def op_attention(Q, K, V, q_start, q_len, kv_start, kv_len, H, D, scale):
                                 O.stride(0), _ptr(q_start), _ptr(q_len), _ptr(kv_start), _ptr(kv_len), B, H, D,
                                 int(q_len.max().item()), C.c_float(scale)))
     return O
-
-
-def gemm_trace_begin() -> None:
-    _check(load_library().mt2_gemm_trace_begin())
-
-
-def gemm_trace_end():
-    """-> list of dicts {config, launches, flops, ms} for the launches since gemm_trace_begin()."""
-    lib = load_library()
-    cap = 32
-    names = (C.c_char_p * cap)()
-    launches = (C.c_int64 * cap)()
-    flops = (C.c_double * cap)()
-    ms = (C.c_double * cap)()
-    n = lib.mt2_gemm_trace_end(cap, names, launches, flops, ms)
-    if n < 0:
-        raise NativeError("gemm trace failed")
-    return [{"config": names[i].decode(), "launches": int(launches[i]), "flops": float(flops[i]), "ms": float(ms[i])}
-            for i in range(n)]
 
 
 def bench_gemm(M, N, K, taps=1, force_cfg=-1, iters=20, w_copies=1, dil=1, flags=0):

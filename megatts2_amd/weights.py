@@ -21,6 +21,8 @@ from typing import Dict, Tuple
 
 import numpy as np
 
+import yaml
+
 from .config import ADMConfig, GConfig, HifiGanConfig, PLMConfig
 
 Inventory = "OrderedDict[str, Tuple[int, ...]]"
@@ -249,3 +251,133 @@ def check_strict(sd: Dict[str, np.ndarray], inv) -> None:
     for k, shape in inv.items():
         if tuple(sd[k].shape) != tuple(shape):
             raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != expected {tuple(shape)}")
+
+
+# ---------------------------------------------------------------------------------------------
+# speechbrain HiFi-GAN checkpoints (reference models/megatts2.py:321-323:
+# `HIFIGAN.from_hparams(source="speechbrain/tts-hifigan-libritts-16kHz")`)
+
+
+def _sb_yaml(path: str) -> dict:
+    """Read a HyperPyYAML file WITHOUT hyperpyyaml: `!new:` / `!name:` / `!ref` tags are kept as plain
+    mappings / scalars, `!ref <key>` scalars are resolved against the top-level keys."""
+
+    class _Loader(yaml.SafeLoader):
+        pass
+
+    def _any(loader, suffix, node):
+        if isinstance(node, yaml.ScalarNode):
+            return loader.construct_scalar(node)
+        if isinstance(node, yaml.SequenceNode):
+            return loader.construct_sequence(node, deep=True)
+        return loader.construct_mapping(node, deep=True)
+
+    _Loader.add_multi_constructor("!", _any)
+    with open(path, "r") as f:
+        tree = yaml.load(f, Loader=_Loader) or {}
+
+    def resolve(v, depth=0):
+        if isinstance(v, str) and v.strip().startswith("<") and v.strip().endswith(">") and depth < 8:
+            return resolve(tree.get(v.strip()[1:-1]), depth + 1)
+        if isinstance(v, dict):
+            return {k: resolve(x, depth) for k, x in v.items()}
+        if isinstance(v, list):
+            return [resolve(x, depth) for x in v]
+        return v
+
+    return {k: resolve(v) for k, v in tree.items()}
+
+
+def hifigan_config_from_speechbrain(hparams_path: str) -> HifiGanConfig:
+    """`hyperparams.yaml` of a speechbrain HiFi-GAN model directory -> HifiGanConfig (generator block or the
+    top-level keys of the same names; HifiganGenerator.__init__ argument names)."""
+    tree = _sb_yaml(hparams_path)
+    gen = tree.get("generator") if isinstance(tree.get("generator"), dict) else {}
+
+    def get(name, default):
+        v = gen.get(name, tree.get(name, default))
+        return default if v is None else v
+
+    if str(get("resblock_type", "1")) != "1":
+        raise ValueError("only HiFi-GAN ResBlock1 generators are supported (resblock_type '1')")
+    if int(get("cond_channels", 0)) != 0:
+        raise ValueError("speaker-conditioned HiFi-GAN (cond_channels > 0) is not supported")
+    if int(get("out_channels", 1)) != 1:
+        raise ValueError("HiFi-GAN out_channels must be 1")
+    if not bool(get("conv_post_bias", True)):
+        raise ValueError("HiFi-GAN conv_post_bias: False is not supported")
+    return HifiGanConfig(
+        in_dim=int(get("in_channels", 80)),
+        upsample_initial_channel=int(get("upsample_initial_channel", 512)),
+        upsample_rates=[int(v) for v in get("upsample_factors", [8, 8, 2, 2])],
+        upsample_kernel_sizes=[int(v) for v in get("upsample_kernel_sizes", [16, 16, 4, 4])],
+        resblock_kernel_sizes=[int(v) for v in get("resblock_kernel_sizes", [3, 7, 11])],
+        resblock_dilation_sizes=[[int(d) for d in row] for row in
+                                 get("resblock_dilation_sizes", [[1, 3, 5], [1, 3, 5], [1, 3, 5]])],
+        leaky_relu_slope=0.1,                                  # LRELU_SLOPE constant of speechbrain's HifiGAN.py
+        inference_padding=int(get("inference_padding", 5)))
+
+
+def fold_weight_norm(g: np.ndarray, v: np.ndarray) -> np.ndarray:
+    """torch.nn.utils.weight_norm (dim=0): w = g * v / ||v||, the norm taken over every dim but the first."""
+    v = np.asarray(v, np.float32)
+    g = np.asarray(g, np.float32).reshape((-1,) + (1,) * (v.ndim - 1))
+    n = np.sqrt((v.astype(np.float64) ** 2).sum(axis=tuple(range(1, v.ndim)), keepdims=True)).astype(np.float32)
+    return (g * (v / n)).astype(np.float32)
+
+
+def convert_speechbrain_hifigan(raw: Dict[str, np.ndarray], cfg: HifiGanConfig) -> Dict[str, np.ndarray]:
+    """State dict of speechbrain's HifiganGenerator (`conv_pre.conv.weight_g/_v/bias`, `ups.{i}.conv.*`,
+    `resblocks.{j}.convs{1,2}.{n}.conv.*`, `conv_post.conv.*`; weight norm as `weight_g`/`weight_v`, as
+    `parametrizations.weight.original0/1`, or already removed) -> the inventory_hifigan names, weight norm folded."""
+    raw = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in raw.items()}
+
+    def weight(prefix: str) -> np.ndarray:
+        for gk, vk in (("weight_g", "weight_v"), ("parametrizations.weight.original0", "parametrizations.weight.original1")):
+            if f"{prefix}.{gk}" in raw:
+                return fold_weight_norm(raw[f"{prefix}.{gk}"], raw[f"{prefix}.{vk}"])
+        if f"{prefix}.weight" in raw:
+            return np.asarray(raw[f"{prefix}.weight"], np.float32)
+        raise KeyError(f"no weight under {prefix} in the speechbrain checkpoint")
+
+    def module(name: str) -> str:          # speechbrain's Conv1d / ConvTranspose1d wrappers hold the torch layer as `.conv`
+        return f"{name}.conv" if any(k.startswith(f"{name}.conv.") for k in raw) else name
+
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for ours, theirs in (("conv_pre", "conv_pre"), ("conv_post", "conv_post")):
+        m = module(theirs)
+        out[f"{ours}.weight"] = weight(m)
+        out[f"{ours}.bias"] = np.asarray(raw[f"{m}.bias"], np.float32)
+    for i in range(len(cfg.upsample_rates)):
+        m = module(f"ups.{i}")
+        out[f"upsampler.{i}.weight"] = weight(m)
+        out[f"upsampler.{i}.bias"] = np.asarray(raw[f"{m}.bias"], np.float32)
+    nk = len(cfg.resblock_kernel_sizes)
+    for j in range(len(cfg.upsample_rates) * nk):
+        for which in ("convs1", "convs2"):
+            for n in range(len(cfg.resblock_dilation_sizes[j % nk])):
+                m = module(f"resblocks.{j}.{which}.{n}")
+                out[f"resblocks.{j}.{which}.{n}.weight"] = weight(m)
+                out[f"resblocks.{j}.{which}.{n}.bias"] = np.asarray(raw[f"{m}.bias"], np.float32)
+    inv = inventory_hifigan(cfg)
+    ordered = OrderedDict((k, out[k]) for k in inv)
+    check_strict(ordered, inv)
+    return ordered
+
+
+def load_speechbrain_hifigan(source: str):
+    """A LOCAL speechbrain model directory (what `HIFIGAN.from_hparams(source=..., savedir=...)` leaves on disk:
+    `hyperparams.yaml` + `generator.ckpt`) -> (HifiGanConfig, state dict).  No hub download (offline)."""
+    import os
+
+    hp, ck = os.path.join(source, "hyperparams.yaml"), os.path.join(source, "generator.ckpt")
+    if not (os.path.isfile(hp) and os.path.isfile(ck)):
+        raise FileNotFoundError(f"{source}: expected hyperparams.yaml and generator.ckpt of a speechbrain HiFi-GAN "
+                                "(the hub model cannot be downloaded offline; point to a local copy)")
+    cfg = hifigan_config_from_speechbrain(hp)
+    import torch
+
+    raw = torch.load(ck, map_location="cpu", weights_only=False)
+    if isinstance(raw, dict) and "state_dict" in raw and not any(k.startswith("conv_pre") for k in raw):
+        raw = raw["state_dict"]
+    return cfg, convert_speechbrain_hifigan(raw, cfg)

@@ -52,6 +52,8 @@ def main() -> None:
         O.enable_torch_kernels(a.threads)
     n_utt, frames, t0 = 0, 0, time.perf_counter()
     for u in utts:
+        if full:    # configs[2] "full VQ-PE -> ...": the prosody encoder on the prompt mel, as bench.py's step does
+            O.vqpe_forward(sd_g, g, u.prompt_mel)
         ref = O.synthesize(sd_g, sd_p, sd_a, g, p, d, u.phone, u.prompt_mel, forced_durations=u.durations,
                            forced_codes=None if full else u.p_codes, run_plm=full)
         if full:
@@ -64,7 +66,10 @@ def main() -> None:
     print(json.dumps({"value": round(frames / cpu_s, 2), "unit": "mel-frames/s", "cores": a.threads, "kind": "port",
                       "sample": f"{n_utt} of the {shape.B} utterances of {a.workload} (Np={shape.Np}, Tp={shape.Tp}, "
                                 f"Tm={shape.Tm}) one after the other, oracle port, dense primitives on "
-                                f"{'ATen' if a.backend == 'aten' else 'numpy/OpenBLAS'}, {a.threads} threads, {cpu_s:.1f} s"}))
+                                f"{'ATen' if a.backend == 'aten' else 'numpy/OpenBLAS'}, {a.threads} threads, {cpu_s:.1f} s"
+                                + ("; stages vqpe+mrte+adm+plm+decoder+vocoder" if full else "; stages mrte+adm+decoder")
+                                + "; kind 'port' because /root/reference is absent on the GPU box - the port is pinned to "
+                                  "the live reference by tests/golden/*"}))
 
 
 if __name__ == "__main__":

@@ -61,7 +61,7 @@ def test_config_struct_matches_header():
                 n *= int(d)
             words += n
     assert fields == [f[0] for f in MT2Config._fields_]
-    assert ctypes.sizeof(MT2Config) == 4 * words == 288
+    assert ctypes.sizeof(MT2Config) == 4 * words == 292
 
 
 def test_production_yaml_equals_builtin_configs():
@@ -176,3 +176,98 @@ def test_wav_io_and_packed_weights(tmp_path):
     assert list(back) == list(sd)
     for k in sd:
         assert back[k].shape == sd[k].shape and np.array_equal(back[k], sd[k])
+
+
+def test_config_rejects_what_the_kernels_do_not_implement(tmp_path):
+    """A checkpoint config with another activation (reference: `getattr(nn, activation)`, modules/convnet.py:14) or
+    an unknown hyper-parameter must not load silently: ReLU is hard-coded in the kernels."""
+    import yaml
+    from megatts2_amd import config as C
+    ref = "/root/reference/configs/config_gan.yaml"
+    if not os.path.isfile(ref):
+        pytest.skip("reference tree not mounted")
+    tree = yaml.safe_load(open(ref))
+    ok = tmp_path / "ok.yaml"
+    ok.write_text(yaml.safe_dump(tree))
+    assert C.g_config_from_yaml(str(ok)) == C.production_g()
+    for path, val in ((("vqpe", "init_args", "activation"), "GELU"), (("mrte", "init_args", "mel_activation"), "SiLU"),
+                      (("activation",), "Tanh"), (("vqpe", "init_args", "stride"), 4), (("mrte", "init_args", "n_heads"), 4)):
+        bad = yaml.safe_load(open(ref))
+        node = bad["model"]["G"]["init_args"]
+        for k in path[:-1]:
+            node = node[k]
+        node[path[-1]] = val
+        f = tmp_path / "bad.yaml"
+        f.write_text(yaml.safe_dump(bad))
+        with pytest.raises(ValueError):
+            C.g_config_from_yaml(str(f))
+
+
+def test_speechbrain_hifigan_directory_loader(tmp_path):
+    """`HIFIGAN.from_hparams(source=<local dir>)` (reference models/megatts2.py:321-323): HyperPyYAML hyper-parameters
+    read without hyperpyyaml, `generator.ckpt` in speechbrain's key names with weight norm (both spellings) folded."""
+    import torch
+    from megatts2_amd import config as C
+    from megatts2_amd import weights
+    hc = C.tiny_hifigan()
+    sd = weights.synth_state_dict(weights.inventory_hifigan(hc), 0, "hifigan.")
+    rng = np.random.default_rng(0)
+    raw = {}
+
+    def put(prefix, w, b, style):
+        v = w * rng.uniform(0.5, 2.0, (w.shape[0],) + (1,) * (w.ndim - 1)).astype(np.float32)   # any v with the same direction
+        gn = np.sqrt((w.astype(np.float64) ** 2).sum(axis=tuple(range(1, w.ndim)), keepdims=True)).astype(np.float32)
+        if style == 0:
+            raw[f"{prefix}.conv.weight_g"], raw[f"{prefix}.conv.weight_v"] = torch.from_numpy(gn), torch.from_numpy(v)
+        elif style == 1:
+            raw[f"{prefix}.conv.parametrizations.weight.original0"] = torch.from_numpy(gn)
+            raw[f"{prefix}.conv.parametrizations.weight.original1"] = torch.from_numpy(v)
+        else:
+            raw[f"{prefix}.conv.weight"] = torch.from_numpy(w)
+        raw[f"{prefix}.conv.bias"] = torch.from_numpy(b)
+
+    for i, k in enumerate(sd):
+        if not k.endswith(".weight"):
+            continue
+        base = k[:-len(".weight")]
+        put(base.replace("upsampler.", "ups."), sd[k], sd[base + ".bias"], i % 3)
+    d = tmp_path / "tts-hifigan-libritts-16kHz"
+    d.mkdir()
+    torch.save(raw, str(d / "generator.ckpt"))
+    (d / "hyperparams.yaml").write_text("""
+in_channels: 80
+out_channels: 1
+resblock_type: "1"
+resblock_dilation_sizes: [[1, 3, 5], [1, 3, 5], [1, 3, 5]]
+resblock_kernel_sizes: [3, 7, 11]
+upsample_kernel_sizes: [16, 16, 4, 4]
+upsample_initial_channel: 64
+upsample_factors: [8, 8, 2, 2]
+inference_padding: 5
+cond_channels: 0
+conv_post_bias: True
+generator: !new:speechbrain.lobes.models.HifiGAN.HifiganGenerator
+    in_channels: !ref <in_channels>
+    out_channels: !ref <out_channels>
+    resblock_type: !ref <resblock_type>
+    resblock_dilation_sizes: !ref <resblock_dilation_sizes>
+    resblock_kernel_sizes: !ref <resblock_kernel_sizes>
+    upsample_kernel_sizes: !ref <upsample_kernel_sizes>
+    upsample_initial_channel: !ref <upsample_initial_channel>
+    upsample_factors: !ref <upsample_factors>
+    inference_padding: !ref <inference_padding>
+    cond_channels: !ref <cond_channels>
+    conv_post_bias: !ref <conv_post_bias>
+modules:
+    generator: !ref <generator>
+pretrainer: !new:speechbrain.utils.parameter_transfer.Pretrainer
+    loadables:
+        generator: !ref <generator>
+""")
+    cfg, got = weights.load_speechbrain_hifigan(str(d))
+    assert cfg.upsample_initial_channel == 64 and cfg.upsample_rates == [8, 8, 2, 2] and cfg.inference_padding == 5
+    assert cfg.hop == 256 and list(got) == list(sd)
+    for k in sd:
+        assert got[k].shape == sd[k].shape and np.abs(got[k] - sd[k]).max() < 1e-6, k
+    with pytest.raises(FileNotFoundError):
+        weights.load_speechbrain_hifigan(str(tmp_path / "nowhere"))

@@ -42,6 +42,13 @@ def _worker(rank, world, port, q):
     mel_all, lens_all = D.gather_mels(local, np.arange(1, rank + 2, dtype=np.int32))
     ok = ok and mel_all.shape == (3, 6, 80) and lens_all.tolist() == [1, 1, 2]
     ok = ok and float(mel_all[0].max()) == 0.0 and float(mel_all[1, :6].min()) == 1.0
+    # fixed capacities known before the step: ONE collective, device-side lengths (what bench.py --gpus N does)
+    mel_cap, lens_cap = D.gather_mels(local, np.arange(1, rank + 2, dtype=np.int32), b_cap=3, t_cap=8, host_lens=False)
+    ok = ok and tuple(mel_cap.shape) == (6, 8, 80) and lens_cap.tolist() == [1, 0, 0, 1, 2, 0]
+    ok = ok and float(mel_cap[3, :6].min()) == 1.0 and float(mel_cap[3, 6:].abs().max()) == 0.0
+    # fewer utterances than ranks: the rank with an empty shard still takes part in the collective (no hang)
+    one = D.synthesize_sharded(FakeTTS(), utts[:1])
+    ok = ok and len(one) == 1 and torch.equal(one[0], fake_mel(utts[0]))
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 

@@ -493,3 +493,381 @@ def test_error_behaviour_matches_reference_exceptions(tiny_batch):
     # the shared handle still works
     out = tts.native.tc_latent(phone, mel).cpu().numpy()
     assert O.rel_l2(out[0], z["tc_latent"]) < TIGHT
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 2: production-size parity beyond C1 - C3 batch (free-running PLM + vocoder), C5-length stages and
+# single AR steps, prompt-conditioned PLM, vocoder boundary, index validation, handle hygiene
+
+
+def _c3_batch():
+    """32 utterances at the C2/C3/C4 geometry; slot 0 is the utterance of the live-reference fixture prod_utt1."""
+    from megatts2_amd import synth
+    z = load_golden("prod_utt1.npz")
+    utts = synth.make_batch(synth.C3, seed=1003)
+    utts[0] = synth.Utterance(z["phone"], z["prompt_mel"], z["forced_dur"], utts[0].p_codes)
+    return z, utts
+
+
+def test_prod_c3_batch_free_running_plm_and_vocoder():
+    """BASELINE configs[2] at full size (B=32, 70 phones, 431-frame prompt, 431 frames): the whole path with the ADM and
+    the PLM free-running and the vocoder.  Utterance 0 against the fixture made by the LIVE reference modules,
+    utterances 7 and 31 against the oracle run alone (ATen backend): durations and prosody codes bit-exact, mel and
+    waveform within 1e-3."""
+    tts = model("prod")
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("prod")
+    z, utts = _c3_batch()
+    phone, pl = pad_stack([u.phone for u in utts])
+    mel, ml = pad_stack([u.prompt_mel for u in utts])
+    dur, _ = pad_stack([u.durations for u in utts])
+    out, lens, aux = tts.native.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, vocoder=True, return_aux=True)
+    out = out.cpu().numpy()
+    assert lens.tolist() == [431] * 32
+    assert np.array_equal(aux["dur"][0].cpu().numpy(), z["adm_dur"])
+    assert np.array_equal(aux["codes"][0, :54].cpu().numpy(), z["p_codes"])
+    assert O.rel_l2(out[0, :431], z["mel"]) < NORTH_STAR
+    O.enable_torch_kernels()
+    try:
+        for i in (7, 31):
+            u = utts[i]
+            ref = O.synthesize(sd_g, sd_p, sd_a, g, p, a, u.phone, u.prompt_mel, forced_durations=u.durations)
+            assert np.array_equal(aux["dur"][i].cpu().numpy(), ref["adm_dur"]), f"durations of utterance {i}"
+            assert np.array_equal(aux["codes"][i, :54].cpu().numpy(), ref["p_codes"]), f"prosody codes of utterance {i}"
+            assert O.rel_l2(out[i, :431], ref["mel"]) < NORTH_STAR
+            wav = O.hifigan(sd_h, h, ref["mel"])
+            assert O.rel_l2(aux["wav"][i, :wav.size].cpu().numpy(), wav) < NORTH_STAR
+    finally:
+        O.disable_torch_kernels()
+
+
+def test_prod_c2_durations_of_the_batched_adm():
+    """C2 at full size: the ADM's own integer durations (not the forced ones) of a ragged batch equal the oracle's."""
+    from megatts2_amd import synth
+    tts = model("prod")
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("prod")
+    utts = synth.make_batch(synth.C2, seed=1002, jitter=0.3)
+    phone, pl = pad_stack([u.phone for u in utts])
+    mel, ml = pad_stack([u.prompt_mel for u in utts])
+    dur, _ = pad_stack([u.durations for u in utts])
+    codes, _ = pad_stack([u.p_codes for u in utts])
+    out, lens, aux = tts.native.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, forced_codes=dev(codes),
+                                                 run_plm=False, return_aux=True)
+    O.enable_torch_kernels()
+    try:
+        for i in (5, 22):
+            u = utts[i]
+            tc = O.mrte_tc_latent(sd_g, g, u.phone, u.prompt_mel)
+            assert np.array_equal(aux["dur"][i, :pl[i]].cpu().numpy(), O.adm_infer(sd_a, a, tc))
+            assert not aux["dur"][i, pl[i]:].any()
+    finally:
+        O.disable_torch_kernels()
+
+
+def test_prod_long_shapes_c5_geometry():
+    """C5 geometry against the live-reference fixture prod_long.npz: mel encoder on a 2584-frame prompt, decoder and
+    VQ-PE on 5168 frames (VQ indices bit-exact), single AR steps on forced histories at n = 71 / 417 / 834 (ADM:
+    13-27 key tiles per head, PE rows > 260) and n = 128 / 646 (PLM: the 256x128 tile regime of its feed-forward)."""
+    import fixtures
+    tts = model("prod")
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("prod")
+    z = load_golden("prod_long.npz")
+    li = fixtures.long_inputs(sd_g[O.CODEBOOK], int(z["seed"]))
+    ctx = tts.native.mel_context(dev(li["prompt_mel"][None])).cpu().numpy()[0]
+    assert ctx.shape == z["mel_context"].shape and O.rel_l2(ctx, z["mel_context"]) < TIGHT
+    mel = tts.generator.decoder(dev(li["decoder_in"].T[None].copy())).cpu().numpy()[0].T
+    assert O.rel_l2(mel, z["mel"]) < TIGHT
+    zq, codes, ze = tts.native.vqpe_forward(dev(li["target_mel"][None]), return_ze=True)
+    assert O.rel_l2(ze[0].cpu().numpy(), z["vqpe_ze"]) < TIGHT
+    assert np.array_equal(codes[0, 0].cpu().numpy(), z["vqpe_codes"])
+    for n in fixtures.ADM_STEPS:
+        _, flt = tts.native.adm_infer(dev(li["adm_tc"][None, :n]), return_float=True, p_prefix=dev(li["adm_hist"][None, :n - 1]),
+                                      max_steps=1)
+        flt = flt[0].cpu().numpy()
+        assert np.array_equal(flt[:n - 1], li["adm_hist"][:n - 1])                 # the forced history comes back untouched
+        want = float(z[f"adm_pred_{n}"])
+        assert abs(float(flt[n - 1]) - want) < 1e-4 * max(1.0, abs(want)), (n, flt[n - 1], want)
+    for n in fixtures.PLM_STEPS:
+        c, lg = tts.native.plm_infer(dev(li["plm_cond"][None, :n]), np.asarray([1], np.int32), return_logits=True,
+                                     prefix_codes=dev(li["plm_hist"][None, :n - 1]), max_steps=1)
+        assert O.rel_l2(lg[0, 0].cpu().numpy(), z[f"plm_logits_{n}"]) < 1e-4
+        assert int(c[0, 0]) == int(z[f"plm_logits_{n}"].argmax())
+    # two sequences of different length stepping from the same forced-history length in ONE call
+    tcs, ln = pad_stack([li["adm_tc"][:300], li["adm_tc"][200:480]])
+    hist = np.stack([li["adm_hist"][:250], li["adm_hist"][200:450]])
+    _, flt = tts.native.adm_infer(dev(tcs), ln, return_float=True, p_prefix=dev(hist), max_steps=2)
+    O.enable_torch_kernels()
+    try:
+        for b, (lo, hi) in enumerate(((0, 300), (200, 480))):
+            _, want = O.adm_infer(sd_a, a, li["adm_tc"][lo:hi], return_float=True, p_prefix=hist[b], steps=2)
+            assert np.allclose(flt[b, :252].cpu().numpy(), want[:252], rtol=1e-4, atol=1e-4)
+    finally:
+        O.disable_torch_kernels()
+
+
+def test_prod_plm_prompt_conditioned():
+    """Row f1: PLM decoding conditioned on a prompt's prosody codes (training layout, modules/datamodule.py:201-212)
+    against the live-reference fixture; through the mirror `MegaPLM.infer(..., prompt_tc_latent, prompt_codes)`."""
+    tts = model("prod")
+    z = load_golden("prod_plm_prefix.npz")
+    P = z["prefix"].size
+    codes, logits = tts.native.plm_infer(dev(z["cond"][None]), return_logits=True, prefix_codes=dev(z["prefix"][None]))
+    assert np.array_equal(codes[0].cpu().numpy(), z["codes"])
+    assert O.rel_l2(logits[0].cpu().numpy(), z["logits"]) < 1e-4
+    got = tts.plm.infer(dev(z["cond"][None, P:]), prompt_tc_latent=dev(z["cond"][None, :P]), prompt_codes=dev(z["prefix"][None]))
+    assert np.array_equal(got[0].cpu().numpy(), z["codes"])
+    # a ragged batch: the fixture's sequence beside a shorter one with another prompt of the same length
+    rng = np.random.default_rng(9)
+    cond2 = np.maximum(rng.standard_normal((P + 11, 512)), 0).astype(np.float32)
+    pre2 = rng.integers(0, 1024, P).astype(np.int64)
+    cb, _ = pad_stack([z["cond"], cond2])
+    both = tts.native.plm_infer(dev(cb), np.asarray([z["codes"].size, 11], np.int32), prefix_codes=dev(np.stack([z["prefix"], pre2])))
+    assert np.array_equal(both[0].cpu().numpy(), z["codes"])
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("prod")
+    O.enable_torch_kernels()
+    try:
+        assert np.array_equal(both[1, :11].cpu().numpy(), O.plm_infer(sd_p, p, cond2, prefix_codes=pre2))
+    finally:
+        O.disable_torch_kernels()
+    assert not both[1, 11:].any()
+    with pytest.raises(ValueError):
+        tts.plm.infer(dev(z["cond"][None, P:]), prompt_codes=dev(z["prefix"][None]))
+
+
+def test_hifigan_production_length_ragged_and_inference_padding():
+    """Vocoder at C3 size (431 + 187 frames, ragged) against transformers.SpeechT5HifiGan carrying the same weights
+    (stand-in: parity unpinned, speechbrain absent), and speechbrain's `inference_padding` behaviour both ways:
+    padding 5 = the generator applied to the mel with its own edge frames replicated 5x on both sides."""
+    from megatts2_amd import megatts2 as M, synth
+    import dataclasses
+    tr = pytest.importorskip("transformers")
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("prod")
+    tts = model("prod")
+    rng = np.random.Generator(np.random.PCG64(78))
+    mels = [synth.make_utterance(rng, 2, T, T).prompt_mel for T in (431, 187)]
+    tcfg = tr.SpeechT5HifiGanConfig(model_in_dim=h.in_dim, upsample_initial_channel=h.upsample_initial_channel,
+                                    upsample_rates=h.upsample_rates, upsample_kernel_sizes=h.upsample_kernel_sizes,
+                                    resblock_kernel_sizes=h.resblock_kernel_sizes,
+                                    resblock_dilation_sizes=h.resblock_dilation_sizes,
+                                    leaky_relu_slope=h.leaky_relu_slope, normalize_before=False)
+    ref = tr.SpeechT5HifiGan(tcfg).eval()
+    full = {k: torch.from_numpy(v) for k, v in sd_h.items()}
+    full["mean"], full["scale"] = torch.zeros(h.in_dim), torch.ones(h.in_dim)
+    ref.load_state_dict(full, strict=True)
+    mel, ln = pad_stack(mels)
+    wav = tts.hifi_gan.decode_batch(dev(mel).transpose(1, 2).contiguous(), mel_lens=ln).cpu().numpy()
+    for i, m in enumerate(mels):
+        with torch.no_grad():
+            want = ref(torch.from_numpy(m)).numpy()
+        n = m.shape[0] * h.hop
+        assert O.rel_l2(wav[i, 0, :n], want) < NORTH_STAR
+        assert not wav[i, 0, n:].any()
+    # inference_padding = 5 (speechbrain's default): tiny model, both ways against the oracle
+    (gt, pt, at, ht), (_, _, _, sd_ht) = synth_models("tiny")
+    hp = dataclasses.replace(ht, inference_padding=5)
+    voc = M.HIFIGAN(hp, sd_ht)
+    small = [synth.make_utterance(rng, 2, T, T).prompt_mel for T in (23, 9, 1)]
+    mel, ln = pad_stack(small)
+    wav = voc.decode_batch(dev(mel).transpose(1, 2).contiguous(), mel_lens=ln).cpu().numpy()
+    assert wav.shape == (3, 1, (23 + 10) * ht.hop)
+    for i, m in enumerate(small):
+        want = O.hifigan(sd_ht, ht, np.pad(m, ((5, 5), (0, 0)), mode="edge"))
+        assert want.size == (m.shape[0] + 10) * ht.hop
+        assert O.rel_l2(wav[i, 0, :want.size], want) < NORTH_STAR
+        assert not wav[i, 0, want.size:].any()
+        plain = tiny_voc().decode_batch(dev(m.T[None].copy())).cpu().numpy()[0, 0]
+        assert O.rel_l2(plain, O.hifigan(sd_ht, ht, m)) < NORTH_STAR      # padding 0: plain forward
+
+
+def tiny_voc():
+    return model("tiny").hifi_gan
+
+
+def test_index_range_errors_instead_of_out_of_bounds_reads(tiny_batch):
+    """nn.Embedding / F.embedding raise IndexError in the reference; here an out-of-range phone id or prosody code is
+    reported as an error by the call that received it (never used as a gather offset), and the handle stays usable."""
+    from megatts2_amd.runtime import NativeError
+    tts = model("tiny")
+    (g, *_), _ = synth_models("tiny")
+    z = tiny_batch[0]
+    phone, mel = z["phone"][None].copy(), dev(z["prompt_mel"][None])
+    bad = phone.copy()
+    bad[0, 3] = g.mrte.phone_vocab_size
+    with pytest.raises(NativeError, match="phone id"):
+        tts.native.tc_latent(dev(bad), mel)
+    bad[0, 3] = -1
+    with pytest.raises(NativeError, match="phone id"):
+        tts.synthesize(dev(bad), mel, forced_durations=z["forced_dur"][None])
+    padded = np.concatenate([phone, np.full((1, 4), 10 ** 6, np.int64)], axis=1)      # garbage BEYOND the true length is fine
+    ok = tts.native.tc_latent(dev(padded), mel, phone_lens=np.asarray([phone.shape[1]], np.int32)).cpu().numpy()
+    assert O.rel_l2(ok[0, :phone.shape[1]], z["tc_latent"]) < TIGHT
+    codes = z["p_codes"][None].copy()
+    codes[0, 1] = g.vqpe.vq_bins
+    with pytest.raises(NativeError, match="prosody code"):
+        tts.synthesize(dev(phone), mel, forced_durations=z["forced_dur"][None], forced_codes=dev(codes))
+    with pytest.raises(NativeError, match="prosody code"):
+        tts.generator.vqpe.vq.decode(dev(codes[None]))
+    with pytest.raises(NativeError, match="prompt prosody code"):
+        tts.native.plm_infer(dev(z["plm_cond"][None]), np.asarray([1], np.int32),
+                             prefix_codes=dev(np.full((1, z["plm_cond"].shape[0] - 1), 5000, np.int64)))
+    out, lens = tts.synthesize(dev(phone), mel, forced_durations=z["forced_dur"][None])
+    assert O.rel_l2(out[0, :lens[0]].cpu().numpy(), z["mel"]) < NORTH_STAR
+
+
+def test_handles_threads_and_streams_do_not_interfere(tiny_batch):
+    """Library hygiene: (a) two handles driven from two host threads at once, each with its own options; (b) one
+    handle called from two threads (serialised by the handle) and on two different streams back to back (the second
+    call waits for the first one's end before reusing the arena) - every result equals the single-threaded one."""
+    import threading
+    from megatts2_amd import megatts2 as M
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("tiny")
+    tts1 = model("tiny")
+    tts2 = M.Megatts(models=(M.MegaG(g, sd_g), M.MegaPLM(p, sd_p), M.MegaADM(a, sd_a)), hifi_gan=M.HIFIGAN(h, sd_h))
+    tts2.native.set_option("ar_groups", 1)
+    tts2.native.set_option("splitk", 0)
+    assert tts1.native.get_option("ar_groups") == 2 and tts2.native.get_option("ar_groups") == 1   # per handle, no globals
+    phone, pl = pad_stack([z["phone"] for z in tiny_batch])
+    mel, ml = pad_stack([z["prompt_mel"] for z in tiny_batch])
+    dur, _ = pad_stack([z["forced_dur"] for z in tiny_batch])
+    dphone, dmel = dev(phone), dev(mel)
+    want, _ = tts1.synthesize(dphone, dmel, pl, ml, forced_durations=dur)
+    want = want.cpu().numpy()
+    res, errs = {}, []
+
+    def work(tag, tts, reps):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for r in range(reps):
+                    out, _ = tts.synthesize(dphone, dmel, pl, ml, forced_durations=dur)
+                s.synchronize()
+                res[tag] = out.cpu().numpy()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=("h1", tts1, 3)), threading.Thread(target=work, args=("h2", tts2, 3)),
+          threading.Thread(target=work, args=("h1b", tts1, 3))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for tag in ("h1", "h2", "h1b"):
+        assert O.rel_l2(res[tag], want) < 2e-6, tag
+    # one handle, two streams, no host synchronisation in between
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        o1, _ = tts1.synthesize(dphone, dmel, pl, ml, forced_durations=dur)
+    with torch.cuda.stream(s2):
+        o2, _ = tts1.synthesize(dphone[:2], dmel[:2], pl[:2], ml[:2], forced_durations=dur[:2])
+    torch.cuda.synchronize()
+    assert O.rel_l2(o1.cpu().numpy(), want) < 2e-6
+    assert O.rel_l2(o2.cpu().numpy()[:, :want.shape[1]], want[:2, :o2.shape[1]]) < 2e-6
+    tts2.native.close()
+
+
+def test_workspace_query_bounds_the_arena():
+    """mt2_workspace_query is an upper bound of what a synthesize_batch call of that geometry really takes, and a
+    reserved arena is not grown by the call."""
+    from megatts2_amd import megatts2 as M, synth
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("tiny")
+    for B, Np, Tp, Tm, voc in ((3, 12, 60, 50, True), (1, 5, 33, 17, False), (6, 9, 97, 61, True)):
+        tts = M.Megatts(models=(M.MegaG(g, sd_g), M.MegaPLM(p, sd_p), M.MegaADM(a, sd_a)), hifi_gan=M.HIFIGAN(h, sd_h))
+        nat = tts.native
+        utts = synth.make_batch(synth.Shape("t", B, Np, Tp, Tm), seed=3, phone_vocab=g.mrte.phone_vocab_size)
+        bound = nat.workspace_query(B, Np, Tp, Tm, run_plm=True, vocoder=voc)
+        nat.workspace_reserve(bound)
+        cap0 = nat.memory()[1]
+        phone, pl = pad_stack([u.phone for u in utts])
+        mel, ml = pad_stack([u.prompt_mel for u in utts])
+        dur, _ = pad_stack([u.durations for u in utts])
+        nat.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, vocoder=voc, tm_cap=Tm)
+        torch.cuda.synchronize()
+        assert nat.workspace_high_water() <= bound, (B, Np, Tp, Tm, nat.workspace_high_water(), bound)
+        assert nat.memory()[1] == cap0                                    # no allocation on the hot path
+        nat.close()
+
+
+def test_megatts_seven_argument_constructor_writes_wav(tmp_path, monkeypatch):
+    """The import-swap of INTEGRATION.md: `Megatts(g_ckpt, g_config, plm_ckpt, plm_config, adm_ckpt, adm_config,
+    symbol_table)` (reference models/megatts2.py:296-323) builds the vocoder from a local speechbrain model directory
+    and `forward` writes test.wav = vocoded prompt + generated audio (:370-375), inference padding included."""
+    import dataclasses
+    import yaml
+    from megatts2_amd import audio_io as A, config as C, megatts2 as M
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("tiny")
+    ck = {}
+    for name, pre, sd in (("g", "G.", sd_g), ("plm", "plm.", sd_p), ("adm", "adm.", sd_a)):
+        ck[name] = str(tmp_path / f"{name}.ckpt")
+        torch.save({"state_dict": {pre + k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}}, ck[name])
+    gy = {"model": {"G": {"class_path": "models.megatts2.MegaG", "init_args": {
+        "mrte": {"class_path": "modules.mrte.MRTE", "init_args": dict(dataclasses.asdict(g.mrte), mel_activation="ReLU", dropout=0.1)},
+        "vqpe": {"class_path": "modules.vqpe.VQProsodyEncoder", "init_args": dict(dataclasses.asdict(g.vqpe), activation="ReLU")},
+        "kernel_size": g.kernel_size, "activation": "ReLU", "hidden_size": g.hidden_size,
+        "decoder_n_stack": g.decoder_n_stack, "decoder_n_block": g.decoder_n_block}}}}
+    cfgs = {"g": gy, "plm": {"model": {"plm": {"init_args": dict(dataclasses.asdict(p), dropout=0.1)}}},
+            "adm": {"model": {"adm": {"init_args": dict(dataclasses.asdict(a), dropout=0.1)}}}}
+    ypath = {}
+    for k, tree in cfgs.items():
+        ypath[k] = str(tmp_path / f"config_{k}.yaml")
+        open(ypath[k], "w").write(yaml.safe_dump(tree))
+    voc = tmp_path / "tts-hifigan-libritts-16kHz"
+    voc.mkdir()
+    raw = {}
+    for k, v in sd_h.items():
+        base, leaf = k.rsplit(".", 1)
+        raw[f"{base.replace('upsampler.', 'ups.')}.conv.{leaf}"] = torch.from_numpy(v)     # weight norm already removed
+    torch.save(raw, str(voc / "generator.ckpt"))
+    (voc / "hyperparams.yaml").write_text(yaml.safe_dump({
+        "in_channels": 80, "out_channels": 1, "resblock_type": "1", "upsample_initial_channel": h.upsample_initial_channel,
+        "upsample_factors": h.upsample_rates, "upsample_kernel_sizes": h.upsample_kernel_sizes,
+        "resblock_kernel_sizes": h.resblock_kernel_sizes, "resblock_dilation_sizes": h.resblock_dilation_sizes,
+        "inference_padding": 5, "cond_channels": 0, "conv_post_bias": True}))
+    monkeypatch.setenv("MEGATTS2_HIFIGAN_DIR", str(voc))
+    rng = np.random.default_rng(6)
+    n = 5000
+    y = (0.4 * np.sin(2 * np.pi * 300.0 * np.arange(n) / 16000.0) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    wdir = tmp_path / "prompts"
+    wdir.mkdir()
+    A.write_wav(str(wdir / "p0.wav"), y, 16000, "PCM_S16")
+    tts = M.Megatts(ck["g"], ypath["g"], ck["plm"], ypath["plm"], ck["adm"], ypath["adm"], None)
+    tts.eval()
+    assert tts.hifi_gan is not None and tts.hifi_gan.cfg.inference_padding == 5
+    phone = rng.integers(0, g.mrte.phone_vocab_size, 5)
+    out_wav = str(tmp_path / "test.wav")
+    mel, lens, aux = tts(str(wdir), None, phone_tokens=phone, out_path=out_wav)
+    prompt = O.mel_spectrogram(A.load_audio(str(wdir / "p0.wav")))
+    ref = O.synthesize(sd_g, sd_p, sd_a, g, p, a, phone.astype(np.int64), prompt)
+    assert lens[0] == ref["mel"].shape[0] and O.rel_l2(mel[0, :lens[0]].cpu().numpy(), ref["mel"]) < NORTH_STAR
+    audio, sr = A.read_wav(out_wav)
+    want_gen = O.hifigan(sd_h, h, np.pad(ref["mel"], ((5, 5), (0, 0)), mode="edge"))
+    assert sr == 16000 and audio.size == (prompt.shape[0] + 10 + int(lens[0]) + 10) * h.hop
+    assert O.rel_l2(audio[-want_gen.size:], want_gen) < 5e-3       # mel round-off amplified by the (random-weight) vocoder
+
+
+def test_synthesize_list_and_sharded_world1_rccl(tiny_batch):
+    """The real `Megatts.synthesize_list` (ragged list -> padded batch) and `dist.synthesize_sharded` on a world-1
+    "nccl" (= RCCL) process group: same mels as the padded-tensor entry point, original order kept."""
+    import socket
+    import torch.distributed as dist
+    from megatts2_amd import dist as D, synth
+    tts = model("tiny")
+    (g, *_), _ = synth_models("tiny")
+    rng = np.random.Generator(np.random.PCG64(17))
+    utts = [synth.make_utterance(rng, n, t, f, g.mrte.phone_vocab_size) for n, t, f in ((7, 40, 29), (3, 19, 11), (11, 70, 35), (1, 17, 4))]
+    mel, lens = tts.synthesize_list(utts)
+    mel = mel.cpu().numpy()
+    for i, u in enumerate(utts):
+        alone, l1 = tts.native.synthesize_batch(dev(u.phone[None]), None, dev(u.prompt_mel[None]), None, forced_dur=u.durations[None])
+        assert lens[i] == l1[0] == int(u.durations.sum())
+        assert O.rel_l2(mel[i, :lens[i]], alone[0, :l1[0]].cpu().numpy()) < 2e-6
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        outs = D.synthesize_sharded(tts, utts)
+        assert len(outs) == len(utts)
+        for i, o in enumerate(outs):
+            assert o.is_cuda and o.shape[0] == lens[i] and O.rel_l2(o.cpu().numpy(), mel[i, :lens[i]]) < 2e-6
+    finally:
+        dist.destroy_process_group()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # One GPU-box session (run through gpurun).  usage: bash tools/gpu_round.sh <mode> [<mode> ...]
 #   tests smoke                      parity suites (-m gpu) and __graft_entry__.smoke()
+#   bench2 pmcstage                  bench.py on C2; per-stage PMC passes (FETCH/WRITE/MFMA) of the default C3 step
 #   bench bench1 bench3 bench5       bench.py on C2 (default) / C1 / C3 / C5
 #   groups thresh splitk             A/B switches of bench.py (AR stream groups, tile thresholds, split-K through LN)
 #   prof prof3 profstage pmc probe   rocprofv3 kernel stats (C2 / C3 / one stage), PMC passes, per-launch PMC probe
@@ -23,7 +24,22 @@ smoke)
   echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log ;;
 bench)
   timeout 900 python bench.py --steps 5 --warmup 2 > gpurun_out/bench.log 2>&1
-  echo "bench rc=$?"; tail -1 gpurun_out/bench.log | cut -c1-1800 ;;
+  echo "bench rc=$?"; tail -1 gpurun_out/bench.log | cut -c1-3500 ;;
+bench2)
+  timeout 900 python bench.py --workload C2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_c2.log 2>&1
+  echo "bench2 rc=$?"; tail -1 gpurun_out/bench_c2.log | cut -c1-1800 ;;
+pmcstage)
+  for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    t=$(echo $c | cut -d" " -f1)
+    rm -rf gpurun_out/pmcs_$t
+    (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcs_$t -o pmc -- python $GRAFT_REPO_ROOT/bench.py --workload ${WL:-C3} --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --stage-markers) > gpurun_out/pmcs_$t.log 2>&1
+    echo "pmcstage $t rc=$?"; tail -1 gpurun_out/pmcs_$t.log | cut -c1-200
+  done
+  F=$(find gpurun_out/pmcs_FETCH_SIZE -name "*counter_collection.csv" | head -1)
+  W=$(find gpurun_out/pmcs_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+  M=$(find gpurun_out/pmcs_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv" | head -1)
+  python tools/pmc_stage_summary.py $F $W $M gpurun_out/pmc_stage_${WL:-C3}.json | tail -60
+  find gpurun_out/pmcs_* -name "*.csv" -size +6M -delete ;;
 bench5)
   timeout 900 python bench.py --workload C5 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_c5.log 2>&1
   echo "bench5 rc=$?"; tail -1 gpurun_out/bench_c5.log | cut -c1-1500 ;;
@@ -60,7 +76,7 @@ bench3)
   echo "bench3 rc=$?"; tail -1 gpurun_out/bench_c3.log | cut -c1-1500 ;;
 prof)
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline) > gpurun_out/prof.log 2>&1
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --stage-markers) > gpurun_out/prof.log 2>&1
   echo "prof rc=$?"; tail -2 gpurun_out/prof.log | cut -c1-400
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/prof_kernel_stats.csv && head -30 "$f"
   find gpurun_out/prof -name "*kernel_trace.csv" -size +8M -delete ;;
@@ -72,7 +88,7 @@ sweep_ar)
   echo "sweep_ar rc=$?"; cat gpurun_out/gemm_sweep_ar.txt ;;
 groups)
   for g in ${GROUPS_LIST:-1 2}; do
-    timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --ar-groups $g > gpurun_out/bench_g$g.log 2>&1
+    timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --opt ar_groups=$g > gpurun_out/bench_g$g.log 2>&1
     echo "groups $g rc=$?"; tail -1 gpurun_out/bench_g$g.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('stage_ms'), d['roofline']['frac'], d['roofline']['gemm_ms_per_step'])"
   done ;;
 probe)
@@ -83,12 +99,13 @@ probe)
   find gpurun_out/probe -name "*.csv" -size +4M -delete ;;
 splitk)
   for w in C2 C3; do for f in "" "--no-splitk"; do
-    timeout 600 python bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-roofline $f > gpurun_out/bench_sk.log 2>&1
+    timeout 600 python bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-roofline ${f:+--opt splitk=0} > gpurun_out/bench_sk.log 2>&1
     echo "splitk $w '$f' rc=$?"; tail -1 gpurun_out/bench_sk.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
   done; done ;;
 thresh)
   for t in 0,0,0 512,1024,32; do
-    timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --thresh $t > gpurun_out/bench_t_$t.log 2>&1
+    IFS=, read a b c <<< "$t"
+    timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --opt t_ks4=$a --opt t_ks2=$b --opt t32=$c > gpurun_out/bench_t_$t.log 2>&1
     echo "thresh $t rc=$?"; tail -1 gpurun_out/bench_t_$t.log | cut -c1-400
   done ;;
 pmc)

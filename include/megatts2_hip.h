@@ -200,7 +200,7 @@ int mt2_synthesize_batch(mt2_model* m, void* stream, const int64_t* phone, const
 /* ---- tuning.  Every switch lives in the handle (no process-global state): two handles do not see each other's
  * settings.  Names: "ar_groups" (1..8, default 2: the sequences of an autoregressive run are dealt into that many
  * independent kernel chains on internal HIP streams that fork from and join back into `stream`; results do not
- * depend on it), "splitk" (1), "lnfuse" (0), "voc_streams" (3), "voc_fused" (1), "force_gemm_config" (-1),
+ * depend on it), "splitk" (1), "lnfuse" (0), "voc_streams" (3), "win_conv" (1), "force_gemm_config" (-1),
  * "t_ks4", "t_ks2", "t32", "t32x32" (tile-choice thresholds).  Unknown names are an error. */
 int mt2_set_option(mt2_model* m, const char* name, int value);
 int mt2_get_option(mt2_model* m, const char* name, int* value);

@@ -633,14 +633,179 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     }
 }
 
+
+// ===================================================================================================
+// v3: WINDOW convolution.  Conv1d("same", k taps, dilation d) over contiguous time-major rows with Cin = 32*QS
+// in {32, 64, 128} and Cout = Cin: the HiFi-GAN resblock convolutions of the narrow stages (A19; 75 % of the
+// vocoder's FLOPs) and every k-tap conv stack of that width.
+//
+// The implicit-GEMM kernels above treat every tap as its own K chunk, i.e. they pull the SAME activation rows
+// through the global->LDS DMA k times: 13-21 FLOP per ingested byte, ingest-bound at 20-60 TF/s for N = 32 / 64.
+// Here a workgroup owns BM output rows x ALL output channels and loads its input WINDOW - rows
+// [m0 + shift0, m0 + shift0 + BM + (k-1)*d) x Cin - into LDS ONCE (one linear DMA, XOR-swizzled like the ring
+// slots); the K loop then walks (tap, 32-channel slice) chunks whose A fragments are ds_read from the window at a
+// row offset of tap*d, and only the weight chunks (Cout x 32 floats each, L2-resident, shared by all workgroups)
+// stream through the ring.  Ingest per output row drops from k*Cin*4 to Cin*4 bytes (+ weights): the loop is
+// MFMA-bound.  Same arithmetic as the implicit GEMM: the k index order is tap-major, 32-wide chunks, identical
+// fma chain per output element.
+template <int QS, int BM, int BN, int WGM, int WGN, int NST, int PRO>
+__global__ __launch_bounds__(WGM* WGN * 64) void conv_win_f32_kernel(GemmP p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int BPIECES = BN / 8;                       // 1-KiB pieces of one weight chunk (BN rows x 32 floats)
+    constexpr int B_IT = (BPIECES + NW - 1) / NW;         // per wave; waves without a real piece issue a dummy one
+    constexpr int STAGE = B_IT * NW * 256;                // floats per ring stage (dummy slots included)
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * B_IT < 64 && BN == 32 * QS, "config");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int taps = p.taps, dil = p.dil;
+    const int WR = BM + (taps - 1) * dil, WRp = (WR + 7) & ~7;     // window rows (padded to whole DMA pieces)
+    float* ring = smem;
+    float* win = smem + NST * STAGE;                                // [QS][WRp][32], slot-swizzled rows
+
+    const int ntm = (p.M + BM - 1) / BM;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, qq = ntm >> 3, rr = ntm & 7;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);   // contiguous run per XCD
+    const int m0 = tile * BM;
+
+    const float* __restrict__ X = p.X;
+    const float* __restrict__ W = p.W;
+    const long long zoff_x = (const float*)g_zero16 - X;
+    const long long zoff_w = (const float*)g_zero16 - W;
+    const int ldx = p.ldx, Rx = p.Rx, Kt = p.K, ldw = p.ldw;
+    const int lrow = lane >> 3;
+
+    // ---- the input window, once: piece pc = (slice q, 8 rows r8*8..+7); lane -> (row r8*8 + lrow, physical slot lane & 7)
+    {
+        const int ppq = WRp >> 3, pieces = QS * ppq;
+        const int row_first = m0 + p.shift0;
+        for (int pc = wave; pc < pieces; pc += NW) {
+            const int q = pc / ppq, r8 = pc - q * ppq;
+            const int row = r8 * 8 + lrow;
+            const int grow = row_first + row;
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);
+            const bool ok = (row < WR) & ((unsigned)grow < (unsigned)Rx);
+            const long long off = ok ? (long long)grow * ldx + q * 32 + slot * 4 : zoff_x;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                             (__attribute__((address_space(3))) void*)(win + (q * WRp + r8 * 8) * 32), 16, 0, 0);
+        }
+    }
+    // ---- weight chunks through the ring: chunk c = K columns [32c, 32c + 32) = (tap c / QS, slice c % QS)
+    const int nk = (Kt + BK - 1) / BK;
+    long long wofs[B_IT];
+    int wslot[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int pc = j * NW + wave;
+        const int n = pc * 8 + lrow;
+        wofs[j] = (pc < BPIECES && n < p.N) ? (long long)n * ldw : -1;
+        wslot[j] = ((lane & 7) ^ ((n >> 1) & 7)) * 4;
+    }
+    auto issue = [&](int c, int st) {
+        float* Bs = ring + st * STAGE + wave * 256;
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const int k = c * BK + wslot[j];
+            const bool ok = (k < Kt) & (wofs[j] >= 0);
+            const long long off = ok ? wofs[j] + k : zoff_w;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + off),
+                                             (__attribute__((address_space(3))) void*)(Bs + j * NW * 256), 16, 0, 0);
+        }
+    };
+    constexpr bool PRET = TM * TN <= 2;
+    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
+    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, 0, m0 + wm * WTM, wn * WTN, lane);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nk) issue(st, st);
+
+    const float pro_slope = p.pro_slope;
+    const int half = lane >> 5;
+    const unsigned lds_ring = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)ring;
+    const unsigned lds_win = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)win;
+    const unsigned b_lane = lds_ring + ((wn * WTN + (lane & 31)) * BK) * 4;
+    const int swzb = (lane >> 1) & 7;
+    unsigned koffb[BK / 8];
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) koffb[kk] = (unsigned)(((2 * kk + half) ^ swzb) * 16);
+    const int arow0 = wm * WTM + (lane & 31);
+
+    int st = 0, tap = 0, q = 0;
+    for (int c = 0; c < nk; ++c) {
+        if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * B_IT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int arow = arow0 + tap * dil;                        // window row of this lane's output row, this tap
+        const int swza = (arow >> 1) & 7;                          // (+ i*32 rows leave the swizzle unchanged)
+        const unsigned sa = lds_win + (unsigned)((q * WRp + arow) * BK) * 4;
+        const unsigned sb = b_lane + (unsigned)st * (STAGE * 4);
+        unsigned koffa[BK / 8];
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) koffa[kk] = (unsigned)(((2 * kk + half) ^ swza) * 16);
+        f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128(sa + koffa[0] + i * 32 * BK * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128(sb + koffb[0] + j * 32 * BK * 4);
+        if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 1 < BK / 8) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read_b128(sa + koffa[kk + 1] + i * 32 * BK * 4);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128(sb + koffb[kk + 1] + j * 32 * BK * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (PRO != ACT_NONE) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fa[cur][i][e] = apply_act<PRO>(fa[cur][i][e], pro_slope);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][e], fb[cur][j][e], acc[i][j], 0, 0, 0);
+        }
+        st = st + 1 == NST ? 0 : st + 1;
+        if (++q == QS) { q = 0; ++tap; }
+    }
+    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, 0, m0 + wm * WTM, wn * WTN, lane);
+    else epilogue<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side: tile-configuration choice and launch
 
 struct TileCfg {
     int bm, bn, threads;
-    size_t lds;
+    size_t lds;               // window configurations: the ring part only (the window depends on taps and dilation)
     const char* name;
     void (*fn[4])(GemmP);     // indexed by the prologue: none / relu / leaky relu / LayerNorm (nullptr: no variant)
+    int win_qs = 0;           // > 0: window convolution for Cin = Cout = 32 * win_qs
 };
 
 #define MT2_CFG(BM_, BN_, WM_, WN_)                                                                    \
@@ -663,6 +828,12 @@ struct TileCfg {
       "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "_s2",                                             \
       { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_RELU>, \
         gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_LRELU>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, PRO_LN> } }
+
+#define MT2_WIN(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
+    { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((BN_ / 8 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 256) * sizeof(float), \
+      "win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                       \
+      { conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_NONE>, conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
+        conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr }, QS_ }
 
 static const TileCfg kCfgs[] = {
     // v1: register-staged double buffer (kept for A/B runs and as the reference implementation)
@@ -699,6 +870,11 @@ static const TileCfg kCfgs[] = {
     MT2_DMAK(128, 64, 4, 2, 2, 2),  // 27: 16 waves (2 K groups of 4x2), 96 KiB
     MT2_DMAL(32, 32, 1, 1, 8),      // 28: 8 waves = 8 K groups of one wave, 128 KiB: the shortest K chain (M*N <= 256 tiles)
     MT2_DMAK(32, 32, 1, 1, 4, 3),   // 29: 4 waves, 96 KiB
+    // v3: window convolutions (Cin = Cout in {32, 64, 128}); ring = 3 stages of max(BN / 8, waves) KiB
+    MT2_WIN(1, 256, 32, 8, 1, 3),    // 30: 8 waves, one 32x32 tile each; 24 + 40 KiB -> 2 workgroups per CU
+    MT2_WIN(2, 256, 64, 8, 1, 3),    // 31: 8 waves, 32x64 each; 24 + 80 KiB
+    MT2_WIN(4, 128, 128, 4, 2, 3),   // 32: 8 waves, 32x64 each; 48 + 92 KiB
+    MT2_WIN(2, 128, 64, 4, 2, 3),    // 33: 8 waves, 32x32 each; 24 + 46 KiB -> 2 workgroups per CU
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -773,8 +949,18 @@ int gemm_trace_collect(EngineOpts& o, int cap, const char** names, int64_t* laun
 //   32x64 K-split tiles while they fit one per CU; 64x64 K-split tiles while THEY fit one (k4) / two (k2) per CU;
 //   a big 8-wave tile when its tile count just fills the chip once (200..256); otherwise plain 64x64 tiles
 //   (three workgroups per CU, de-phased) and the 8-wave tiles for the conv stacks and the vocoder.
+// window convolution: plain "same" conv over contiguous rows, square, narrow (see conv_win_f32_kernel)
+static bool win_eligible(const GemmP& p) {
+    return p.taps >= 2 && !p.rowbase && p.a_mul == 1 && p.groups == 1 && p.N == p.Cin &&
+           (p.Cin == 32 || p.Cin == 64 || p.Cin == 128) && (p.taps - 1) * p.dil <= 64 && p.pro_act != PRO_LN;
+}
 static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_out) {
     int bi = 12;                                                        // dma64x64_2x2_s3
+    if (o.win_conv && win_eligible(p) && !(o.force_cfg >= 0 && o.force_cfg < kNumCfgs)) {
+        bi = p.Cin == 32 ? 30 : (p.Cin == 64 ? 31 : 32);
+        *idx_out = bi;
+        return &kCfgs[bi];
+    }
     const long long t32 = (long long)((p.M + 31) / 32) * ((p.N + 63) / 64) * p.groups;
     const long long t32x32 = (long long)((p.M + 31) / 32) * ((p.N + 31) / 32) * p.groups;
     const long long t64 = (long long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.groups;
@@ -803,7 +989,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     int idx = 0;
     const TileCfg* c = choose_cfg(p, o, &idx);
     if (p.pro_act < 0 || p.pro_act > PRO_LN) return hipErrorInvalidValue;
-    size_t lds = c->lds;
+    size_t lds = c->lds, lds_attr = 0;
     if (p.pro_act == PRO_LN) {
         if (p.taps != 1 || p.K > 1024 || !p.ln_g || !p.ln_b) return hipErrorInvalidValue;
         // Measured (C2 / C3, profiles/r01_lnfuse_ab.txt): the prologue costs ~2 us of row statistics plus ~30 % of the
@@ -814,12 +1000,20 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
         const int ks = c->threads / 64 / ((c->bm / 32) * (c->bn / 32));     // one 32x32 tile per wave
         lds = c->lds + (size_t)ks * 2 * 256 * sizeof(float) + (size_t)c->bm * 2 * sizeof(float);
     }
+    if (c->win_qs) {
+        if (!win_eligible(p) || p.Cin != 32 * c->win_qs) return hipErrorInvalidValue;
+        const int wrp = (c->bm + (p.taps - 1) * p.dil + 7) & ~7;
+        lds = c->lds + (size_t)c->win_qs * wrp * BK * sizeof(float);
+    }
     void (*fn)(GemmP) = c->fn[p.pro_act];
-    if (!g_attr_done[idx][p.pro_act]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        g_attr_done[idx][p.pro_act] = true;
+    if (!g_attr_done[idx][p.pro_act] || c->win_qs) {
+        if (c->win_qs) lds_attr = c->lds + (size_t)c->win_qs * ((c->bm + 64 + 7) & ~7) * BK * sizeof(float);
+        if (!g_attr_done[idx][p.pro_act]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c->win_qs ? lds_attr : lds));
+            if (e != hipSuccess) return e;
+            g_attr_done[idx][p.pro_act] = true;
+        }
     }
     const int tiles = ((p.M + c->bm - 1) / c->bm) * ((p.N + c->bn - 1) / c->bn);
     dim3 grid(tiles, 1, p.groups), block(c->threads);

@@ -50,7 +50,7 @@ struct EngineOpts {
     bool splitk = true;          // split-K through the LayerNorm in the AR layers
     bool lnfuse = false;         // LayerNorm as a GEMM prologue in the AR layers (measured slower, profiles/r01_lnfuse_ab.txt)
     int voc_streams = 3;         // resblock chains of a vocoder stage in flight (1 = serial)
-    bool voc_fused = true;       // fused LDS-resident resblock kernel for the narrow vocoder stages (hifigan_fused.hip)
+    bool win_conv = true;        // window-convolution kernel for narrow square convs (Cin = Cout in {32, 64, 128})
     bool markers = false;        // a named no-op kernel at every stage boundary: lets tools/pmc_stage_summary.py attribute
                                  // the rocprofv3 --pmc rows of one step to stages (measurement only)
     bool trace_on = false;       // HIP events around every GEMM launch (measurement only)

@@ -314,6 +314,16 @@ class Megatts:
                 except FileNotFoundError as e:
                     warnings.warn(f"no vocoder: {e}")
         self.hifi_gan = hifi_gan
+        self.native = NativeModel(self.generator.cfg, self.plm.cfg, self.adm.cfg,
+                                  hifi_gan.cfg if hifi_gan else None, self.generator.state, self.plm.state,
+                                  self.adm.state, hifi_gan.state if hifi_gan else None)
+        for part in (self.generator, self.plm, self.adm) + ((hifi_gan,) if hifi_gan else ()):
+            part._native = self.native
+        self.lr = LengthRegulator(HIFIGAN_HOP_LENGTH, 16000, (HIFIGAN_HOP_LENGTH / HIFIGAN_SR * 1000), self.native)
+        self.symbol_table = symbol_table
+        self.tt = None
+        self.ttc = None
+
     def eval(self):
         return self
 

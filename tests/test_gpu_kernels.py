@@ -32,7 +32,10 @@ def rt():
     return runtime
 
 
-@pytest.mark.parametrize("cfg", list(range(30)) + [-1])
+N_GEMM_CFGS = 30          # general tile configurations (indices 30+ are the window-convolution kernels)
+
+
+@pytest.mark.parametrize("cfg", list(range(N_GEMM_CFGS)) + [-1])
 @pytest.mark.parametrize("M,N,K", [(77, 96, 100), (300, 512, 256), (128, 32, 64), (33, 1024, 512)])
 def test_gemm_linear_all_tile_configs(rt, cfg, M, N, K):
     rng = np.random.default_rng(M * 7 + N + K)
@@ -58,7 +61,7 @@ def test_gemm_is_transpose_detecting(rt):
 
 @pytest.mark.parametrize("cfg", [-1, 3, 8, 11, 13, 15, 18, 20, 21, 23, 28])
 @pytest.mark.parametrize("k,dil,cin,cout", [(3, 1, 80, 64), (5, 1, 64, 96), (17, 1, 32, 32), (11, 5, 32, 32),
-                                            (7, 3, 64, 64), (5, 1, 20, 96)])
+                                            (7, 3, 64, 64), (5, 1, 20, 96), (11, 3, 128, 128), (3, 5, 128, 128)])
 def test_gemm_conv1d_with_gaps(rt, k, dil, cin, cout, cfg):
     """Conv1d 'same' over gap-padded rows == per-utterance zero-padded conv (batch-1 semantics)."""
     rng = np.random.default_rng(k * 100 + dil)
@@ -86,6 +89,49 @@ def test_gemm_conv1d_with_gaps(rt, k, dil, cin, cout, cfg):
         ref = O.conv1d(O.leaky_relu(u[:, :cin], 0.1), w, b, padding=((k - 1) // 2) * dil, dilation=dil)
         assert rel(out[o:o + n], ref) < 3e-6
     assert not out[valid == 0].any()                                             # gap rows stay zero
+
+
+@pytest.mark.parametrize("k,dil,C,cfg", [(3, 1, 32, 30), (7, 3, 32, 30), (11, 5, 32, 30), (11, 1, 32, -1),
+                                         (3, 5, 64, 31), (7, 1, 64, 31), (11, 5, 64, 33), (11, 3, 64, -1),
+                                         (3, 3, 128, 32), (7, 5, 128, 32), (11, 1, 128, -1), (5, 1, 64, 33)])
+@pytest.mark.parametrize("pro", ["none", "relu", "lrelu"])
+def test_window_conv_kernels(rt, k, dil, C, cfg, pro):
+    """The window-convolution kernels (Cin = Cout in {32, 64, 128}: the input rows of a workgroup are loaded into
+    LDS once and every tap reads them at a row offset) against the float64 conv, with residual, bias, row mask, all
+    three prologues, several tiles of rows, utterance gaps and a buffer that starts / ends inside the halo."""
+    rng = np.random.default_rng(k * 1000 + dil * 10 + C)
+    lens = [700, 1, 300, 33]                       # > 2 row tiles for every BM; a 1-row utterance
+    G = ((k - 1) // 2) * dil
+    off, rows = [], 0                              # NO leading gap: the first window reaches below row 0 (zero fill)
+    for n in lens:
+        off.append(rows)
+        rows += n + G
+    rows -= G                                      # and none at the end: the last window runs past the buffer
+    X = np.zeros((rows, C), np.float32)
+    valid = np.zeros(rows, np.int32)
+    utts = []
+    for o, n in zip(off, lens):
+        u = rng.standard_normal((n, C)).astype(np.float32)
+        X[o:o + n] = u
+        valid[o:o + n] = 1
+        utts.append(u)
+    w = (rng.standard_normal((C, C, k)) / math.sqrt(C * k)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    R = rng.standard_normal((rows, C)).astype(np.float32)
+    wp = np.ascontiguousarray(w.transpose(0, 2, 1).reshape(C, k * C))
+    act = {"none": rt.ACT_NONE, "relu": rt.ACT_RELU, "lrelu": rt.ACT_LRELU}[pro]
+    out = rt.op_gemm(dev(X), dev(wp), dev(b), dev(R), valid=dev(valid), shift0=-G, taps=k, dil=dil, Cin=C, pro_act=act,
+                     pro_slope=0.1, epi_act=rt.ACT_LRELU, force_cfg=cfg).cpu().numpy()
+    f = {"none": lambda v: v, "relu": O.relu, "lrelu": lambda v: O.leaky_relu(v, 0.1)}[pro]
+    for o, n, u in zip(off, lens, utts):
+        ref = O.leaky_relu(O.conv1d(f(u), w, b, padding=G, dilation=dil), 0.1) + R[o:o + n]
+        assert rel(out[o:o + n], ref) < 3e-6
+    assert not out[valid == 0].any()
+    # same numbers as the implicit-GEMM engine (same k order within a 32-wide chunk): bit-identical is not required,
+    # round-off level agreement is
+    gen = rt.op_gemm(dev(X), dev(wp), dev(b), dev(R), valid=dev(valid), shift0=-G, taps=k, dil=dil, Cin=C, pro_act=act,
+                     pro_slope=0.1, epi_act=rt.ACT_LRELU, force_cfg=12).cpu().numpy()
+    assert rel(out, gen) < 2e-6
 
 
 @pytest.mark.parametrize("cfg", [-1, 3, 9, 12, 14, 19, 22, 24, 29])

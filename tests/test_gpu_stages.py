@@ -665,7 +665,7 @@ def test_hifigan_production_length_ragged_and_inference_padding():
     (gt, pt, at, ht), (_, _, _, sd_ht) = synth_models("tiny")
     hp = dataclasses.replace(ht, inference_padding=5)
     voc = M.HIFIGAN(hp, sd_ht)
-    small = [synth.make_utterance(rng, 2, T, T).prompt_mel for T in (23, 9, 1)]
+    small = [synth.make_utterance(rng, 1, T, T).prompt_mel for T in (23, 9, 1)]
     mel, ln = pad_stack(small)
     wav = voc.decode_batch(dev(mel).transpose(1, 2).contiguous(), mel_lens=ln).cpu().numpy()
     assert wav.shape == (3, 1, (23 + 10) * ht.hop)
@@ -857,7 +857,8 @@ def test_synthesize_list_and_sharded_world1_rccl(tiny_batch):
     mel, lens = tts.synthesize_list(utts)
     mel = mel.cpu().numpy()
     for i, u in enumerate(utts):
-        alone, l1 = tts.native.synthesize_batch(dev(u.phone[None]), None, dev(u.prompt_mel[None]), None, forced_dur=u.durations[None])
+        alone, l1 = tts.native.synthesize_batch(dev(u.phone[None]), None, dev(u.prompt_mel[None]), None, forced_dur=u.durations[None],
+                                                forced_codes=dev(u.p_codes[None]), run_plm=False)   # records carry p_codes -> forced
         assert lens[i] == l1[0] == int(u.durations.sum())
         assert O.rel_l2(mel[i, :lens[i]], alone[0, :l1[0]].cpu().numpy()) < 2e-6
     with socket.socket() as s:

@@ -29,16 +29,20 @@ bench2)
   timeout 900 python bench.py --workload C2 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_c2.log 2>&1
   echo "bench2 rc=$?"; tail -1 gpurun_out/bench_c2.log | cut -c1-1800 ;;
 pmcstage)
+  # the step is profiled in two halves (a full C3 step exceeds the profiler's dispatch limit with TCC counters)
+  SPECS=""
   for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
     t=$(echo $c | cut -d" " -f1)
-    rm -rf gpurun_out/pmcs_$t
-    (cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcs_$t -o pmc -- python $GRAFT_REPO_ROOT/bench.py --workload ${WL:-C3} --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --stage-markers) > gpurun_out/pmcs_$t.log 2>&1
-    echo "pmcstage $t rc=$?"; tail -1 gpurun_out/pmcs_$t.log | cut -c1-200
+    for half in a b; do
+      if [ $half = a ]; then ARGS="--workload C2"; KEEP="mrte,adm"; else ARGS="--workload C3 --skip-adm"; KEEP="vqpe,regulate,plm,decoder,vocoder"; fi
+      rm -rf gpurun_out/pmcs_${t}_$half
+      (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcs_${t}_$half -o pmc -- python $GRAFT_REPO_ROOT/bench.py $ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --stage-markers) > gpurun_out/pmcs_${t}_$half.log 2>&1
+      echo "pmcstage $t $half rc=$?"; tail -1 gpurun_out/pmcs_${t}_$half.log | cut -c1-160
+      f=$(find gpurun_out/pmcs_${t}_$half -name "*counter_collection.csv" | head -1)
+      [ -n "$f" ] && SPECS="$SPECS $f:$KEEP"
+    done
   done
-  F=$(find gpurun_out/pmcs_FETCH_SIZE -name "*counter_collection.csv" | head -1)
-  W=$(find gpurun_out/pmcs_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-  M=$(find gpurun_out/pmcs_SQ_VALU_MFMA_BUSY_CYCLES -name "*counter_collection.csv" | head -1)
-  python tools/pmc_stage_summary.py $F $W $M gpurun_out/pmc_stage_${WL:-C3}.json | tail -60
+  python tools/pmc_stage_summary.py $SPECS gpurun_out/pmc_stage_C3.json | tail -70
   find gpurun_out/pmcs_* -name "*.csv" -size +6M -delete ;;
 bench5)
   timeout 900 python bench.py --workload C5 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_c5.log 2>&1
@@ -86,6 +90,13 @@ sweep)
 sweep_ar)
   timeout 600 python tools/gemm_sweep.py ar > gpurun_out/gemm_sweep_ar.txt 2>&1
   echo "sweep_ar rc=$?"; cat gpurun_out/gemm_sweep_ar.txt ;;
+opts)
+  # A/B of handle options on the default workload: OPTS="win_conv=0 ar_groups=1 ..." (one run per entry; "-" = defaults)
+  for o in ${OPTS:--}; do
+    if [ "$o" = "-" ]; then A=""; else A=$(echo $o | tr ',' '\n' | sed 's/^/--opt /' | tr '\n' ' '); fi
+    timeout 600 python bench.py --workload ${WL:-C3} --steps 3 --warmup 1 --no-cpu-baseline $A > gpurun_out/bench_opt_$o.log 2>&1
+    echo "opts $o rc=$?"; tail -1 gpurun_out/bench_opt_$o.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('stage_ms')); print('   ', [(r['config'], r['launches'], r['ms'], r['tflops']) for r in d['roofline']['per_config']])"
+  done ;;
 groups)
   for g in ${GROUPS_LIST:-1 2}; do
     timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --opt ar_groups=$g > gpurun_out/bench_g$g.log 2>&1

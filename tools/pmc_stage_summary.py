@@ -1,6 +1,11 @@
 """Attribute rocprofv3 --pmc counter rows of ONE bench step to the stages of the path.
 
-    python tools/pmc_stage_summary.py <fetch counter_collection.csv> <write counter_collection.csv> [mfma csv] out.json
+    python tools/pmc_stage_summary.py <counter_collection.csv>[:stage,stage...] ... out.json
+
+Every input is one rocprofv3 --pmc pass (FETCH_SIZE, WRITE_SIZE or SQ_VALU_MFMA_BUSY_CYCLES ...) of one bench step;
+`:stages` keeps only those stages of that file (a full C3 step has 18 k dispatches and the profiler dies beyond ~16 k
+profiled dispatches with TCC counters, so the step is profiled in two halves: `--workload C2` for mrte + adm,
+`--workload C3 --skip-adm` for vqpe + plm + decoder + vocoder).
 
 The bench is run with --stage-markers: a no-op kernel `mt2::stage_marker_kernel<ID>` is enqueued at every stage
 boundary (IDs: 8 / 9 around the VQ-PE call; 0 start, 1 mrte, 2 adm, 3 regulate, 4 plm, 5 decoder, 6 vocoder inside
@@ -61,13 +66,20 @@ def main(argv):
     launches = defaultdict(int)
     gemm = defaultdict(float)
     gemm_launches = 0
-    for path in ins:
+    seen_counter_stage = set()
+    for spec in ins:
+        path, _, keep = spec.partition(":")
+        keep = set(keep.split(",")) if keep else None
         rows = load(path)
         lab = stages_of(rows)
-        counted = not launches
+        names = {cn for d in rows for cn in d["c"]}
+        counted_here = set()
         for d, st in zip(rows, lab):
-            if st is None:
+            if st is None or (keep is not None and st not in keep):
                 continue
+            counted = (st not in launches) or (st in counted_here)
+            if counted:
+                counted_here.add(st)
             for cn, v in d["c"].items():
                 acc[st][cn] += v
                 if "gemm_f32" in d["name"]:

@@ -125,6 +125,9 @@ def main() -> None:
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="debug: a handle option (mt2_set_option), e.g. ar_groups=1, splitk=0, win_conv=0, t_ks4=512")
+    ap.add_argument("--vqpe", default="overlap", choices=["overlap", "separate"],
+                    help="C3/C5: the VQ-PE stage inside the synthesis call on an internal stream beside the ADM (default) "
+                         "or as its own call in front of it")
     ap.add_argument("--skip-adm", action="store_true",
                     help="measurement: leave the ADM out (forced durations) - halves the dispatch count of a step so that "
                          "a rocprofv3 --pmc pass of the PLM / vocoder half stays under the profiler's dispatch limit")
@@ -163,7 +166,7 @@ def main() -> None:
     full = args.workload in ("C3", "C5")
     if dry:
         class _StandIn:                                                  # shapes only; never used for a measurement
-            def synthesize_batch(self, phone, pl, mel_in, ml, forced_dur=None, tm_cap=None, **_):   # noqa: D401
+            def synthesize_batch(self, phone, pl, mel_in, ml, forced_dur=None, tm_cap=None, **_):
                 lens = forced_dur.sum(axis=1).astype(np.int32)
                 return torch.zeros(phone.shape[0], tm_cap, g.mrte.mel_bins), lens
 
@@ -200,21 +203,23 @@ def main() -> None:
     frames_per_step = int(dur.sum())
     stages = [s for s in (STAGES_FULL if full else ["mrte", "adm", "decoder"]) if not (args.skip_adm and s == "adm")]
     if not dry and full:            # pre-size the activation arena: no hipMalloc inside the timed region
-        model.workspace_reserve(model.workspace_query(B, Np, Tp, shape.Tm, run_plm=True, vocoder=True))
+        model.workspace_reserve(model.workspace_query(B, Np, Tp, shape.Tm, run_plm=True, vocoder=True, prompt_vqpe=True))
 
     ev = None if dry else [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
     def step(time_vqpe=False):
-        if full:
-            # configs[2] "full VQ-PE -> ...": VQProsodyEncoder.forward (conv stacks + codebook L2-argmin) on the
-            # 431-frame prompt mel - the prosody codes a prompt-conditioned PLM / stage-2 extraction consume
+        # configs[2] "full VQ-PE -> ...": VQProsodyEncoder.forward (conv stacks + codebook L2-argmin) on the 431-frame
+        # prompt mel - the prosody codes a prompt-conditioned PLM / stage-2 extraction consume.  Same work either way:
+        # "overlap" runs it inside the synthesis call on an internal stream beside the ADM, "separate" in front.
+        side = full and args.vqpe == "overlap"
+        if full and not side:
             if time_vqpe:
                 ev[0].record()
             model.vqpe_forward(mel_in, ml)
             if time_vqpe:
                 ev[1].record()
         out = model.synthesize_batch(phone, pl, mel_in, ml, forced_dur=dur, forced_codes=codes, run_plm=full,
-                                     vocoder=full, tm_cap=shape.Tm, skip_adm=args.skip_adm)
+                                     vocoder=full, tm_cap=shape.Tm, skip_adm=args.skip_adm, prompt_vqpe=side)
         mel, lens = out[0], out[1]
         if world > 1:   # the path's only exchange: ONE fixed-capacity RCCL all-gather over xGMI, lengths stay on the device
             mel, lens = gather_mels(mel, lens, b_cap=B, t_cap=shape.Tm, host_lens=False)
@@ -277,8 +282,10 @@ def main() -> None:
         step(time_vqpe=True)
         torch.cuda.synchronize()
         stage_ms = {k: v for k, v in model.last_stage_ms().items()}
-        if full:
+        if full and args.vqpe == "separate":
             stage_ms["vqpe"] = ev[0].elapsed_time(ev[1])
+        elif "vqpe_side" in stage_ms:          # its duration on the internal stream (overlapped with the ADM stage)
+            stage_ms["vqpe"] = stage_ms.pop("vqpe_side")
         model.set_profiling(False)
         result["stage_ms"] = {k: round(v, 3) for k, v in stage_ms.items()}
         # (2) one TRACED step: HIP events around every GEMM/conv launch -> per tile configuration breakdown.  The
@@ -286,6 +293,7 @@ def main() -> None:
         model.gemm_trace_begin()
         step()
         torch.cuda.synchronize()
+        shapes = model.gemm_trace_shapes(14)
         tr = model.gemm_trace_end()
         alg_s, att_s = stage_flops_model(g, a, p, h, utts, stages)
         alg_gemm, alg_attn = sum(alg_s.values()), sum(att_s.values())
@@ -332,6 +340,7 @@ def main() -> None:
             "launches_per_step": n_launch, "avg_launch_us": round(sum_ms * 1e3 / max(n_launch, 1), 2),
             "traced_gemm_ms_sum_of_launches": round(sum_ms, 3),
             "stages": per_stage,
+            "slowest_shapes_traced": shapes,
             "per_config": [{"config": r["config"], "launches": r["launches"], "ms": round(r["ms"], 3),
                             "tflops": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2)} for r in tr],
         }

@@ -191,11 +191,14 @@ int mt2_mel_spectrogram(mt2_model* m, void* stream, const mt2_audio_config* ac, 
 #define MT2_RUN_PLM 1
 #define MT2_RUN_VOCODER 2
 #define MT2_SKIP_ADM 4
+#define MT2_PROMPT_VQPE 8   /* also run VQProsodyEncoder.forward (modules/vqpe.py:50-62) on the PROMPT mel, on an internal
+                             * stream beside the ADM: prompt_codes int64 [B, ceil(Tp_max / vq_stride)] (device) receives
+                             * its prosody codes (what a prompt-conditioned PLM or stage-2 extraction consume) */
 int mt2_synthesize_batch(mt2_model* m, void* stream, const int64_t* phone, const int32_t* phone_lens /*host*/,
                          int Np_max, const float* prompt_mel, const int32_t* prompt_lens /*host*/, int Tp_max,
                          int B, const int32_t* forced_dur /*host*/, const int64_t* forced_codes, int Tq_cap,
                          int flags, float* mel, int Tm_cap, int32_t* mel_lens /*host*/, int32_t* dur_out,
-                         int64_t* codes_out, float* wav);
+                         int64_t* codes_out, float* wav, int64_t* prompt_codes);
 
 /* ---- tuning.  Every switch lives in the handle (no process-global state): two handles do not see each other's
  * settings.  Names: "ar_groups" (1..8, default 2: the sequences of an autoregressive run are dealt into that many
@@ -235,6 +238,9 @@ int mt2_op_attention(void* stream, const float* Q, int ldq, const float* K, int 
  * returns the number of entries written (<= cap). */
 int mt2_gemm_trace_begin(mt2_model* m);
 int mt2_gemm_trace_end(mt2_model* m, int cap, const char** names, int64_t* launches, double* flops, double* ms);
+/* text table "config M N K groups launches ms tflops" of the traced launches grouped by shape, slowest first;
+ * call BEFORE mt2_gemm_trace_end (which frees the records); returns the bytes written or -1 */
+int mt2_gemm_trace_shapes(mt2_model* m, char* buf, int cap, int top);
 int mt2_gemm_config_count(void);
 const char* mt2_gemm_config_name(int idx);
 /* time `iters` back-to-back launches of one GEMM / conv (taps, dilation) with HIP events on `stream`, cycling

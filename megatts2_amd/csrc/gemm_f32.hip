@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdio>
 #include <utility>
 #include <vector>
 
@@ -878,6 +879,32 @@ static const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
+int gemm_trace_shapes(EngineOpts& o, char* buf, int cap, int top) {
+    struct Agg { int cfg, M, N, K, g; long long n; double ms, fl; };
+    std::vector<Agg> v;
+    for (auto& r : o.trace) {
+        float dt = 0.f;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&dt, r.e0, r.e1) != hipSuccess) return -1;
+        bool found = false;
+        for (auto& a : v)
+            if (a.cfg == r.cfg && a.M == r.M && a.N == r.N && a.K == r.K && a.g == r.groups) {
+                ++a.n; a.ms += dt; a.fl += r.flops; found = true;
+                break;
+            }
+        if (!found) v.push_back({r.cfg, r.M, r.N, r.K, r.groups, 1, (double)dt, r.flops});
+    }
+    std::sort(v.begin(), v.end(), [](const Agg& a, const Agg& b) { return a.ms > b.ms; });
+    int off = 0;
+    for (int i = 0; i < (int)v.size() && i < top; ++i) {
+        const Agg& a = v[i];
+        const int w = snprintf(buf + off, cap - off, "%s %d %d %d %d %lld %.3f %.2f\n", kCfgs[a.cfg].name, a.M, a.N, a.K, a.g,
+                               a.n, a.ms, a.fl / (a.ms > 0 ? a.ms : 1e-9) / 1e9);
+        if (w < 0 || w >= cap - off) break;
+        off += w;
+    }
+    return off;
+}
+
 int gemm_num_configs() { return kNumCfgs; }
 const char* gemm_config_name(int idx) { return idx >= 0 && idx < kNumCfgs ? kCfgs[idx].name : ""; }
 
@@ -1022,6 +1049,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
         TraceRec r;
         r.cfg = idx;
         r.flops = 2.0 * p.M * p.N * p.K * p.groups;
+        r.M = p.M; r.N = p.N; r.K = p.K; r.groups = p.groups;
         if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return hipErrorUnknown;
         (void)hipEventRecord(r.e0, s);
         hipLaunchKernelGGL(fn, grid, block, lds, s, p);

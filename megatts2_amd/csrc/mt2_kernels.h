@@ -43,7 +43,7 @@ struct GemmP {
 // Tuning / measurement switches of the engine.  They live in the model handle (mt2_model::opts) or in a local
 // object of a kernel-level entry point - never in process globals: two handles (or two threads) do not see each
 // other's settings.  The defaults are what the product path runs.
-struct TraceRec { int cfg; double flops; hipEvent_t e0, e1; };
+struct TraceRec { int cfg; double flops; hipEvent_t e0, e1; int M, N, K, groups; };
 struct EngineOpts {
     int force_cfg = -1;                                    // >= 0: tile configuration index for every GEMM launch
     int t_ks4 = 256, t_ks2 = 640, t32 = 256, t32x32 = 256; // tile-choice thresholds in tiles (tools/gemm_sweep.py)
@@ -62,6 +62,9 @@ int gemm_num_configs();
 const char* gemm_config_name(int idx);
 // per tile configuration: launches, executed FLOPs, summed ms; last entry "union" (see gemm_f32.hip); -1 on error
 int gemm_trace_collect(EngineOpts& o, int cap, const char** names, int64_t* launches, double* flops, double* ms);
+// text table "config M N K groups launches ms tflops" of the traced launches grouped by shape, slowest first (call
+// BEFORE gemm_trace_collect, which frees the records); returns the number of bytes written (< cap)
+int gemm_trace_shapes(EngineOpts& o, char* buf, int cap, int top);
 
 // Row LayerNorm over C channels (biased variance, eps inside the sqrt), one wave per row:
 //   out[m, :] = mask_m * ( act( LN(x[m, :]) * gamma[g] + beta[g] ) + R1[m, :] + R2[m, :] )

@@ -162,6 +162,9 @@ struct mt2_model {
     std::vector<hipStream_t> aux_streams;
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;
+    // dedicated stream of the optional prompt VQ-PE of mt2_synthesize_batch (runs beside the ADM)
+    hipStream_t vq_stream = nullptr;
+    hipEvent_t ev_vq_fork = nullptr, ev_vq_join = nullptr, ev_vq_t0 = nullptr, ev_vq_t1 = nullptr;
 
     // mel front-end constants for the last mt2_audio_config seen (windowed DFT basis, mel filterbank)
     mt2_audio_config fe_cfg{};

@@ -19,7 +19,7 @@ from . import config as cfgmod
 _LIB = None
 MAX_POSITIONS = 8192       # rows of the sine tables (the reference builds 4000 and extends on demand)
 
-MT2_RUN_PLM, MT2_RUN_VOCODER, MT2_SKIP_ADM = 1, 2, 4
+MT2_RUN_PLM, MT2_RUN_VOCODER, MT2_SKIP_ADM, MT2_PROMPT_VQPE = 1, 2, 4, 8
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 
 
@@ -379,7 +379,7 @@ class NativeModel:
 
     def synthesize_batch(self, phone, phone_lens, prompt_mel, prompt_lens, forced_dur=None, forced_codes=None,
                          run_plm=True, vocoder=False, skip_adm=False, tm_cap: Optional[int] = None,
-                         return_aux=False):
+                         return_aux=False, prompt_vqpe=False):
         """Megatts.forward's no_grad block for a batch; returns (mel [B, Tm_cap, 80], mel_lens[, aux])."""
         import torch
         B, Np = phone.shape
@@ -411,12 +411,14 @@ class NativeModel:
         codes_out = torch.empty(B, tq_cap, device=dev, dtype=torch.int64)
         pad = int(getattr(self.hg_cfg, "inference_padding", 0))
         wav = torch.empty(B, self.hg_cfg.hop * (tm_cap + 2 * pad), device=dev, dtype=torch.float32) if vocoder else None
-        flags = (MT2_RUN_PLM if run_plm else 0) | (MT2_RUN_VOCODER if vocoder else 0) | (MT2_SKIP_ADM if skip_adm else 0)
+        flags = ((MT2_RUN_PLM if run_plm else 0) | (MT2_RUN_VOCODER if vocoder else 0) | (MT2_SKIP_ADM if skip_adm else 0)
+                 | (MT2_PROMPT_VQPE if prompt_vqpe else 0))
+        pcodes = torch.empty(B, -(-Tp // st), device=dev, dtype=torch.int64) if prompt_vqpe else None
         _check(self.lib.mt2_synthesize_batch(self.h, _stream(), _ptr(phone), _iptr(pl), Np, _ptr(prompt_mel), _iptr(ml),
                                              Tp, B, _iptr(fd), _ptr(forced_codes), tq_cap, flags, _ptr(mel), tm_cap,
-                                             _iptr(mel_lens), _ptr(dur_out), _ptr(codes_out), _ptr(wav)))
+                                             _iptr(mel_lens), _ptr(dur_out), _ptr(codes_out), _ptr(wav), _ptr(pcodes)))
         if return_aux:
-            return mel, mel_lens, {"dur": dur_out, "codes": codes_out, "wav": wav}
+            return mel, mel_lens, {"dur": dur_out, "codes": codes_out, "wav": wav, "prompt_codes": pcodes}
         return mel, mel_lens
 
     # ---- tuning / measurement (every switch lives in THIS handle; the library has no mutable globals)
@@ -432,9 +434,10 @@ class NativeModel:
         self.set_option("ar_groups", groups)
 
     def workspace_query(self, B: int, Np_max: int, Tp_max: int, Tm_cap: int, run_plm=True, vocoder=False,
-                        skip_adm=False) -> int:
+                        skip_adm=False, prompt_vqpe=False) -> int:
         """Upper bound (bytes) of the arena one synthesize_batch call of this geometry needs."""
-        flags = (MT2_RUN_PLM if run_plm else 0) | (MT2_RUN_VOCODER if vocoder else 0) | (MT2_SKIP_ADM if skip_adm else 0)
+        flags = ((MT2_RUN_PLM if run_plm else 0) | (MT2_RUN_VOCODER if vocoder else 0) | (MT2_SKIP_ADM if skip_adm else 0)
+                 | (MT2_PROMPT_VQPE if prompt_vqpe else 0))
         n = C.c_size_t(0)
         _check(self.lib.mt2_workspace_query(self.h, B, Np_max, Tp_max, Tm_cap, flags, C.byref(n)))
         return n.value
@@ -449,6 +452,19 @@ class NativeModel:
 
     def gemm_trace_begin(self) -> None:
         _check(self.lib.mt2_gemm_trace_begin(self.h))
+
+    def gemm_trace_shapes(self, top: int = 16):
+        """Traced launches grouped by (config, M, N, K, groups), slowest first - call before gemm_trace_end()."""
+        buf = C.create_string_buffer(1 << 14)
+        n = self.lib.mt2_gemm_trace_shapes(self.h, buf, len(buf), int(top))
+        if n < 0:
+            raise NativeError("gemm trace failed")
+        out = []
+        for line in buf.value.decode().splitlines():
+            c, M, N, K, g, cnt, ms, tf = line.split()
+            out.append({"config": c, "M": int(M), "N": int(N), "K": int(K), "groups": int(g), "launches": int(cnt),
+                        "ms": float(ms), "tflops": float(tf)})
+        return out
 
     def gemm_trace_end(self):
         """-> list of dicts {config, launches, flops, ms} for this handle's GEMM launches since gemm_trace_begin()."""

@@ -872,3 +872,21 @@ def test_synthesize_list_and_sharded_world1_rccl(tiny_batch):
             assert o.is_cuda and o.shape[0] == lens[i] and O.rel_l2(o.cpu().numpy(), mel[i, :lens[i]]) < 2e-6
     finally:
         dist.destroy_process_group()
+
+
+def test_prompt_vqpe_inside_the_synthesis_call(tiny_batch):
+    """MT2_PROMPT_VQPE: the VQ prosody encoder of the prompt mel on an internal stream beside the ADM gives the same
+    codes as the stand-alone call, and leaves every other output of the call unchanged."""
+    tts = model("tiny")
+    phone, pl = pad_stack([z["phone"] for z in tiny_batch])
+    mel, ml = pad_stack([z["prompt_mel"] for z in tiny_batch])
+    dur, _ = pad_stack([z["forced_dur"] for z in tiny_batch])
+    a, la, auxa = tts.native.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, vocoder=True, return_aux=True)
+    b, lb, auxb = tts.native.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, vocoder=True, return_aux=True,
+                                              prompt_vqpe=True)
+    assert torch.equal(a, b) and torch.equal(auxa["wav"], auxb["wav"]) and torch.equal(auxa["codes"], auxb["codes"])
+    _, codes = tts.native.vqpe_forward(dev(mel), ml)
+    assert torch.equal(auxb["prompt_codes"], codes[0])
+    for i, z in enumerate(tiny_batch):
+        want = O.vqpe_forward(synth_models("tiny")[1][0], synth_models("tiny")[0][0], z["prompt_mel"])[1]
+        assert np.array_equal(auxb["prompt_codes"][i, :want.size].cpu().numpy(), want)

@@ -203,7 +203,7 @@ int mt2_synthesize_batch(mt2_model* m, void* stream, const int64_t* phone, const
 /* ---- tuning.  Every switch lives in the handle (no process-global state): two handles do not see each other's
  * settings.  Names: "ar_groups" (1..8, default 2: the sequences of an autoregressive run are dealt into that many
  * independent kernel chains on internal HIP streams that fork from and join back into `stream`; results do not
- * depend on it), "splitk" (1), "lnfuse" (0), "voc_streams" (3), "win_conv" (1), "force_gemm_config" (-1),
+ * depend on it), "lnalg" (1: algebraic LayerNorm in the AR layers), "splitk" (1), "lnfuse" (0), "voc_streams" (3), "win_conv" (1), "force_gemm_config" (-1),
  * "t_ks4", "t_ks2", "t32", "t32x32" (tile-choice thresholds).  Unknown names are an error. */
 int mt2_set_option(mt2_model* m, const char* name, int value);
 int mt2_get_option(mt2_model* m, const char* name, int* value);
@@ -221,11 +221,14 @@ int mt2_op_gemm(void* stream, const float* X, int ldx, int Rx, const int32_t* ro
                 int taps, int dil, int Cin, const float* W, int ldw, const float* bias, const float* R, int ldr,
                 const int32_t* valid, float* C, int ldc, int M, int N, int pro_act, float pro_slope, int epi_act,
                 float out_scale, int force_cfg);
-/* C[M,N] = act(LayerNorm(X rows m*a_mul + shift0; gamma, beta, eps) @ W^T + bias): the LayerNorm-prologue form of
- * the engine (AR steps: LN1 -> QKV, LN2 -> ff.0 in one launch).  K <= 1024; force_cfg -1 or a 2-deep-ring config. */
+/* C[M,N] = act(LayerNorm(X rows m*a_mul + shift0; gamma, beta, eps) @ W^T + bias) in one launch (AR steps: LN1 -> QKV,
+ * LN2 -> ff.0).  K <= 1024.  algebraic = 0: fragments normalised on the fly (force_cfg -1 or a 2-deep-ring config);
+ * algebraic = 1 (what the model runs): W must be the gamma-scaled weights W'[n,k] = gamma[k] W[n,k], `bias` the vector
+ * c[n] = sum_k beta[k] W[n,k] + b[n], `gamma` the vector s[n] = sum_k W'[n,k] (beta unused): the kernel computes the row
+ * statistics in its prologue and rstd * (X W'^T - mean * s) + c in its epilogue; any LDS-DMA tile configuration. */
 int mt2_op_ln_gemm(void* stream, const float* X, int ldx, int Rx, int a_mul, int shift0, const float* gamma,
                    const float* beta, float eps, const float* W, const float* bias, float* C, int ldc, int M, int N, int K,
-                   int epi_act, int force_cfg);
+                   int epi_act, int force_cfg, int algebraic);
 int mt2_op_layernorm(void* stream, const float* x, int ldx, const float* gamma, const float* beta, const float* R1,
                      int ldr1, const int32_t* valid, float* out, int ldo, int M, int C, float eps, int act);
 int mt2_op_attention(void* stream, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,

@@ -204,6 +204,7 @@ __device__ __forceinline__ void epilogue_pre_t(const GemmP& p, f32x16 (&acc)[TM]
 
 constexpr int BK = 32;   // K chunk (floats)
 constexpr int PRO_LN = 3;   // prologue kind: LayerNorm of the A rows (value of GemmP::pro_act)
+constexpr int PRO_LNA = 4;  // LayerNorm of the A rows, ALGEBRAIC form: statistics in the prologue, correction in the epilogue
 constexpr int LS = 36;   // LDS row stride (floats): 144 B = 9 x 16 B -> conflict-free ds_read_b128
 
 template <int BM, int BN, int WGM, int WGN>
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW);   // 1-KiB DMA pieces per wave per chunk
     constexpr int L = A_IT + B_IT;
     constexpr bool LNP = PRO == PRO_LN;                         // LayerNorm prologue (see below)
+    constexpr bool LNA = PRO == PRO_LNA;                        // algebraic LayerNorm (see below)
     constexpr int GBF = LNP ? 256 : 0;                          // + one 1-KiB piece per stage: gamma | beta chunk
     constexpr int STAGE = (BM + BN) * BK + GBF;                 // floats per ring stage (of one K group)
     static_assert(!LNP || (NST == 2 && TM == 1 && TN == 1), "LayerNorm prologue: 2-deep ring, one tile per wave");
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     // fragments on the fly: a' = (a - mean) * (rstd * gamma_k) + beta_k, gamma / beta travelling through the ring
     // as one extra DMA piece per chunk.  Linear layers only (taps = 1), K <= 1024.
     float ln_mu = 0.0f, ln_rs = 0.0f;
-    if constexpr (LNP) {
+    auto row_stats = [&]() {       // mean / rstd of this workgroup's BM rows -> LDS stat[BM][2] (two passes in registers)
         float* stat = smem + KS * NST * STAGE;                  // [BM][2]
         constexpr int NWALL = NW * KS;
         const int Kf = p.K;
@@ -471,7 +473,11 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
                 stat[2 * r0 + 1] = ok ? 1.0f / sqrtf(q2 * inv_k + p.ln_eps) : 0.0f;
             }
         }
+    };
+    if constexpr (LNP) {
+        row_stats();
         __syncthreads();
+        const float* stat = smem + KS * NST * STAGE;
         ln_mu = stat[2 * (wm * WTM + (lane & 31))];
         ln_rs = stat[2 * (wm * WTM + (lane & 31)) + 1];
         wait_vmcnt<0>();
@@ -532,6 +538,18 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     for (int st = 0; st < NST - 1; ++st)
         if (st < nr) issue(st, st);
 
+    // ---- algebraic LayerNorm (PRO_LNA): C = LN(X; gamma, beta) W^T + b WITHOUT touching the K loop.  With
+    //   W'[n,k] = gamma[k] W[n,k],  s[n] = sum_k W'[n,k],  c[n] = sum_k beta[k] W[n,k] + b[n]   (prepared once at load)
+    //   LN(x) W^T + b = rstd * (x W'^T - mean * s) + c
+    // so the GEMM runs on the RAW rows against W' and only the epilogue differs.  The row statistics (same two-pass
+    // arithmetic as layernorm_kernel) are computed HERE, while the first ring stages are in flight - their latency
+    // hides the pass - and kept in LDS for the epilogue.  p.W = W', p.bias = c, p.ln_g = s.  Linear layers, K <= 1024.
+    if constexpr (LNA) {
+        row_stats();
+        wait_vmcnt<0>();            // the statistic loads share the counter with the DMAs: everything issued so far landed
+        __syncthreads();
+    }
+
     const float pro_slope = p.pro_slope;
     // MFMA operand fetch: inline-asm ds_read_b128 (a compiler-visible LDS load would make hipcc drain the
     // DMA queue with s_waitcnt vmcnt(0) in front of it), software-pipelined one k-group ahead.
@@ -586,7 +604,7 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
             if constexpr (LNP) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) fa[cur][0][e] = (fa[cur][0][e] - ln_mu) * (ln_rs * fg[cur][e]) + fbt[cur][e];
-            } else if (PRO != ACT_NONE) {
+            } else if (PRO != ACT_NONE && !LNA) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -602,6 +620,11 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
         }
         st = st + 1 == NST ? 0 : st + 1;
     }
+    // LN-A correction of an accumulator element of row r (tile-local), column n: rstd_r * (acc - mean_r * s_n)
+    auto lna_fix = [&](float acc_v, int row_local, float s_n) {
+        const float* stat = smem + KS * NST * STAGE;
+        return stat[2 * row_local + 1] * (acc_v - stat[2 * row_local] * s_n);
+    };
     if constexpr (KS > 1) {
         // sum the KS partial tiles through LDS (ring memory is free: every DMA has been waited for and the
         // barrier below orders the last operand reads), fixed order kg = 0..KS-1; group kg finishes elements
@@ -621,19 +644,41 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
             for (int g2 = 0; g2 < KS; ++g2) v += smem[(((g2 * NW + wave) * 16) + e) * 64 + lane];
             out[i] = v;
         }
-        epilogue_pre<EPG>(p, out, pre, g, m0 + wm * WTM, n0 + wn * WTN, lane, kg * EPG);
-    } else if constexpr (PRE) {
-        float out[16];
+        if constexpr (LNA) {
+            const int n = n0 + wn * WTN + (lane & 31);
+            const float s_n = n < p.N ? p.ln_g[n] : 0.0f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) out[e] = acc[0][0][e];
-        epilogue_pre<16>(p, out, pre, g, m0 + wm * WTM, n0 + wn * WTN, lane, 0);
-    } else if constexpr (PRET) {
-        epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+            for (int i = 0; i < EPG; ++i) {
+                const int e = kg * EPG + i;
+                out[i] = lna_fix(out[i], wm * WTM + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), s_n);
+            }
+        }
+        epilogue_pre<EPG>(p, out, pre, g, m0 + wm * WTM, n0 + wn * WTN, lane, kg * EPG);
     } else {
-        epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+        if constexpr (LNA) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+                const float s_n = n < p.N ? p.ln_g[n] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        acc[i][j][e] = lna_fix(acc[i][j][e], wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), s_n);
+            }
+        }
+        if constexpr (PRE) {
+            float out[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out[e] = acc[0][0][e];
+            epilogue_pre<16>(p, out, pre, g, m0 + wm * WTM, n0 + wn * WTN, lane, 0);
+        } else if constexpr (PRET) {
+            epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+        } else {
+            epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+        }
     }
 }
-
 
 // ===================================================================================================
 // v3: WINDOW convolution.  Conv1d("same", k taps, dilation d) over contiguous time-major rows with Cin = 32*QS
@@ -805,36 +850,39 @@ struct TileCfg {
     int bm, bn, threads;
     size_t lds;               // window configurations: the ring part only (the window depends on taps and dilation)
     const char* name;
-    void (*fn[4])(GemmP);     // indexed by the prologue: none / relu / leaky relu / LayerNorm (nullptr: no variant)
+    void (*fn[5])(GemmP);     // indexed by the prologue: none / relu / leaky relu / LayerNorm / algebraic LayerNorm (nullptr: no variant)
     int win_qs = 0;           // > 0: window convolution for Cin = Cout = 32 * win_qs
 };
 
 #define MT2_CFG(BM_, BN_, WM_, WN_)                                                                    \
     { BM_, BN_, WM_* WN_ * 64, 2ull * (BM_ + BN_) * LS * sizeof(float), #BM_ "x" #BN_ "_" #WM_ "x" #WN_, \
       { gemm_f32_kernel<BM_, BN_, WM_, WN_>, gemm_f32_kernel<BM_, BN_, WM_, WN_>,                        \
-        gemm_f32_kernel<BM_, BN_, WM_, WN_>, nullptr } }
+        gemm_f32_kernel<BM_, BN_, WM_, WN_>, nullptr, nullptr } }
 #define MT2_DMA(BM_, BN_, WM_, WN_, NST_)                                              \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (BM_ + BN_) * BK * sizeof(float),          \
       "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                   \
       { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_RELU>, \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_LRELU>, nullptr } }
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_LRELU>, nullptr,                             \
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, PRO_LNA> } }
 #define MT2_DMAK(BM_, BN_, WM_, WN_, KS_, NST_)                                                        \
     { BM_, BN_, WM_* WN_ * KS_ * 64, (size_t)KS_ * NST_ * (BM_ + BN_) * BK * sizeof(float),              \
       "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "_s" #NST_,                                        \
       { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_RELU>, \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_LRELU>, nullptr } }
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_LRELU>, nullptr,                           \
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, PRO_LNA> } }
 // 2-deep ring, one 32x32 tile per wave: also built with the LayerNorm prologue
 #define MT2_DMAL(BM_, BN_, WM_, WN_, KS_)                                                               \
     { BM_, BN_, WM_* WN_ * KS_ * 64, (size_t)KS_ * 2 * (BM_ + BN_) * BK * sizeof(float),                 \
       "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "_s2",                                             \
       { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_RELU>, \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_LRELU>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, PRO_LN> } }
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_LRELU>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, PRO_LN>, \
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, PRO_LNA> } }
 
 #define MT2_WIN(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((BN_ / 8 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 256) * sizeof(float), \
       "win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                       \
       { conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_NONE>, conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
-        conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr }, QS_ }
+        conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, QS_ }
 
 static const TileCfg kCfgs[] = {
     // v1: register-staged double buffer (kept for A/B runs and as the reference implementation)
@@ -910,7 +958,7 @@ const char* gemm_config_name(int idx) { return idx >= 0 && idx < kNumCfgs ? kCfg
 
 // hipFuncSetAttribute is process-wide state of the code object: a "done" cache per (configuration, prologue) only
 // saves the call; the benign race (two threads both setting the same value) is harmless.
-static std::atomic<bool> g_attr_done[kNumCfgs][4];
+static std::atomic<bool> g_attr_done[kNumCfgs][5];
 
 // ---- launch trace (measurement only): HIP events around every GEMM launch, on the launch stream; the records
 // live in the EngineOpts of whoever asked for the trace (the model handle).
@@ -979,7 +1027,7 @@ int gemm_trace_collect(EngineOpts& o, int cap, const char** names, int64_t* laun
 // window convolution: plain "same" conv over contiguous rows, square, narrow (see conv_win_f32_kernel)
 static bool win_eligible(const GemmP& p) {
     return p.taps >= 2 && !p.rowbase && p.a_mul == 1 && p.groups == 1 && p.N == p.Cin &&
-           (p.Cin == 32 || p.Cin == 64 || p.Cin == 128) && (p.taps - 1) * p.dil <= 64 && p.pro_act != PRO_LN;
+           (p.Cin == 32 || p.Cin == 64 || p.Cin == 128) && (p.taps - 1) * p.dil <= 64 && p.pro_act < PRO_LN;
 }
 static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_out) {
     int bi = 12;                                                        // dma64x64_2x2_s3
@@ -1015,7 +1063,11 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     if ((p.Cin & 3) || (p.ldx & 3) || (p.ldw & 3) || p.K != p.taps * p.Cin) return hipErrorInvalidValue;
     int idx = 0;
     const TileCfg* c = choose_cfg(p, o, &idx);
-    if (p.pro_act < 0 || p.pro_act > PRO_LN) return hipErrorInvalidValue;
+    if (p.pro_act < 0 || p.pro_act > PRO_LNA) return hipErrorInvalidValue;
+    if (p.pro_act == PRO_LNA) {     // algebraic LayerNorm: every LDS-DMA configuration has the variant
+        if (p.taps != 1 || p.K > 1024 || !p.ln_g || p.groups != 1) return hipErrorInvalidValue;
+        if (!c->fn[PRO_LNA]) return hipErrorNotSupported;
+    }
     size_t lds = c->lds, lds_attr = 0;
     if (p.pro_act == PRO_LN) {
         if (p.taps != 1 || p.K > 1024 || !p.ln_g || !p.ln_b) return hipErrorInvalidValue;
@@ -1027,6 +1079,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
         const int ks = c->threads / 64 / ((c->bm / 32) * (c->bn / 32));     // one 32x32 tile per wave
         lds = c->lds + (size_t)ks * 2 * 256 * sizeof(float) + (size_t)c->bm * 2 * sizeof(float);
     }
+    if (p.pro_act == PRO_LNA) lds = c->lds + (size_t)c->bm * 2 * sizeof(float);     // + row statistics [BM][2]
     if (c->win_qs) {
         if (!win_eligible(p) || p.Cin != 32 * c->win_qs) return hipErrorInvalidValue;
         const int wrp = (c->bm + (p.taps - 1) * p.dil + 7) & ~7;

@@ -209,6 +209,27 @@ struct Loader {
             } else {
                 w.ff0w = mat(p + ".ff.0.weight", ff, d); w.ff0b = vec(p + ".ff.0.bias", ff);
                 w.ff1w = mat(p + ".ff.3.weight", d, ff); w.ff1b = vec(p + ".ff.3.bias", d);
+                // algebraic-LayerNorm operands (EncLayerW): sums in double, stored as f32
+                auto fold = [&](const std::vector<float>& W, const std::vector<float>& b, const std::vector<float>& gam,
+                                const std::vector<float>& bet, int N, float*& Wl, float*& sv, float*& cv) {
+                    std::vector<float> wl((size_t)N * d), s(N), c(N);
+                    for (int n = 0; n < N; ++n) {
+                        double ss = 0.0, cc = b[n];
+                        for (int k = 0; k < d; ++k) {
+                            const float v = W[(size_t)n * d + k] * gam[k];
+                            wl[(size_t)n * d + k] = v;
+                            ss += (double)v;
+                            cc += (double)bet[k] * (double)W[(size_t)n * d + k];
+                        }
+                        s[n] = (float)ss;
+                        c[n] = (float)cc;
+                    }
+                    Wl = upload(wl); sv = upload(s); cv = upload(c);
+                };
+                fold(qkv, bqkv, get(p + ".norm1.weight", {d}).data, get(p + ".norm1.bias", {d}).data, 3 * d, w.wqkv_l, w.sqkv,
+                     w.cqkv);
+                fold(get(p + ".ff.0.weight", {ff, d}).data, get(p + ".ff.0.bias", {ff}).data, get(p + ".norm2.weight", {d}).data,
+                     get(p + ".norm2.bias", {d}).data, ff, w.ff0_l, w.sff0, w.cff0);
             }
             e.layers.push_back(w);
         }

@@ -89,26 +89,51 @@ static void linear(const Ctx& c, const float* x, int ldx, int M, const float* W,
     gemm(c, p);
 }
 
-// y[M, N] = act(LN(x_rows)[M, K] @ W^T + b), x_rows[m] = x + (m * a_mul + shift0) * ldx: LayerNorm fused into the
-// GEMM as its prologue (gemm_f32.hip, PRO_LN) - one launch instead of two.  When the tile configuration chosen
-// for this shape has no such variant (big tiles), falls back to launch_layernorm into `h_scratch` + a plain GEMM.
-static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, int shift0, int M, const float* lng,
-                      const float* lnb, const float* W, const float* b, int N, int K, float* y, int ldy,
-                      float* h_scratch, int epi_act = ACT_NONE) {
+// y[M, N] = act(LN(x_rows)[M, K] @ W^T + b), x_rows[m] = x + (m * a_mul + shift0) * ldx.  Three forms, same result
+// up to fp32 round-off:
+//   algebraic (default, opts.lnalg; needs the folded operands Wl / s / c of EncLayerW): ONE launch, statistics in the
+//     GEMM's prologue while its first operand chunks are in flight, rstd * (acc - mean * s) + c in its epilogue;
+//   prologue  (opts.lnfuse): one launch, fragments normalised on the fly (slower K loop, two smallest tiles only);
+//   plain: launch_layernorm into `h_scratch` + a GEMM.
+struct LnOps {                 // operands of one LN -> Linear pair, rows [n0, n0 + N) of the weight matrix
+    const float *g, *b, *W, *bias;        // LayerNorm affine, Linear weight / bias
+    const float *Wl, *s, *c;              // folded operands (nullptr: not available)
+};
+static LnOps ln_ops(const float* g, const float* b, const float* W, const float* bias, const float* Wl, const float* s,
+                    const float* c, int n0, int K) {
+    return LnOps{g, b, W + (size_t)n0 * K, bias + n0, Wl ? Wl + (size_t)n0 * K : nullptr, s ? s + n0 : nullptr,
+                 c ? c + n0 : nullptr};
+}
+static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, int shift0, int M, const LnOps& w, int N,
+                      int K, float* y, int ldy, float* h_scratch, int epi_act = ACT_NONE) {
     GemmP p{};
     p.X = x; p.ldx = ldx; p.Rx = Rx; p.a_mul = a_mul ? a_mul : 1; p.shift0 = shift0; p.taps = 1; p.dil = 1; p.Cin = K;
-    p.K = K; p.W = W; p.ldw = K; p.bias = b; p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.groups = 1; p.out_scale = 1.0f;
-    p.epi_act = epi_act; p.pro_act = 3; p.ln_g = lng; p.ln_b = lnb; p.ln_eps = 1e-5f;
+    p.K = K; p.W = w.W; p.ldw = K; p.bias = w.bias; p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.groups = 1; p.out_scale = 1.0f;
+    p.epi_act = epi_act; p.ln_eps = 1e-5f;
+    if (c.m.opts.lnalg && w.Wl && K <= 1024) {
+        p.pro_act = 4; p.W = w.Wl; p.bias = w.c; p.ln_g = w.s;
+        const hipError_t e = launch_gemm(p, c.s, &c.m.opts);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotSupported) MT2_HIP(e);
+        p.W = w.W; p.bias = w.bias;
+    }
+    p.pro_act = 3; p.ln_g = w.g; p.ln_b = w.b;
     if (c.m.opts.lnfuse && K <= 1024) {
         const hipError_t e = launch_gemm(p, c.s, &c.m.opts);
         if (e == hipSuccess) return;
         if (e != hipErrorNotSupported) MT2_HIP(e);
     }
     LnP q{};
-    q.x = x + (long long)shift0 * ldx; q.ldx = ldx * p.a_mul; q.gamma = lng; q.beta = lnb; q.out = h_scratch; q.ldo = K;
+    q.x = x + (long long)shift0 * ldx; q.ldx = ldx * p.a_mul; q.gamma = w.g; q.beta = w.b; q.out = h_scratch; q.ldo = K;
     q.M = M; q.C = K; q.eps = 1e-5f; q.act = ACT_NONE;
     MT2_HIP(launch_layernorm(q, c.s));
-    linear(c, h_scratch, K, M, W, b, N, K, y, ldy, nullptr, 0, nullptr, epi_act);
+    linear(c, h_scratch, K, M, w.W, w.bias, N, K, y, ldy, nullptr, 0, nullptr, epi_act);
+}
+static LnOps ln1_qkv(const EncLayerW& w, int d, int n0 = 0) {
+    return ln_ops(w.ln1g, w.ln1b, w.wqkv, w.bqkv, w.wqkv_l, w.sqkv, w.cqkv, n0, d);
+}
+static LnOps ln2_ff0(const EncLayerW& w, int d) {
+    return ln_ops(w.ln2g, w.ln2b, w.ff0w, w.ff0b, w.ff0_l, w.sff0, w.cff0, 0, d);
 }
 
 // nn.Conv1d(k, stride 1, padding (k-1)/2 * dil, dilation dil) over gap-padded rows
@@ -243,6 +268,7 @@ static int choose_split(const Ctx& c, int M, int N, int K) {
     if (!c.m.opts.splitk) return 1;
     // a split GEMM hands its reduction to a stand-alone LayerNorm launch, which the LayerNorm-prologue GEMM
     // (ln_linear) otherwise removes: worth it only for the long K chains (PLM ff.3, K = 4096)
+    if (c.m.opts.lnalg) return 1;       // the algebraic form has no stand-alone LayerNorm launch to ride on
     if (c.m.opts.lnfuse && K < 2048) return 1;
     const long long tiles = (long long)((M + 31) / 32) * ((N + 63) / 64);
     int S = 1;
@@ -279,7 +305,7 @@ static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, fl
         linear(c, s.h, d, M, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, nullptr, 0, nullptr, ACT_RELU);
     } else {
         linear(c, att, d, M, w.wo, w.bo, d, d, x, d, x, d);
-        ln_linear(c, x, d, M, 1, 0, M, w.ln2g, w.ln2b, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, s.h, ACT_RELU);   // LN2 -> ff.0
+        ln_linear(c, x, d, M, 1, 0, M, ln2_ff0(w, d), e.ff, d, s.f, e.ff, s.h, ACT_RELU);   // LN2 -> ff.0
     }
     const int S2 = choose_split(c, M, d, e.ff);
     if (S2 > 1) {
@@ -299,7 +325,7 @@ static Pending encoder_layer_ar(const Ctx& c, const EncW& e, const EncLayerW& w,
         ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
         linear(c, s.h, d, M, w.wqkv, w.bqkv, 3 * d, d, s.qkv, 3 * d);
     } else {
-        ln_linear(c, x, d, M, 1, 0, M, w.ln1g, w.ln1b, w.wqkv, w.bqkv, 3 * d, d, s.qkv, 3 * d, s.h);     // LN1 -> QKV
+        ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d), 3 * d, d, s.qkv, 3 * d, s.h);     // LN1 -> QKV
     }
     attention_self(c, e, g, s.qkv, s.att);
     return ar_layer_tail(c, e, w, x, M, s.att, s);
@@ -324,8 +350,8 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
         p.C = q; p.ldc = d; p.M = A; p.N = d;
         gemm(c, p);
     } else {   // LN1 fused into both consumers: K|V of all rows, Q of the last row of each sequence
-        ln_linear(c, x, d, M, 1, 0, M, w.ln1g, w.ln1b, w.wqkv + (size_t)d * d, w.bqkv + d, 2 * d, d, kv, 2 * d, s.h);
-        ln_linear(c, x, d, M, n, n - 1, A, w.ln1g, w.ln1b, w.wqkv, w.bqkv, d, d, q, d, s.f);
+        ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d, d), 2 * d, d, kv, 2 * d, s.h);
+        ln_linear(c, x, d, M, n, n - 1, A, ln1_qkv(w, d), d, d, q, d, s.f);
     }
     AttnP a{};
     a.Q = q; a.ldq = d; a.K = kv; a.ldk = 2 * d; a.V = kv + d; a.ldv = 2 * d; a.O = att; a.ldo = d;
@@ -334,7 +360,7 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
     MT2_HIP(launch_attention(a, c.s));
     // y = x[last rows] + out_proj(att): the residual rows sit n*d floats apart starting at row n-1
     linear(c, att, d, A, w.wo, w.bo, d, d, y, d, x + (size_t)(n - 1) * d, n * d);
-    ln_linear(c, y, d, A, 1, 0, A, w.ln2g, w.ln2b, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, s.h, ACT_RELU);   // LN2 -> ff.0
+    ln_linear(c, y, d, A, 1, 0, A, ln2_ff0(w, d), e.ff, d, s.f, e.ff, s.h, ACT_RELU);   // LN2 -> ff.0
     linear(c, s.f, e.ff, A, w.ff1w, w.ff1b, d, e.ff, y, d, y, d);
 }
 
@@ -349,13 +375,12 @@ static Pending encoder_layer_first_cached(const Ctx& c, const EncW& e, const Enc
     if (fill_all && n > 1) {
         // first step of a run that starts from a forced history (prompt prefix, teacher-forced tests): the cache
         // has no rows yet - LN1 -> QKV of ALL n rows, compact, then one strided copy into the cache layout
-        ln_linear(c, x, d, M, 1, 0, M, w.ln1g, w.ln1b, w.wqkv, w.bqkv, 3 * d, d, s.qkv, 3 * d, s.h);
+        ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d), 3 * d, d, s.qkv, 3 * d, s.h);
         MT2_HIP(launch_copy_2d(s.qkv, (long long)n * 3 * d, qkv_cache, (long long)cs * 3 * d, (long long)n * 3 * d, A,
                                c.s));
     } else {
         // LN1 -> QKV of the newest row of every active sequence, written into the cache at row stride cs
-        ln_linear(c, x, d, M, n, n - 1, A, w.ln1g, w.ln1b, w.wqkv, w.bqkv, 3 * d, d,
-                  qkv_cache + (size_t)(n - 1) * 3 * d, cs * 3 * d, s.h);
+        ln_linear(c, x, d, M, n, n - 1, A, ln1_qkv(w, d), 3 * d, d, qkv_cache + (size_t)(n - 1) * 3 * d, cs * 3 * d, s.h);
     }
     AttnP a{};
     a.Q = qkv_cache; a.ldq = 3 * d; a.K = qkv_cache + d; a.ldk = 3 * d; a.V = qkv_cache + 2 * d; a.ldv = 3 * d;

@@ -38,6 +38,8 @@ struct GemmP {
     // pro_act == 3 (LayerNorm prologue, linear layers with K <= 1024 only): A rows are normalised on the fly,
     // C = LN(X; ln_g, ln_b, ln_eps) W^T ...  launch_gemm returns hipErrorNotSupported when the tile configuration
     // it would choose has no such variant (big tiles) - callers then run launch_layernorm + a plain GEMM.
+    // pro_act == 4 (ALGEBRAIC LayerNorm, K <= 1024): W = gamma-scaled weights W', bias = c, ln_g = s (see EncLayerW):
+    // C = rstd * (X W'^T - mean * s) + c = LN(X) W^T + b; statistics in the prologue, K loop untouched.
     const float* ln_g; const float* ln_b; float ln_eps;
 };
 // Tuning / measurement switches of the engine.  They live in the model handle (mt2_model::opts) or in a local
@@ -49,6 +51,8 @@ struct EngineOpts {
     int t_ks4 = 256, t_ks2 = 640, t32 = 256, t32x32 = 256; // tile-choice thresholds in tiles (tools/gemm_sweep.py)
     bool splitk = true;          // split-K through the LayerNorm in the AR layers
     bool lnfuse = false;         // LayerNorm as a GEMM prologue in the AR layers (measured slower, profiles/r01_lnfuse_ab.txt)
+    bool lnalg = true;           // ALGEBRAIC LayerNorm in the AR layers: LN1 -> QKV and LN2 -> ff.0 are ONE launch each,
+                                 // statistics in the GEMM's prologue, rstd * (acc - mean * s) + c in its epilogue
     int voc_streams = 3;         // resblock chains of a vocoder stage in flight (1 = serial)
     bool win_conv = true;        // window-convolution kernel for narrow square convs (Cin = Cout in {32, 64, 128})
     bool markers = false;        // a named no-op kernel at every stage boundary: lets tools/pmc_stage_summary.py attribute

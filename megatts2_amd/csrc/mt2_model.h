@@ -95,6 +95,10 @@ struct StackW {
 };
 struct EncLayerW {
     float *ln1g, *ln1b, *ln2g, *ln2b, *wqkv, *bqkv, *wo, *bo, *ff0w, *ff0b, *ff1w, *ff1b;
+    // algebraic-LayerNorm operands of the Linear-FF (AR) encoders, prepared once at load (gemm_f32.hip, PRO_LNA):
+    //   W'[n,k] = gamma[k] W[n,k],  s[n] = sum_k W'[n,k],  c[n] = sum_k beta[k] W[n,k] + b[n]
+    // for LN1 -> QKV (wqkv_l, sqkv, cqkv) and LN2 -> ff.0 (ff0_l, sff0, cff0); nullptr for conv-FF encoders
+    float *wqkv_l = nullptr, *sqkv = nullptr, *cqkv = nullptr, *ff0_l = nullptr, *sff0 = nullptr, *cff0 = nullptr;
 };
 struct EncW {
     std::vector<EncLayerW> layers;

@@ -189,6 +189,35 @@ def test_gemm_with_layernorm_prologue(rt, cfg, M, N, K):
         assert rel(out2, ref[2::3][:Ms]) < 3e-6
 
 
+@pytest.mark.parametrize("cfg", [-1, 12, 16, 17, 18, 20, 21, 22, 24, 27, 28, 29])
+@pytest.mark.parametrize("M,N,K", [(70, 2304, 768), (33, 96, 100), (300, 1024, 1024), (5, 64, 64), (1120, 768, 768)])
+def test_gemm_with_algebraic_layernorm(rt, cfg, M, N, K):
+    """LN(x) @ W^T + b in the algebraic form the AR layers run: gamma folded into the weights, row statistics in the
+    GEMM's prologue, rstd * (acc - mean * s) + c in its epilogue - every LDS-DMA tile family (plain, K-split, big tiles),
+    rows with a large common offset (the cancellation case), and the strided "last row of each sequence" gather."""
+    rng = np.random.default_rng(M + N + K)
+    X = (rng.standard_normal((M, K)) * 2.0 + 0.7).astype(np.float32)
+    X[::7] += 25.0                                     # |mean| >> std on some rows
+    g = rng.standard_normal(K).astype(np.float32)
+    b = rng.standard_normal(K).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    x64 = X.astype(np.float64)
+    ln = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * g + b
+    ref = np.maximum(ln @ W.T.astype(np.float64) + bias, 0)
+    out = rt.op_ln_gemm(dev(X), dev(g), dev(b), dev(W), dev(bias), epi_act=rt.ACT_RELU, force_cfg=cfg,
+                        algebraic=True).cpu().numpy()
+    assert rel(out, ref) < 2e-5                        # cancellation on the offset rows: ~ eps * |mean| / std
+    plain = np.ones(M, bool)
+    plain[::7] = False
+    assert rel(out[plain], ref[plain]) < 4e-6
+    if M >= 6:
+        Ms = (M - 3) // 3 + 1
+        out2 = rt.op_ln_gemm(dev(X), dev(g), dev(b), dev(W), dev(bias), M=Ms, a_mul=3, shift0=2, epi_act=rt.ACT_RELU,
+                             force_cfg=cfg, algebraic=True).cpu().numpy()
+        assert rel(out2, ref[2::3][:Ms]) < 2e-5
+
+
 @pytest.mark.parametrize("C", [32, 64, 384, 512, 768, 1024])
 def test_layernorm(rt, C):
     rng = np.random.default_rng(C)

@@ -438,39 +438,48 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     auto row_stats = [&]() {       // mean / rstd of this workgroup's BM rows -> LDS stat[BM][2] (two passes in registers)
         float* stat = smem + KS * NST * STAGE;                  // [BM][2]
         constexpr int NWALL = NW * KS;
+        constexpr int RB = 4;                                   // rows in flight per wave: ONE memory round trip per batch
         const int Kf = p.K;
         const float inv_k = 1.0f / (float)Kf;
-        for (int r0 = wave_all; r0 < BM; r0 += NWALL) {
-            const int m = m0 + r0;
-            int src = -1;
-            if (m < p.M) src = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
-            float4 xv[4];
-            float sum = 0.0f;
-            const bool ok = (unsigned)src < (unsigned)Rx;
+        for (int rb = wave_all * RB; rb < BM; rb += NWALL * RB) {
+            float4 xv[RB][4];
+            bool ok[RB];
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int c = (v * 64 + lane) * 4;
-                xv[v] = (ok && c < Kf) ? *reinterpret_cast<const float4*>(X + (long long)src * ldx + c)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-                sum += (xv[v].x + xv[v].y) + (xv[v].z + xv[v].w);
-            }
+            for (int u = 0; u < RB; ++u) {
+                const int m = m0 + rb + u;
+                int src = -1;
+                if (rb + u < BM && m < p.M) src = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
+                ok[u] = (unsigned)src < (unsigned)Rx;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum * inv_k;
-            float q2 = 0.0f;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int c = (v * 64 + lane) * 4;
-                if (c < Kf) {
-                    const float a = xv[v].x - mean, b = xv[v].y - mean, cc = xv[v].z - mean, d = xv[v].w - mean;
-                    q2 += (a * a + b * b) + (cc * cc + d * d);
+                for (int v = 0; v < 4; ++v) {
+                    const int c = (v * 64 + lane) * 4;
+                    xv[u][v] = (ok[u] && c < Kf) ? *reinterpret_cast<const float4*>(X + (long long)src * ldx + c)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
-            if (lane == 0) {
-                stat[2 * r0] = ok ? mean : 0.0f;
-                stat[2 * r0 + 1] = ok ? 1.0f / sqrtf(q2 * inv_k + p.ln_eps) : 0.0f;
+            for (int u = 0; u < RB; ++u) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sum += (xv[u][v].x + xv[u][v].y) + (xv[u][v].z + xv[u][v].w);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                const float mean = sum * inv_k;
+                float q2 = 0.0f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = (v * 64 + lane) * 4;
+                    if (c < Kf) {
+                        const float a = xv[u][v].x - mean, b = xv[u][v].y - mean, cc = xv[u][v].z - mean, d = xv[u][v].w - mean;
+                        q2 += (a * a + b * b) + (cc * cc + d * d);
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
+                if (lane == 0 && rb + u < BM) {
+                    stat[2 * (rb + u)] = ok[u] ? mean : 0.0f;
+                    stat[2 * (rb + u) + 1] = ok[u] ? 1.0f / sqrtf(q2 * inv_k + p.ln_eps) : 0.0f;
+                }
             }
         }
     };
@@ -1067,6 +1076,11 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     if (p.pro_act == PRO_LNA) {     // algebraic LayerNorm: every LDS-DMA configuration has the variant
         if (p.taps != 1 || p.K > 1024 || !p.ln_g || p.groups != 1) return hipErrorInvalidValue;
         if (!c->fn[PRO_LNA]) return hipErrorNotSupported;
+        // Measured (profiles/r02_lnalg_ab.txt): the statistics pass costs one memory round trip per 4 rows of a wave.
+        // Tiles whose waves own <= 4 rows each (the K-split configurations of the latency-bound AR launches) hide it
+        // behind the ring prefetch; a 256-row tile with 8 waves (32 rows per wave) pays ~20 us for it - slower than
+        // the LayerNorm launch it replaces.  Big tiles keep LayerNorm + GEMM as two launches.
+        if (o.force_cfg < 0 && c->bm / (c->threads / 64) > o.lnalg_rows) return hipErrorNotSupported;
     }
     size_t lds = c->lds, lds_attr = 0;
     if (p.pro_act == PRO_LN) {

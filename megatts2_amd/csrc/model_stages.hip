@@ -268,7 +268,6 @@ static int choose_split(const Ctx& c, int M, int N, int K) {
     if (!c.m.opts.splitk) return 1;
     // a split GEMM hands its reduction to a stand-alone LayerNorm launch, which the LayerNorm-prologue GEMM
     // (ln_linear) otherwise removes: worth it only for the long K chains (PLM ff.3, K = 4096)
-    if (c.m.opts.lnalg) return 1;       // the algebraic form has no stand-alone LayerNorm launch to ride on
     if (c.m.opts.lnfuse && K < 2048) return 1;
     const long long tiles = (long long)((M + 31) / 32) * ((N + 63) / 64);
     int S = 1;

@@ -51,6 +51,7 @@ struct EngineOpts {
     int t_ks4 = 256, t_ks2 = 640, t32 = 256, t32x32 = 256; // tile-choice thresholds in tiles (tools/gemm_sweep.py)
     bool splitk = true;          // split-K through the LayerNorm in the AR layers
     bool lnfuse = false;         // LayerNorm as a GEMM prologue in the AR layers (measured slower, profiles/r01_lnfuse_ab.txt)
+    int lnalg_rows = 4;          // ... for tile configurations whose waves own at most this many rows each (see launch_gemm)
     bool lnalg = true;           // ALGEBRAIC LayerNorm in the AR layers: LN1 -> QKV and LN2 -> ff.0 are ONE launch each,
                                  // statistics in the GEMM's prologue, rstd * (acc - mean * s) + c in its epilogue
     int voc_streams = 3;         // resblock chains of a vocoder stage in flight (1 = serial)

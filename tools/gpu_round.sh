@@ -90,6 +90,13 @@ sweep)
 sweep_ar)
   timeout 600 python tools/gemm_sweep.py ar > gpurun_out/gemm_sweep_ar.txt 2>&1
   echo "sweep_ar rc=$?"; cat gpurun_out/gemm_sweep_ar.txt ;;
+gaps)
+  # plain kernel trace (no counters) of one C2 step + per-queue gap analysis of the ADM stage
+  rm -rf gpurun_out/gaps
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/gaps -o t -- python $GRAFT_REPO_ROOT/bench.py --workload ${WL:-C2} --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --stage-markers) > gpurun_out/gaps.log 2>&1
+  echo "gaps rc=$?"; f=$(find gpurun_out/gaps -name "*kernel_trace.csv" | head -1)
+  [ -n "$f" ] && python tools/gap_analysis.py $f ${M0:-1} ${M1:-2} | tee gpurun_out/gap_analysis.txt
+  find gpurun_out/gaps -name "*.csv" -size +6M -delete ;;
 opts)
   # A/B of handle options on the default workload: OPTS="win_conv=0 ar_groups=1 ..." (one run per entry; "-" = defaults)
   for o in ${OPTS:--}; do

@@ -203,7 +203,8 @@ int mt2_synthesize_batch(mt2_model* m, void* stream, const int64_t* phone, const
 /* ---- tuning.  Every switch lives in the handle (no process-global state): two handles do not see each other's
  * settings.  Names: "ar_groups" (1..8, default 2: the sequences of an autoregressive run are dealt into that many
  * independent kernel chains on internal HIP streams that fork from and join back into `stream`; results do not
- * depend on it), "lnalg" (1: algebraic LayerNorm in the AR layers), "splitk" (1), "lnfuse" (0), "voc_streams" (3), "win_conv" (1), "force_gemm_config" (-1),
+ * depend on it), "lnalg" (0: algebraic LayerNorm in the AR layers), "splitk" (1), "lnfuse" (0), "voc_streams" (3),
+ * "x6_conv" (1: window convolutions on the bf16 matrix pipe in the f32-equivalent 6-product form), "win_conv" (1), "force_gemm_config" (-1),
  * "t_ks4", "t_ks2", "t32", "t32x32" (tile-choice thresholds).  Unknown names are an error. */
 int mt2_set_option(mt2_model* m, const char* name, int value);
 int mt2_get_option(mt2_model* m, const char* name, int* value);
@@ -221,6 +222,12 @@ int mt2_op_gemm(void* stream, const float* X, int ldx, int Rx, const int32_t* ro
                 int taps, int dil, int Cin, const float* W, int ldw, const float* bias, const float* R, int ldr,
                 const int32_t* valid, float* C, int ldc, int M, int N, int pro_act, float pro_slope, int epi_act,
                 float out_scale, int force_cfg);
+/* Window convolution with the weights additionally given as three bf16 planes W3 [3][N][K] (device uint16; truncation
+ * split: W = W3[0] + W3[1] + W3[2] exactly): the kernel may then run on the bf16 matrix pipe in the f32-equivalent
+ * 6-product form (conv_win_x6_kernel; force_cfg 34..36 or -1 for the automatic choice). */
+int mt2_op_gemm_x6(void* stream, const float* X, int ldx, int Rx, int shift0, int taps, int dil, int Cin, const float* W,
+                   const void* W3, const float* bias, const float* R, int ldr, const int32_t* valid, float* C, int ldc,
+                   int M, int N, int pro_act, float pro_slope, int epi_act, int force_cfg);
 /* C[M,N] = act(LayerNorm(X rows m*a_mul + shift0; gamma, beta, eps) @ W^T + bias) in one launch (AR steps: LN1 -> QKV,
  * LN2 -> ff.0).  K <= 1024.  algebraic = 0: fragments normalised on the fly (force_cfg -1 or a 2-deep-ring config);
  * algebraic = 1 (what the model runs): W must be the gamma-scaled weights W'[n,k] = gamma[k] W[n,k], `bias` the vector

@@ -852,6 +852,201 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_f32_kernel(GemmP p) {
     else epilogue<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
 }
 
+
+// ===================================================================================================
+// v3b: the WINDOW convolution on the bf16 matrix pipe, f32-equivalent ("x6").
+//
+// The f32 MFMA runs at 1/16 of the bf16 rate.  An f32 number is EXACTLY the sum of three bf16 numbers (truncation
+// split: a1 = top 16 bits of a, a2 = top 16 bits of a - a1, a3 = a - a1 - a2: 3 x 8 = 24 significant bits), a product
+// of two bf16 is exact in f32, and v_mfma_f32_32x32x16_bf16 accumulates in f32.  So
+//     a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2)  +  terms below 2^-24 |a||b| (dropped: a2b3, a3b2, a3b3)
+// gives the f32 product to f32 accuracy with SIX bf16 MFMAs (each 32x32x16 in 32 cycles) instead of eight f32 MFMAs
+// (32x32x2, 64 cycles each) for the same 16-deep k block: 2.67x the throughput at the accuracy of an f32 GEMM (the
+// result differs from an f32 fma chain only by summation order - the same class of difference as between any two
+// f32 GEMM implementations; tests/test_gpu_kernels.py::test_window_conv_x6_is_f32_equivalent measures it).
+//
+// Operands: the WEIGHTS are split once at load into three bf16 planes [3][Cout][K] and stream through the ring as
+// (3 x Cout x 32) bf16 chunks; the ACTIVATIONS stay f32 everywhere (same HBM formats as the f32 kernels): the f32
+// window is loaded into LDS exactly as in conv_win_f32_kernel and each A fragment (8 consecutive k of one row) is
+// split into its three planes in REGISTERS (11 VALU per 2 elements, on the vector pipe beside the matrix pipe) -
+// amortised over the TN column tiles a wave owns.  Epilogue and arithmetic order over taps unchanged.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int PRO>
+__device__ __forceinline__ void split3_bf16(const f32x4& lo, const f32x4& hi, float slope, u32x4& p1, u32x4& p2, u32x4& p3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = apply_act<PRO>(i < 2 ? lo[2 * i] : hi[2 * i - 4], slope);
+        const float y = apply_act<PRO>(i < 2 ? lo[2 * i + 1] : hi[2 * i - 3], slope);
+        const unsigned xb = __float_as_uint(x), yb = __float_as_uint(y);
+        p1[i] = __builtin_amdgcn_perm(yb, xb, 0x07060302u);                     // (hi16(x), hi16(y)): truncation to bf16
+        const float xr = x - __uint_as_float(xb & 0xffff0000u), yr = y - __uint_as_float(yb & 0xffff0000u);   // exact
+        const unsigned xc = __float_as_uint(xr), yc = __float_as_uint(yr);
+        p2[i] = __builtin_amdgcn_perm(yc, xc, 0x07060302u);
+        const float xs = xr - __uint_as_float(xc & 0xffff0000u), ys = yr - __uint_as_float(yc & 0xffff0000u);  // <= 8 bits left
+        p3[i] = __builtin_amdgcn_perm(__float_as_uint(ys), __float_as_uint(xs), 0x07060302u);
+    }
+}
+
+template <int QS, int BM, int BN, int WGM, int WGN, int NST, int PRO>
+__global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int BPIECES = 3 * BN / 16;                  // 1-KiB pieces of one weight chunk: 3 planes x BN rows x 64 B
+    constexpr int B_IT = (BPIECES + NW - 1) / NW;
+    constexpr int STAGE_B = B_IT * NW * 1024;             // BYTES per ring stage (dummy slots included)
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * B_IT < 64 && BN == 32 * QS, "config");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int taps = p.taps, dil = p.dil;
+    const int WR = BM + (taps - 1) * dil, WRp = (WR + 7) & ~7;
+    char* ring = reinterpret_cast<char*>(smem);
+    float* win = smem + NST * STAGE_B / 4;                          // [QS][WRp][32] f32, slot-swizzled rows
+
+    const int ntm = (p.M + BM - 1) / BM;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, qq = ntm >> 3, rr = ntm & 7;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int m0 = tile * BM;
+
+    const float* __restrict__ X = p.X;
+    const unsigned short* __restrict__ W3 = reinterpret_cast<const unsigned short*>(p.W3);
+    const long long zoff_x = (const float*)g_zero16 - X;
+    const long long zoff_w = (const unsigned short*)g_zero16 - W3;
+    const int ldx = p.ldx, Rx = p.Rx, Kt = p.K;
+    const long long plane = (long long)p.N * Kt;                    // elements per weight plane
+
+    {   // ---- the f32 input window, once (as conv_win_f32_kernel)
+        const int lrow = lane >> 3;
+        const int ppq = WRp >> 3, pieces = QS * ppq;
+        const int row_first = m0 + p.shift0;
+        for (int pc = wave; pc < pieces; pc += NW) {
+            const int q = pc / ppq, r8 = pc - q * ppq;
+            const int row = r8 * 8 + lrow;
+            const int grow = row_first + row;
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);
+            const bool ok = (row < WR) & ((unsigned)grow < (unsigned)Rx);
+            const long long off = ok ? (long long)grow * ldx + q * 32 + slot * 4 : zoff_x;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                             (__attribute__((address_space(3))) void*)(win + (q * WRp + r8 * 8) * 32), 16, 0, 0);
+        }
+    }
+    // ---- weight chunks (3 bf16 planes x BN rows x 32 k = 64-byte rows) through the ring; piece = 16 rows of one plane;
+    // lane -> row lane >> 2, physical 16-B slot lane & 3, logical slot = phys ^ ((row >> 2) & 3)
+    const int nk = Kt / 32;
+    long long wofs[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int pc = j * NW + wave;                    // piece = plane * (BN / 16) + row block
+        const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
+        const int n = rb * 16 + (lane >> 2);
+        const int sl = (lane & 3) ^ ((n >> 2) & 3);
+        wofs[j] = (pc < BPIECES && n < p.N) ? pl * plane + (long long)n * Kt + sl * 8 : -1;
+    }
+    auto issue = [&](int c, int st) {
+        char* Bs = ring + st * STAGE_B + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const long long off = wofs[j] >= 0 ? wofs[j] + c * 32 : zoff_w;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                             (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
+        }
+    };
+    constexpr bool PRET = TM * TN <= 2;
+    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
+    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, 0, m0 + wm * WTM, wn * WTN, lane);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nk) issue(st, st);
+
+    const float pro_slope = p.pro_slope;
+    const int half = lane >> 5;
+    const unsigned lds_ring = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
+    const unsigned lds_win = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)win;
+    // B fragment of k block b (16 k): logical slot b*2 + half of row n = wn*WTN + j*32 + (lane & 31), plane pl
+    const int nrow = wn * WTN + (lane & 31);
+    const unsigned b_lane = lds_ring + nrow * 64;
+    const int swzb = (nrow >> 2) & 3;
+    unsigned koffb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+    const int arow0 = wm * WTM + (lane & 31);
+
+    int st = 0, tap = 0, q = 0;
+    for (int c = 0; c < nk; ++c) {
+        if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * B_IT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int arow = arow0 + tap * dil;
+        const int swza = (arow >> 1) & 7;
+        const unsigned sa = lds_win + (unsigned)((q * WRp + arow) * BK) * 4;
+        const unsigned sb = b_lane + (unsigned)st * STAGE_B;
+        // raw operands of both 16-k blocks of this chunk: A = 2 x (two f32x4 = 8 consecutive k), B = 2 x 3 planes x TN
+        f32x4 ra[2][TM][2];
+        u32x4 rb[2][3][TN];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ra[b][i][0] = lds_read_b128(sa + (unsigned)(((b * 4 + half * 2) ^ swza) * 16) + i * 32 * BK * 4);
+                ra[b][i][1] = lds_read_b128(sa + (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16) + i * 32 * BK * 4);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
+                    rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
+                }
+        }
+        if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                u32x4 a1, a2, a3;
+                split3_bf16<PRO>(ra[b][i][0], ra[b][i][1], pro_slope, a1, a2, a3);
+                const bf16x8 A1 = __builtin_bit_cast(bf16x8, a1), A2 = __builtin_bit_cast(bf16x8, a2),
+                             A3 = __builtin_bit_cast(bf16x8, a3);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bf16x8 B1 = __builtin_bit_cast(bf16x8, rb[b][0][j]), B2 = __builtin_bit_cast(bf16x8, rb[b][1][j]),
+                                 B3 = __builtin_bit_cast(bf16x8, rb[b][2][j]);
+                    // smallest terms first: they meet an accumulator increment of their own size before the big one lands
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        st = st + 1 == NST ? 0 : st + 1;
+        if (++q == QS) { q = 0; ++tap; }
+    }
+    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, 0, m0 + wm * WTM, wn * WTN, lane);
+    else epilogue<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side: tile-configuration choice and launch
 
@@ -861,6 +1056,7 @@ struct TileCfg {
     const char* name;
     void (*fn[5])(GemmP);     // indexed by the prologue: none / relu / leaky relu / LayerNorm / algebraic LayerNorm (nullptr: no variant)
     int win_qs = 0;           // > 0: window convolution for Cin = Cout = 32 * win_qs
+    bool x6 = false;          // window convolution on the bf16 pipe (3-way split, 6 products): needs GemmP::W3
 };
 
 #define MT2_CFG(BM_, BN_, WM_, WN_)                                                                    \
@@ -892,6 +1088,12 @@ struct TileCfg {
       "win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                       \
       { conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_NONE>, conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
         conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, QS_ }
+
+#define MT2_WX6(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
+    { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024),   \
+      "x6win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                     \
+      { conv_win_x6_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_NONE>, conv_win_x6_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
+        conv_win_x6_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, QS_, true }
 
 static const TileCfg kCfgs[] = {
     // v1: register-staged double buffer (kept for A/B runs and as the reference implementation)
@@ -933,6 +1135,10 @@ static const TileCfg kCfgs[] = {
     MT2_WIN(2, 256, 64, 8, 1, 3),    // 31: 8 waves, 32x64 each; 24 + 80 KiB
     MT2_WIN(4, 128, 128, 4, 2, 3),   // 32: 8 waves, 32x64 each; 48 + 92 KiB
     MT2_WIN(2, 128, 64, 4, 2, 3),    // 33: 8 waves, 32x32 each; 24 + 46 KiB -> 2 workgroups per CU
+    // v3b: window convolutions on the bf16 pipe, f32-equivalent (6 products); ring stage = 3 planes x BN x 64 B
+    MT2_WX6(1, 256, 32, 8, 1, 3),    // 34: 8 waves, 32x32 each; 24 + 40 KiB
+    MT2_WX6(2, 256, 64, 8, 1, 3),    // 35: 8 waves, 32x64 each; 48 + 80 KiB
+    MT2_WX6(4, 128, 128, 4, 2, 2),   // 36: 8 waves, 32x64 each; 48 + 92 KiB
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -1042,6 +1248,7 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     int bi = 12;                                                        // dma64x64_2x2_s3
     if (o.win_conv && win_eligible(p) && !(o.force_cfg >= 0 && o.force_cfg < kNumCfgs)) {
         bi = p.Cin == 32 ? 30 : (p.Cin == 64 ? 31 : 32);
+        if (o.x6_conv && p.W3) bi += 4;                                 // the bf16-pipe form of the same tile
         *idx_out = bi;
         return &kCfgs[bi];
     }
@@ -1095,7 +1302,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     }
     if (p.pro_act == PRO_LNA) lds = c->lds + (size_t)c->bm * 2 * sizeof(float);     // + row statistics [BM][2]
     if (c->win_qs) {
-        if (!win_eligible(p) || p.Cin != 32 * c->win_qs) return hipErrorInvalidValue;
+        if (!win_eligible(p) || p.Cin != 32 * c->win_qs || (c->x6 && !p.W3)) return hipErrorInvalidValue;
         const int wrp = (c->bm + (p.taps - 1) * p.dil + 7) & ~7;
         lds = c->lds + (size_t)c->win_qs * wrp * BK * sizeof(float);
     }

@@ -152,12 +152,36 @@ struct Loader {
                 for (int64_t tap = 0; tap < k; ++tap)
                     o[(a * k + tap) * ci + c] = t.data[(a * ci + c) * k + tap];
     }
-    ConvW conv(const std::string& p, int cout, int cin, int k) {
+    // f32 -> three bf16 planes by truncation: v = p1 + p2 + p3 EXACTLY (3 x 8 significant bits); [3][n] uint16
+    void* upload_planes(const std::vector<float>& v) {
+        const size_t n = v.size();
+        std::vector<uint16_t> pl(3 * n);
+        for (size_t i = 0; i < n; ++i) {
+            float r = v[i];
+            for (int k = 0; k < 3; ++k) {
+                uint32_t bits;
+                std::memcpy(&bits, &r, 4);
+                bits &= 0xffff0000u;
+                float top;
+                std::memcpy(&top, &bits, 4);
+                pl[k * n + i] = (uint16_t)(bits >> 16);
+                r -= top;                       // exact
+            }
+        }
+        void* d = nullptr;
+        MT2_HIP(hipMalloc(&d, pl.size() * sizeof(uint16_t)));
+        MT2_HIP(hipMemcpy(d, pl.data(), pl.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        m.dev_allocs.push_back(d);
+        m.weight_bytes += pl.size() * sizeof(uint16_t);
+        return d;
+    }
+    ConvW conv(const std::string& p, int cout, int cin, int k, bool planes = false) {
         ConvW w;
         w.cout = cout; w.cin = cin; w.k = k;
         std::vector<float> packed;
         pack_conv(get(p + ".weight", {cout, cin, k}), packed);
         w.w = upload(packed);
+        if (planes) w.w3 = upload_planes(packed);
         w.b = vec(p + ".bias", cout);
         return w;
     }
@@ -388,8 +412,9 @@ void finalize_model(mt2_model& m) {
                 const std::string rp = "hifigan.resblocks." + std::to_string(i * c.hg_n_res + j);
                 for (int n = 0; n < 3; ++n) {
                     r.dil[n] = c.hg_res_dilations[j][n];
-                    r.c1[n] = L.conv(rp + ".convs1." + std::to_string(n), co, co, r.k);
-                    r.c2[n] = L.conv(rp + ".convs2." + std::to_string(n), co, co, r.k);
+                    const bool x6 = co == 32 || co == 64 || co == 128;     // window-convolution widths: + bf16 planes
+                    r.c1[n] = L.conv(rp + ".convs1." + std::to_string(n), co, co, r.k, x6);
+                    r.c2[n] = L.conv(rp + ".convs2." + std::to_string(n), co, co, r.k, x6);
                 }
                 m.hg_res.push_back(r);
             }

@@ -142,7 +142,7 @@ static void conv_same(const Ctx& c, const float* x, int ldx, int R, const ConvW&
                       const float* Rsd = nullptr, int ldr = 0, int dil = 1) {
     GemmP p{};
     p.X = x; p.ldx = ldx; p.Rx = R; p.taps = w.k; p.dil = dil; p.shift0 = -((w.k - 1) / 2) * dil; p.Cin = w.cin;
-    p.W = w.w; p.bias = w.b; p.R = Rsd; p.ldr = ldr; p.valid = valid; p.C = y; p.ldc = ldy; p.M = R; p.N = w.cout;
+    p.W = w.w; p.W3 = w.w3; p.bias = w.b; p.R = Rsd; p.ldr = ldr; p.valid = valid; p.C = y; p.ldc = ldy; p.M = R; p.N = w.cout;
     p.pro_act = pro_act; p.pro_slope = slope; p.epi_act = epi_act;
     gemm(c, p);
 }

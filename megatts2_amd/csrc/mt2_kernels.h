@@ -29,6 +29,8 @@ struct GemmP {
     const float* X; long long strideX; int ldx; int Rx;
     const int* rowbase; int a_mul; int shift0; int taps; int dil; int Cin;
     const float* W; long long strideW; int ldw;
+    const void* W3 = nullptr;   // optional: the same weights as three bf16 planes [3][N][K] (truncation split, exact sum) -
+                                // lets launch_gemm run a window convolution on the bf16 matrix pipe (conv_win_x6_kernel)
     const float* bias; long long strideB;
     const float* R; long long strideR; int ldr;
     const int* valid;
@@ -52,10 +54,11 @@ struct EngineOpts {
     bool splitk = true;          // split-K through the LayerNorm in the AR layers
     bool lnfuse = false;         // LayerNorm as a GEMM prologue in the AR layers (measured slower, profiles/r01_lnfuse_ab.txt)
     int lnalg_rows = 4;          // ... for tile configurations whose waves own at most this many rows each (see launch_gemm)
-    bool lnalg = true;           // ALGEBRAIC LayerNorm in the AR layers: LN1 -> QKV and LN2 -> ff.0 are ONE launch each,
+    bool lnalg = false;          // ALGEBRAIC LayerNorm in the AR layers: LN1 -> QKV and LN2 -> ff.0 are ONE launch each,
                                  // statistics in the GEMM's prologue, rstd * (acc - mean * s) + c in its epilogue
     int voc_streams = 3;         // resblock chains of a vocoder stage in flight (1 = serial)
     bool win_conv = true;        // window-convolution kernel for narrow square convs (Cin = Cout in {32, 64, 128})
+    bool x6_conv = true;         // ... on the bf16 matrix pipe, f32-equivalent 3-way split (6 products), where W3 planes exist
     bool markers = false;        // a named no-op kernel at every stage boundary: lets tools/pmc_stage_summary.py attribute
                                  // the rocprofv3 --pmc rows of one step to stages (measurement only)
     bool trace_on = false;       // HIP events around every GEMM launch (measurement only)

@@ -86,7 +86,10 @@ class IntPlan {
     int* d_ = nullptr;
 };
 
-struct ConvW { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, k = 0; };
+struct ConvW {
+    float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, k = 0;
+    void* w3 = nullptr;     // optional: the packed weights as three bf16 planes [3][cout][k*cin] (GemmP::W3)
+};
 // grouped residual stack: entry (s, blk) holds `groups` consecutive [C, k*C] matrices
 struct StackW {
     float *w = nullptr, *b = nullptr, *g = nullptr, *be = nullptr;

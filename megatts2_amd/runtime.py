@@ -550,6 +550,33 @@ def op_gemm(X, W, bias=None, R=None, valid=None, rowbase=None, a_mul=1, shift0=0
     return out
 
 
+def split_bf16x3(W):
+    """f32 tensor -> three bf16 planes (uint16 bit patterns, [3, *W.shape]) by truncation; their sum is W exactly."""
+    import torch
+    r = W.detach().to(torch.float32).cpu().clone()
+    planes = []
+    for _ in range(3):
+        bits = r.view(torch.int32) & -65536          # 0xffff0000
+        planes.append((bits >> 16).to(torch.int16))
+        r = r - bits.view(torch.float32)
+    return torch.stack(planes).contiguous()
+
+
+def op_conv_x6(X, W, bias=None, R=None, valid=None, shift0=0, taps=1, dil=1, Cin=None, pro_act=ACT_NONE, pro_slope=0.0,
+               epi_act=ACT_NONE, force_cfg=-1):
+    """Window convolution with bf16 weight planes (mt2_op_gemm_x6): X [rows, Cin] f32, W [N, taps*Cin] f32."""
+    import torch
+    lib = load_library()
+    Cin = Cin or X.shape[1]
+    N, M = W.shape[0], X.shape[0]
+    W3 = split_bf16x3(W).to(X.device)
+    out = torch.empty(M, N, device=X.device, dtype=torch.float32)
+    _check(lib.mt2_op_gemm_x6(_stream(), _ptr(X), X.shape[1], M, shift0, taps, dil, Cin, _ptr(W), _ptr(W3), _ptr(bias),
+                              _ptr(R), R.shape[1] if R is not None else 0, _ptr(valid), _ptr(out), N, M, N, pro_act,
+                              C.c_float(pro_slope), epi_act, force_cfg))
+    return out
+
+
 def op_ln_gemm(X, gamma, beta, W, bias=None, M=None, a_mul=1, shift0=0, eps=1e-5, epi_act=ACT_NONE, force_cfg=-1,
                algebraic=False):
     """LN(X) @ W^T + b in one launch.  algebraic=True folds gamma / beta into the operands on the host (float64 sums,

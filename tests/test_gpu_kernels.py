@@ -189,6 +189,54 @@ def test_gemm_with_layernorm_prologue(rt, cfg, M, N, K):
         assert rel(out2, ref[2::3][:Ms]) < 3e-6
 
 
+@pytest.mark.parametrize("k,dil,C,cfg", [(3, 1, 32, 34), (7, 3, 32, 34), (11, 5, 32, -1), (3, 5, 64, 35), (7, 1, 64, -1),
+                                         (11, 5, 64, 35), (3, 3, 128, 36), (7, 5, 128, -1), (11, 1, 128, 36)])
+@pytest.mark.parametrize("pro", ["none", "lrelu"])
+def test_window_conv_x6_is_f32_equivalent(rt, k, dil, C, cfg, pro):
+    """The window convolution on the bf16 matrix pipe (weights as three bf16 planes, activations split in registers,
+    six products per k block): measured against float64 it must be AS ACCURATE AS the f32-MFMA kernel on the same
+    data - that is the claim "f32-equivalent" - on data with a wide dynamic range (so that the low planes matter)."""
+    rng = np.random.default_rng(k * 1000 + dil * 10 + C + 7)
+    lens = [700, 1, 300, 33]
+    G = ((k - 1) // 2) * dil
+    off, rows = [], 0
+    for n in lens:
+        off.append(rows)
+        rows += n + G
+    rows -= G
+    X = np.zeros((rows, C), np.float32)
+    valid = np.zeros(rows, np.int32)
+    utts = []
+    for o, n in zip(off, lens):
+        u = (rng.standard_normal((n, C)) * np.exp(rng.uniform(-4, 4, (n, C)))).astype(np.float32)   # 3.5 decades
+        X[o:o + n] = u
+        valid[o:o + n] = 1
+        utts.append(u)
+    w = (rng.standard_normal((C, C, k)) / math.sqrt(C * k) * np.exp(rng.uniform(-2, 2, (C, C, k)))).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    R = rng.standard_normal((rows, C)).astype(np.float32)
+    wp = np.ascontiguousarray(w.transpose(0, 2, 1).reshape(C, k * C))
+    act = {"none": rt.ACT_NONE, "lrelu": rt.ACT_LRELU}[pro]
+    kw = dict(valid=dev(valid), shift0=-G, taps=k, dil=dil, Cin=C, pro_act=act, pro_slope=0.1)
+    x6 = rt.op_conv_x6(dev(X), dev(wp), dev(b), dev(R), force_cfg=cfg, **kw).cpu().numpy()
+    f32 = rt.op_gemm(dev(X), dev(wp), dev(b), dev(R), force_cfg={32: 30, 64: 31, 128: 32}[C], **kw).cpu().numpy()
+    f = (lambda v: v) if pro == "none" else (lambda v: np.where(v >= 0, v, v * np.float32(0.1)).astype(np.float32))
+    err6 = err32 = 0.0
+    for o, n, u in zip(off, lens, utts):
+        a = f(u).astype(np.float64)
+        ap = np.zeros((n + 2 * G, C))
+        ap[G:G + n] = a
+        ref = np.zeros((n, C))
+        for t in range(k):
+            ref += ap[t * dil:t * dil + n] @ w[:, :, t].T.astype(np.float64)
+        ref += b + R[o:o + n]
+        err6 = max(err6, rel(x6[o:o + n], ref))
+        err32 = max(err32, rel(f32[o:o + n], ref))
+    assert err6 < 1e-6 and err6 <= 2.0 * err32 + 1e-7, (err6, err32)      # f32-class: not worse than the f32 MFMA kernel
+    assert not x6[valid == 0].any()
+    assert rel(x6, f32) < 2e-6
+
+
 @pytest.mark.parametrize("cfg", [-1, 12, 16, 17, 18, 20, 21, 22, 24, 27, 28, 29])
 @pytest.mark.parametrize("M,N,K", [(70, 2304, 768), (33, 96, 100), (300, 1024, 1024), (5, 64, 64), (1120, 768, 768)])
 def test_gemm_with_algebraic_layernorm(rt, cfg, M, N, K):

@@ -919,7 +919,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
     const long long zoff_x = (const float*)g_zero16 - X;
     const long long zoff_w = (const unsigned short*)g_zero16 - W3;
     const int ldx = p.ldx, Rx = p.Rx, Kt = p.K;
-    const long long plane = (long long)p.N * Kt;                    // elements per weight plane
+    const long long plane = p.w3_plane;                             // elements between the weight planes
 
     {   // ---- the f32 input window, once (as conv_win_f32_kernel)
         const int lrow = lane >> 3;
@@ -946,7 +946,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
         const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
         const int n = rb * 16 + (lane >> 2);
         const int sl = (lane & 3) ^ ((n >> 2) & 3);
-        wofs[j] = (pc < BPIECES && n < p.N) ? pl * plane + (long long)n * Kt + sl * 8 : -1;
+        wofs[j] = (pc < BPIECES && n < p.N) ? pl * plane + (long long)n * p.ldw + sl * 8 : -1;
     }
     auto issue = [&](int c, int st) {
         char* Bs = ring + st * STAGE_B + wave * 1024;
@@ -1047,6 +1047,184 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
     else epilogue<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
 }
 
+
+// ===================================================================================================
+// v2b: the implicit-GEMM engine on the bf16 matrix pipe, f32-equivalent ("x6", see conv_win_x6_kernel for the
+// arithmetic).  Same operand path as gemm_f32_dma_kernel - A chunks (f32, conv taps / row gathers / zero fill) and B
+// chunks through an LDS-DMA ring, XOR-swizzled, counted vmcnt - except that B travels as three bf16 planes
+// (3 x BN x 32 bf16 per chunk, 64-byte rows) and every A fragment is split into its planes in registers.  Used for
+// the throughput-bound launches (big tiles: conv stacks, vocoder stage 1, the large-M AR GEMMs); the latency-bound
+// K-split tiles stay on the f32 kernel.
+template <int BM, int BN, int WGM, int WGN, int NST, int PRO>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int A_IT = BM / (8 * NW);                   // f32 pieces: 8 rows x 128 B
+    constexpr int BPIECES = 3 * BN / 16;                  // bf16 plane pieces: 16 rows x 64 B
+    constexpr int B_IT = (BPIECES + NW - 1) / NW;
+    constexpr int L = A_IT + B_IT;
+    constexpr int STAGE_A = BM * BK * 4, STAGE_B = B_IT * NW * 1024, STAGE = STAGE_A + STAGE_B;   // bytes
+    static_assert(BM % (8 * NW) == 0 && WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64, "config");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* ring = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int g = blockIdx.z;
+
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const bool nmajor = p.M < p.N;
+    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
+
+    const float* __restrict__ X = p.X + (long long)g * p.strideX;
+    const unsigned short* __restrict__ W3 = reinterpret_cast<const unsigned short*>(p.W3) + (long long)g * p.strideW;
+    const long long zoff_x = (const float*)g_zero16 - X;
+    const long long zoff_w = (const unsigned short*)g_zero16 - W3;
+    const long long plane = p.w3_plane;
+
+    const int lrow = lane >> 3;
+    auto kslot_of = [&](int j) { return ((lane & 7) ^ (((j * NW + wave) * 4 + (lane >> 4)) & 7)) * 4; };
+    int abase[A_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+        const int m = m0 + (j * NW + wave) * 8 + lrow;
+        int b = kInvalidRow;
+        if (m < p.M) b = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
+        abase[j] = b;
+    }
+    const int Kt = p.K, ldw = p.ldw;
+    long long wofs[B_IT];
+    int wk[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int pc = j * NW + wave;                    // piece = plane * (BN / 16) + row block
+        const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
+        const int nl = rb * 16 + (lane >> 2);
+        const int n = n0 + nl;
+        wk[j] = ((lane & 3) ^ ((nl >> 2) & 3)) * 8;     // k offset of this lane's 16-byte slot inside a chunk
+        wofs[j] = (pc < BPIECES && n < p.N) ? pl * plane + (long long)n * ldw : -1;
+    }
+    const int nk = (Kt + BK - 1) / BK;
+    const int ldx = p.ldx, Rx = p.Rx, Cin = p.Cin, dil = p.dil;
+    const bool multi_tap = p.taps > 1;
+    wait_vmcnt<0>();
+    constexpr bool PRET = TM * TN <= 2;
+    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
+    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+
+    auto issue = [&](int c, int st) {
+        const int kchunk = c * BK;
+        float* As = reinterpret_cast<float*>(ring + st * STAGE) + wave * 256;
+        char* Bs = ring + st * STAGE + STAGE_A + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            const int k = kchunk + kslot_of(NW % 2 == 0 ? 0 : j);
+            int tap = 0, cc = k;
+            if (multi_tap) { tap = k / Cin; cc = k - tap * Cin; }
+            const int src = abase[j] + tap * dil;
+            const bool ok = (k < Kt) & ((unsigned)src < (unsigned)Rx);
+            const long long off = ok ? (long long)src * ldx + cc : zoff_x;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                             (__attribute__((address_space(3))) void*)(As + j * NW * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const int k = kchunk + wk[j];
+            const bool ok = (k < Kt) & (wofs[j] >= 0);
+            const long long off = ok ? wofs[j] + k : zoff_w;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                             (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nk) issue(st, st);
+
+    const float pro_slope = p.pro_slope;
+    const int half = lane >> 5;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
+    const int swza = (lane >> 1) & 7;
+    const unsigned a_lane = lds0 + ((wm * WTM + (lane & 31)) * BK) * 4;
+    const int nrow = wn * WTN + (lane & 31);
+    const int swzb = (nrow >> 2) & 3;
+    const unsigned b_lane = lds0 + STAGE_A + nrow * 64;
+    unsigned koffa[2][2], koffb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        koffa[b][0] = (unsigned)(((b * 4 + half * 2) ^ swza) * 16);
+        koffa[b][1] = (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
+        koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+    }
+
+    int st = 0;
+    for (int c = 0; c < nk; ++c) {
+        if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
+        f32x4 ra[2][TM][2];
+        u32x4 rb[2][3][TN];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ra[b][i][0] = lds_read_b128(sa + koffa[b][0] + i * 32 * BK * 4);
+                ra[b][i][1] = lds_read_b128(sa + koffa[b][1] + i * 32 * BK * 4);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
+                    rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
+                }
+        }
+        if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                u32x4 a1, a2, a3;
+                split3_bf16<PRO>(ra[b][i][0], ra[b][i][1], pro_slope, a1, a2, a3);
+                const bf16x8 A1 = __builtin_bit_cast(bf16x8, a1), A2 = __builtin_bit_cast(bf16x8, a2),
+                             A3 = __builtin_bit_cast(bf16x8, a3);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bf16x8 B1 = __builtin_bit_cast(bf16x8, rb[b][0][j]), B2 = __builtin_bit_cast(bf16x8, rb[b][1][j]),
+                                 B3 = __builtin_bit_cast(bf16x8, rb[b][2][j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        st = st + 1 == NST ? 0 : st + 1;
+    }
+    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side: tile-configuration choice and launch
 
@@ -1089,6 +1267,12 @@ struct TileCfg {
       { conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_NONE>, conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
         conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, QS_ }
 
+#define MT2_GX6(BM_, BN_, WM_, WN_, NST_)                                                                      \
+    { BM_, BN_, WM_* WN_ * 64,                                                                                    \
+      (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024), \
+      "x6dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                          \
+      { gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_NONE>, gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
+        gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
 #define MT2_WX6(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024),   \
       "x6win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                     \
@@ -1139,6 +1323,9 @@ static const TileCfg kCfgs[] = {
     MT2_WX6(1, 256, 32, 8, 1, 3),    // 34: 8 waves, 32x32 each; 24 + 40 KiB
     MT2_WX6(2, 256, 64, 8, 1, 3),    // 35: 8 waves, 32x64 each; 48 + 80 KiB
     MT2_WX6(4, 128, 128, 4, 2, 2),   // 36: 8 waves, 32x64 each; 48 + 92 KiB
+    // v2b: implicit GEMM on the bf16 pipe, f32-equivalent; stage = BM x 128 B (A, f32) + 3 x BN x 64 B (B planes)
+    MT2_GX6(256, 128, 4, 2, 2),      // 37: 8 waves, 64x64 each; 2 x 56 KiB
+    MT2_GX6(128, 128, 4, 2, 3),      // 38: 8 waves, 32x64 each; 3 x 40 KiB
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -1266,6 +1453,11 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     else if (t32 <= o.t32) bi = 22;                                     // dma32x64_1x2_k4_s2
     else if (t64 <= o.t_ks4) bi = 20;                                   // dma64x64_2x2_k4_s2
     else if (t64 <= o.t_ks2) bi = 18;                                   // dma64x64_2x2_k2_s2
+    // throughput-bound launches (the big 8-wave tiles) move to the bf16 pipe when the weights come with planes
+    if (o.x6_gemm && p.W3 && (p.K & 7) == 0 && (p.ldw & 7) == 0 && p.pro_act < PRO_LN) {
+        if (bi == 16) bi = 37;
+        else if (bi == 17) bi = 38;
+    }
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;
     *idx_out = bi;
     return &kCfgs[bi];
@@ -1301,8 +1493,10 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
         lds = c->lds + (size_t)ks * 2 * 256 * sizeof(float) + (size_t)c->bm * 2 * sizeof(float);
     }
     if (p.pro_act == PRO_LNA) lds = c->lds + (size_t)c->bm * 2 * sizeof(float);     // + row statistics [BM][2]
+    if (c->x6 && (!p.W3 || (p.K & 7) || (p.ldw & 7) || p.pro_act >= PRO_LN)) return hipErrorInvalidValue;
+    if (c->x6 && p.w3_plane == 0) p.w3_plane = (long long)p.N * p.ldw;
     if (c->win_qs) {
-        if (!win_eligible(p) || p.Cin != 32 * c->win_qs || (c->x6 && !p.W3)) return hipErrorInvalidValue;
+        if (!win_eligible(p) || p.Cin != 32 * c->win_qs) return hipErrorInvalidValue;
         const int wrp = (c->bm + (p.taps - 1) * p.dil + 7) & ~7;
         lds = c->lds + (size_t)c->win_qs * wrp * BK * sizeof(float);
     }

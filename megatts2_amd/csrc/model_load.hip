@@ -13,6 +13,7 @@
 //            (see hifigan stage in model_stages.hip)
 #include "mt2_model.h"
 
+#include <algorithm>
 #include <cstring>
 
 namespace mt2 {
@@ -129,31 +130,19 @@ struct Loader {
     }
     bool has(const std::string& name) const { return m.host.count(name) != 0; }
 
-    float* upload(const std::vector<float>& v) {
+    // planes = true: a GEMM / conv weight matrix - also kept as three bf16 planes (PlaneRange)
+    float* upload(const std::vector<float>& v, bool planes = false) {
         float* d = nullptr;
         const size_t bytes = v.size() * sizeof(float);
         MT2_HIP(hipMalloc(reinterpret_cast<void**>(&d), bytes ? bytes : 4));
         if (bytes) MT2_HIP(hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice));
         m.dev_allocs.push_back(d);
         m.weight_bytes += bytes;
+        if (planes && !v.empty()) m.planes.push_back({d, v.size(), upload_planes(v)});
         return d;
     }
-    float* vec(const std::string& name, int64_t n) { return upload(get(name, {n}).data); }
-    float* mat(const std::string& name, int64_t r, int64_t c) { return upload(get(name, {r, c}).data); }
-
-    // [Cout, Cin, k] -> [Cout, k*Cin]
-    static void pack_conv(const HostTensor& t, std::vector<float>& out) {
-        const int64_t co = t.shape[0], ci = t.shape[1], k = t.shape[2];
-        const size_t base = out.size();
-        out.resize(base + (size_t)co * ci * k);
-        float* o = out.data() + base;
-        for (int64_t a = 0; a < co; ++a)
-            for (int64_t c = 0; c < ci; ++c)
-                for (int64_t tap = 0; tap < k; ++tap)
-                    o[(a * k + tap) * ci + c] = t.data[(a * ci + c) * k + tap];
-    }
     // f32 -> three bf16 planes by truncation: v = p1 + p2 + p3 EXACTLY (3 x 8 significant bits); [3][n] uint16
-    void* upload_planes(const std::vector<float>& v) {
+    const uint16_t* upload_planes(const std::vector<float>& v) {
         const size_t n = v.size();
         std::vector<uint16_t> pl(3 * n);
         for (size_t i = 0; i < n; ++i) {
@@ -173,18 +162,32 @@ struct Loader {
         MT2_HIP(hipMemcpy(d, pl.data(), pl.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
         m.dev_allocs.push_back(d);
         m.weight_bytes += pl.size() * sizeof(uint16_t);
-        return d;
+        return static_cast<const uint16_t*>(d);
     }
-    ConvW conv(const std::string& p, int cout, int cin, int k, bool planes = false) {
+    float* vec(const std::string& name, int64_t n) { return upload(get(name, {n}).data); }
+    float* mat(const std::string& name, int64_t r, int64_t c) { return upload(get(name, {r, c}).data); }
+
+    // [Cout, Cin, k] -> [Cout, k*Cin]
+    static void pack_conv(const HostTensor& t, std::vector<float>& out) {
+        const int64_t co = t.shape[0], ci = t.shape[1], k = t.shape[2];
+        const size_t base = out.size();
+        out.resize(base + (size_t)co * ci * k);
+        float* o = out.data() + base;
+        for (int64_t a = 0; a < co; ++a)
+            for (int64_t c = 0; c < ci; ++c)
+                for (int64_t tap = 0; tap < k; ++tap)
+                    o[(a * k + tap) * ci + c] = t.data[(a * ci + c) * k + tap];
+    }
+    ConvW conv(const std::string& p, int cout, int cin, int k) {
         ConvW w;
         w.cout = cout; w.cin = cin; w.k = k;
         std::vector<float> packed;
         pack_conv(get(p + ".weight", {cout, cin, k}), packed);
-        w.w = upload(packed);
-        if (planes) w.w3 = upload_planes(packed);
+        w.w = upload(packed, true);
         w.b = vec(p + ".bias", cout);
         return w;
     }
+    float* wmat(const std::string& name, int64_t r, int64_t c) { return upload(get(name, {r, c}).data, true); }
     // ResidualBlockStack of `groups` parallel branches; prefix(l) gives branch l's stack prefix
     template <class F> StackW stack(F prefix, int groups, int C, int k, int nstack, int nblock) {
         StackW s;
@@ -203,7 +206,7 @@ struct Loader {
                     const auto& ee = get(p + ".norm.bias", {C}).data;
                     be.insert(be.end(), ee.begin(), ee.end());
                 }
-        s.w = upload(w); s.b = upload(b); s.g = upload(g); s.be = upload(be);
+        s.w = upload(w, true); s.b = upload(b); s.g = upload(g); s.be = upload(be);
         return s;
     }
     EncW encoder(const std::string& prefix, int layers, int d, int ff, int heads, bool conv_ff) {
@@ -221,18 +224,18 @@ struct Loader {
                 const auto& bb = get(p + ".attn." + n + ".bias", {d}).data;
                 bqkv.insert(bqkv.end(), bb.begin(), bb.end());
             }
-            w.wqkv = upload(qkv); w.bqkv = upload(bqkv);
-            w.wo = mat(p + ".attn.out_proj.0.weight", d, d);
+            w.wqkv = upload(qkv, true); w.bqkv = upload(bqkv);
+            w.wo = wmat(p + ".attn.out_proj.0.weight", d, d);
             w.bo = vec(p + ".attn.out_proj.0.bias", d);
             if (conv_ff) {
                 std::vector<float> a, c;
                 pack_conv(get(p + ".ff.0.weight", {ff, d, 5}), a);
                 pack_conv(get(p + ".ff.2.weight", {d, ff, 5}), c);
-                w.ff0w = upload(a); w.ff0b = vec(p + ".ff.0.bias", ff);
-                w.ff1w = upload(c); w.ff1b = vec(p + ".ff.2.bias", d);
+                w.ff0w = upload(a, true); w.ff0b = vec(p + ".ff.0.bias", ff);
+                w.ff1w = upload(c, true); w.ff1b = vec(p + ".ff.2.bias", d);
             } else {
-                w.ff0w = mat(p + ".ff.0.weight", ff, d); w.ff0b = vec(p + ".ff.0.bias", ff);
-                w.ff1w = mat(p + ".ff.3.weight", d, ff); w.ff1b = vec(p + ".ff.3.bias", d);
+                w.ff0w = wmat(p + ".ff.0.weight", ff, d); w.ff0b = vec(p + ".ff.0.bias", ff);
+                w.ff1w = wmat(p + ".ff.3.weight", d, ff); w.ff1b = vec(p + ".ff.3.bias", d);
                 // algebraic-LayerNorm operands (EncLayerW): sums in double, stored as f32
                 auto fold = [&](const std::vector<float>& W, const std::vector<float>& b, const std::vector<float>& gam,
                                 const std::vector<float>& bet, int N, float*& Wl, float*& sv, float*& cv) {
@@ -299,7 +302,7 @@ void finalize_model(mt2_model& m) {
                        c.mrte_n_layer, H, c.mrte_kernel, c.mrte_n_stack, c.mrte_n_block);
     m.phone_enc = L.encoder("G.mrte.phone_encoder.layers", c.content_n_layers, H, c.content_ff_dim,
                             c.content_n_heads, true);
-    m.x_wq = L.mat("G.mrte.mha.w_q.weight", H, H);
+    m.x_wq = L.wmat("G.mrte.mha.w_q.weight", H, H);
     m.x_bq = L.vec("G.mrte.mha.w_q.bias", H);
     {
         std::vector<float> kv, bkv;
@@ -309,10 +312,10 @@ void finalize_model(mt2_model& m) {
             const auto& bb = L.get(std::string("G.mrte.mha.") + n + ".bias", {H}).data;
             bkv.insert(bkv.end(), bb.begin(), bb.end());
         }
-        m.x_wkv = L.upload(kv);
+        m.x_wkv = L.upload(kv, true);
         m.x_bkv = L.upload(bkv);
     }
-    m.x_wo = L.mat("G.mrte.mha.out_proj.0.weight", H, H);
+    m.x_wo = L.wmat("G.mrte.mha.out_proj.0.weight", H, H);
     m.x_bo = L.vec("G.mrte.mha.out_proj.0.bias", H);
     m.x_ng = L.vec("G.mrte.norm.weight", H);
     m.x_nb = L.vec("G.mrte.norm.bias", H);
@@ -357,7 +360,7 @@ void finalize_model(mt2_model& m) {
         MT2_REQUIRE(c.adm_emb_dim % 4 == 0 && c.adm_tc_emb_dim % 4 == 0, "ADM embedding widths");
         m.adm_enc = L.encoder("adm.adm.layers", c.adm_layers, d, ff, c.adm_heads, false);
         m.adm_wdt = L.upload(L.get("adm.dt_linear_emb.weight", {c.adm_emb_dim, 1}).data);
-        m.adm_wtc = L.mat("adm.tc_linear_emb.weight", c.adm_tc_emb_dim, c.adm_tc_dim);
+        m.adm_wtc = L.wmat("adm.tc_linear_emb.weight", c.adm_tc_emb_dim, c.adm_tc_dim);
         m.adm_wpred = L.upload(L.get("adm.predict_layer.weight", {1, d}).data);
         (void)L.get("adm.pos_emb.alpha", {1});
         m.pe_adm = L.mat("pe.adm", c.max_positions, d);
@@ -404,7 +407,7 @@ void finalize_model(mt2_model& m) {
                 }
             UpW u;
             u.cin = ch; u.cout = co; u.stride = s;
-            u.wlo = L.upload(lo); u.whi = L.upload(hi); u.bias = L.upload(bias);
+            u.wlo = L.upload(lo, true); u.whi = L.upload(hi, true); u.bias = L.upload(bias);
             m.hg_up.push_back(u);
             for (int j = 0; j < c.hg_n_res; ++j) {
                 ResW r;
@@ -412,9 +415,8 @@ void finalize_model(mt2_model& m) {
                 const std::string rp = "hifigan.resblocks." + std::to_string(i * c.hg_n_res + j);
                 for (int n = 0; n < 3; ++n) {
                     r.dil[n] = c.hg_res_dilations[j][n];
-                    const bool x6 = co == 32 || co == 64 || co == 128;     // window-convolution widths: + bf16 planes
-                    r.c1[n] = L.conv(rp + ".convs1." + std::to_string(n), co, co, r.k, x6);
-                    r.c2[n] = L.conv(rp + ".convs2." + std::to_string(n), co, co, r.k, x6);
+                    r.c1[n] = L.conv(rp + ".convs1." + std::to_string(n), co, co, r.k);
+                    r.c2[n] = L.conv(rp + ".convs2." + std::to_string(n), co, co, r.k);
                 }
                 m.hg_res.push_back(r);
             }
@@ -427,6 +429,7 @@ void finalize_model(mt2_model& m) {
     for (auto& kv : m.host)
         if (!L.used.count(kv.first)) throw Error("unexpected tensor in state_dict: " + kv.first);
     m.host.clear();
+    std::sort(m.planes.begin(), m.planes.end(), [](const PlaneRange& a, const PlaneRange& b) { return a.base < b.base; });
     m.finalized = true;
 }
 

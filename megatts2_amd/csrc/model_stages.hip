@@ -68,7 +68,20 @@ struct Ctx {
     Arena& ws;
 };
 
+// the bf16 planes of a weight pointer, if its buffer has them (mt2_model::planes, sorted by base)
+static void attach_planes(const mt2_model& m, GemmP& p) {
+    if (p.W3 || m.planes.empty()) return;
+    auto it = std::upper_bound(m.planes.begin(), m.planes.end(), p.W,
+                               [](const float* w, const PlaneRange& r) { return w < r.base; });
+    if (it == m.planes.begin()) return;
+    --it;
+    if (p.W < it->base + it->n) {
+        p.W3 = it->p3 + (p.W - it->base);
+        p.w3_plane = (long long)it->n;
+    }
+}
 static void gemm(const Ctx& c, GemmP p) {
+    attach_planes(c.m, p);
     if (p.taps <= 0) p.taps = 1;
     if (p.dil <= 0) p.dil = 1;
     if (p.a_mul == 0) p.a_mul = 1;
@@ -142,7 +155,7 @@ static void conv_same(const Ctx& c, const float* x, int ldx, int R, const ConvW&
                       const float* Rsd = nullptr, int ldr = 0, int dil = 1) {
     GemmP p{};
     p.X = x; p.ldx = ldx; p.Rx = R; p.taps = w.k; p.dil = dil; p.shift0 = -((w.k - 1) / 2) * dil; p.Cin = w.cin;
-    p.W = w.w; p.W3 = w.w3; p.bias = w.b; p.R = Rsd; p.ldr = ldr; p.valid = valid; p.C = y; p.ldc = ldy; p.M = R; p.N = w.cout;
+    p.W = w.w; p.bias = w.b; p.R = Rsd; p.ldr = ldr; p.valid = valid; p.C = y; p.ldc = ldy; p.M = R; p.N = w.cout;
     p.pro_act = pro_act; p.pro_slope = slope; p.epi_act = epi_act;
     gemm(c, p);
 }

@@ -29,8 +29,9 @@ struct GemmP {
     const float* X; long long strideX; int ldx; int Rx;
     const int* rowbase; int a_mul; int shift0; int taps; int dil; int Cin;
     const float* W; long long strideW; int ldw;
-    const void* W3 = nullptr;   // optional: the same weights as three bf16 planes [3][N][K] (truncation split, exact sum) -
-                                // lets launch_gemm run a window convolution on the bf16 matrix pipe (conv_win_x6_kernel)
+    const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like
+    long long w3_plane = 0;     // W (same ldw / strideW, in bf16 elements), planes w3_plane elements apart (0: N * ldw) -
+                                // lets launch_gemm run on the bf16 matrix pipe in the f32-equivalent 6-product form
     const float* bias; long long strideB;
     const float* R; long long strideR; int ldr;
     const int* valid;
@@ -59,6 +60,7 @@ struct EngineOpts {
     int voc_streams = 3;         // resblock chains of a vocoder stage in flight (1 = serial)
     bool win_conv = true;        // window-convolution kernel for narrow square convs (Cin = Cout in {32, 64, 128})
     bool x6_conv = true;         // ... on the bf16 matrix pipe, f32-equivalent 3-way split (6 products), where W3 planes exist
+    bool x6_gemm = true;         // the big-tile implicit GEMMs likewise (gemm_x6_dma_kernel)
     bool markers = false;        // a named no-op kernel at every stage boundary: lets tools/pmc_stage_summary.py attribute
                                  // the rocprofv3 --pmc rows of one step to stages (measurement only)
     bool trace_on = false;       // HIP events around every GEMM launch (measurement only)

@@ -86,10 +86,11 @@ class IntPlan {
     int* d_ = nullptr;
 };
 
-struct ConvW {
-    float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, k = 0;
-    void* w3 = nullptr;     // optional: the packed weights as three bf16 planes [3][cout][k*cin] (GemmP::W3)
-};
+struct ConvW { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, k = 0; };
+// A GEMM weight buffer that also exists as three bf16 planes (truncation split, exact sum; model_load.hip): the stage
+// drivers look a weight pointer up here and hand the planes to launch_gemm (GemmP::W3), which may then run the launch
+// on the bf16 matrix pipe in the f32-equivalent 6-product form.
+struct PlaneRange { const float* base; size_t n; const uint16_t* p3; };
 // grouped residual stack: entry (s, blk) holds `groups` consecutive [C, k*C] matrices
 struct StackW {
     float *w = nullptr, *b = nullptr, *g = nullptr, *be = nullptr;
@@ -124,6 +125,7 @@ struct mt2_model {
     bool has_g = false, has_adm = false, has_plm = false;
     std::map<std::string, mt2::HostTensor> host;
     std::vector<void*> dev_allocs;
+    std::vector<mt2::PlaneRange> planes;       // sorted by base after finalize
     size_t weight_bytes = 0;
     mt2::Arena ws;
 

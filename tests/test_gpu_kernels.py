@@ -237,6 +237,36 @@ def test_window_conv_x6_is_f32_equivalent(rt, k, dil, C, cfg, pro):
     assert rel(x6, f32) < 2e-6
 
 
+@pytest.mark.parametrize("cfg", [37, 38])
+@pytest.mark.parametrize("M,N,taps,cin,dil", [(300, 512, 1, 256, 1), (77, 96, 1, 104, 1), (1000, 384, 5, 384, 1),
+                                               (700, 64, 3, 80, 1), (515, 256, 7, 256, 3), (2240, 4096, 1, 1024, 1)])
+def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
+    """The implicit-GEMM engine on the bf16 matrix pipe (gemm_x6_dma_kernel): linear layers and convolutions with K
+    tails (K = 104, 240: not multiples of 32), tap boundaries inside a chunk (Cin = 80), M / N tails, all epilogue
+    operands - as accurate against float64 as the f32-MFMA kernel on wide-dynamic-range data."""
+    rng = np.random.default_rng(M + N + taps * cin)
+    K = taps * cin
+    G = ((taps - 1) // 2) * dil
+    X = (rng.standard_normal((M, cin)) * np.exp(rng.uniform(-3, 3, (M, cin)))).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / math.sqrt(K) * np.exp(rng.uniform(-2, 2, (N, K)))).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    valid = (rng.random(M) > 0.1).astype(np.int32)
+    kw = dict(valid=dev(valid), shift0=-G, taps=taps, dil=dil, Cin=cin, pro_act=rt.ACT_RELU, epi_act=rt.ACT_NONE)
+    x6 = rt.op_conv_x6(dev(X), dev(W), dev(b), dev(R), force_cfg=cfg, **kw).cpu().numpy()
+    f32 = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=16 if cfg == 37 else 17, **kw).cpu().numpy()
+    a = np.maximum(X, 0).astype(np.float64)
+    ap = np.zeros((M + 2 * G, cin))
+    ap[G:G + M] = a
+    ref = np.zeros((M, N))
+    for t in range(taps):
+        ref += ap[t * dil:t * dil + M] @ W[:, t * cin:(t + 1) * cin].T.astype(np.float64)
+    ref = (ref + b + R) * valid[:, None]
+    e6, e32 = rel(x6, ref), rel(f32, ref)
+    assert e6 < 1e-6 and e6 <= 2.0 * e32 + 1e-7, (e6, e32)
+    assert not x6[valid == 0].any()
+
+
 @pytest.mark.parametrize("cfg", [-1, 12, 16, 17, 18, 20, 21, 22, 24, 27, 28, 29])
 @pytest.mark.parametrize("M,N,K", [(70, 2304, 768), (33, 96, 100), (300, 1024, 1024), (5, 64, 64), (1120, 768, 768)])
 def test_gemm_with_algebraic_layernorm(rt, cfg, M, N, K):

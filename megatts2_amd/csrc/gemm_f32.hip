@@ -996,11 +996,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
         const int swza = (arow >> 1) & 7;
         const unsigned sa = lds_win + (unsigned)((q * WRp + arow) * BK) * 4;
         const unsigned sb = b_lane + (unsigned)st * STAGE_B;
-        // raw operands of both 16-k blocks of this chunk: A = 2 x (two f32x4 = 8 consecutive k), B = 2 x 3 planes x TN
+        // the stage consumed in the previous iteration is free once everyone has passed the barrier: refill it first
+        if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
         f32x4 ra[2][TM][2];
         u32x4 rb[2][3][TN];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        auto fetch = [&](int b) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ra[b][i][0] = lds_read_b128(sa + (unsigned)(((b * 4 + half * 2) ^ swza) * 16) + i * 32 * BK * 4);
@@ -1013,13 +1013,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
                     const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
                     rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
                 }
-        }
-        if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        };
+        auto compute = [&](int b) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 u32x4 a1, a2, a3;
@@ -1039,7 +1034,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[i][j], 0, 0, 0);
                 }
             }
-        }
+        };
+        // block 1 is fetched while block 0 is on the matrix pipe
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
         st = st + 1 == NST ? 0 : st + 1;
         if (++q == QS) { q = 0; ++tap; }
     }
@@ -1177,10 +1184,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
+        if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);     // refill the stage freed by the barrier
         f32x4 ra[2][TM][2];
         u32x4 rb[2][3][TN];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        auto fetch = [&](int b) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 ra[b][i][0] = lds_read_b128(sa + koffa[b][0] + i * 32 * BK * 4);
@@ -1193,13 +1200,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
                     const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
                     rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
                 }
-        }
-        if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        };
+        auto compute = [&](int b) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 u32x4 a1, a2, a3;
@@ -1218,7 +1220,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[i][j], 0, 0, 0);
                 }
             }
-        }
+        };
+        // block 1 is fetched while block 0 is on the matrix pipe
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
         st = st + 1 == NST ? 0 : st + 1;
     }
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
@@ -1326,6 +1340,9 @@ static const TileCfg kCfgs[] = {
     // v2b: implicit GEMM on the bf16 pipe, f32-equivalent; stage = BM x 128 B (A, f32) + 3 x BN x 64 B (B planes)
     MT2_GX6(256, 128, 4, 2, 2),      // 37: 8 waves, 64x64 each; 2 x 56 KiB
     MT2_GX6(128, 128, 4, 2, 3),      // 38: 8 waves, 32x64 each; 3 x 40 KiB
+    MT2_GX6(128, 128, 4, 2, 2),      // 39: the same with a 2-deep ring: 80 KiB -> 2 workgroups per CU
+    MT2_GX6(128, 256, 2, 4, 2),      // 40: 8 waves, 64x64 each; 2 x 64 KiB (wide N: the AR feed-forward / QKV)
+    MT2_GX6(256, 128, 8, 2, 2),      // 41: 16 waves, 32x64 each; 2 x 56 KiB (4 waves per SIMD)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 

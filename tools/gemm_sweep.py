@@ -23,7 +23,21 @@ if mode == "vocx":     # the vocoder's real launches: dilation, leaky-ReLU prolo
             ms, cn = rt.bench_gemm(M, N, K, taps=taps, iters=6, dil=dil, flags=flags)
             print(f"{name} dil={dil} prologue={flags & 1} epilogue={flags >> 1}: {cn} {ms * 1e3:.1f} us {2.0 * M * N * K / ms / 1e9:.1f} TF/s", flush=True)
     sys.exit(0)
-if mode == "voc":
+if mode == "x6":       # the bf16-pipe (f32-equivalent) configurations against their f32 counterparts
+    cfgs = [16, 17, 37, 38, 39, 40, 41]
+    shapes = [("mrte_stack", 14064, 512, 1536, 3), ("decoder", 13858, 512, 2560, 5), ("vqpe", 13858, 384, 1920, 5),
+              ("hifi_s1", 111000, 256, 1792, 7), ("hifi_s1k11", 111000, 256, 2816, 11),
+              ("plm_ff0", 1728, 4096, 1024, 1), ("plm_ff0", 864, 4096, 1024, 1), ("plm_ff0", 432, 4096, 1024, 1),
+              ("plm_qkv", 1728, 3072, 1024, 1), ("plm_qkv", 864, 3072, 1024, 1), ("plm_ff1", 1728, 1024, 4096, 1),
+              ("plm_ff1", 864, 1024, 4096, 1), ("plm_out", 1728, 1024, 1024, 1), ("adm_qkv", 2240, 2304, 768, 1),
+              ("adm_qkv", 1120, 2304, 768, 1), ("adm_ff0", 2240, 1024, 768, 1), ("adm_out", 2240, 768, 768, 1),
+              ("big", 4096, 4096, 4096, 1)]
+elif mode == "x6win":
+    cfgs = [30, 34, 31, 35, 32, 36]
+    shapes = [("hifi_s4k3", 3552000, 32, 96, 3), ("hifi_s4k11", 3552000, 32, 352, 11), ("hifi_s3k3", 1776000, 64, 192, 3),
+              ("hifi_s3k11", 1776000, 64, 704, 11), ("hifi_s2k3", 888000, 128, 384, 3), ("hifi_s2k7", 888000, 128, 896, 7),
+              ("hifi_s2k11", 888000, 128, 1408, 11)]
+elif mode == "voc":
     cfgs = [3, 12, 15, 16, 17, 23, 24]
     shapes = [("hifi_s1", 111000, 256, 1792, 7), ("hifi_s2", 888000, 128, 896, 7), ("hifi_s3", 1776000, 64, 448, 7),
               ("hifi_s3k11", 1776000, 64, 704, 11), ("hifi_s4", 3552000, 32, 224, 7), ("hifi_s4k11", 3552000, 32, 352, 11),
@@ -40,7 +54,7 @@ for name, M, N, K, taps in shapes:
     row = []
     for cfg in cfgs + [-1]:
         try:
-            ms, cn = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=24, w_copies=copies)
+            ms, cn = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=6 if M > 100000 else 24, w_copies=copies)
             row.append((2.0 * M * N * K / ms / 1e9, cn, ms))
         except Exception as e:
             row.append((0.0, "err", 0.0))

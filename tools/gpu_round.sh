@@ -87,6 +87,11 @@ prof)
 sweep)
   timeout 900 python tools/gemm_sweep.py > gpurun_out/gemm_sweep.txt 2>&1
   echo "sweep rc=$?"; cat gpurun_out/gemm_sweep.txt ;;
+sweep_x6)
+  timeout 600 python tools/gemm_sweep.py x6 > gpurun_out/gemm_sweep_x6.txt 2>&1
+  echo "sweep_x6 rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x6.txt
+  timeout 600 python tools/gemm_sweep.py x6win > gpurun_out/gemm_sweep_x6win.txt 2>&1
+  echo "sweep_x6win rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x6win.txt ;;
 sweep_ar)
   timeout 600 python tools/gemm_sweep.py ar > gpurun_out/gemm_sweep_ar.txt 2>&1
   echo "sweep_ar rc=$?"; cat gpurun_out/gemm_sweep_ar.txt ;;

@@ -1473,8 +1473,10 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     // Throughput-bound launches move to the bf16 pipe (f32-equivalent x6 form) when the weights come with planes.
     // profiles/r02_gemm_sweep_x6.txt: the x6 256x128 tile does 138-142 TF/s where the f32 tiles do 91-97 once it has
     // >= ~160 tiles (conv stacks, vocoder stage 1, the PLM / ADM QKV and ff.0 at full batch); the x6 128x128 tile
-    // (2 workgroups per CU) wins from ~140 tiles on (90-126 vs 67-84 TF/s: QKV / ff.0 of one AR stream group, VQ-PE);
-    // below that the K-split f32 tiles keep their latency advantage (out-projection, ff.3, early AR steps).
+    // (2 workgroups per CU) wins from ~140 tiles on in isolation (90-126 vs 67-84 TF/s: QKV / ff.0 of one AR stream
+    // group, VQ-PE) and from ~100 tiles on inside the model, where two AR chains share the chip (C3 step 297.2 ->
+    // 295.2 ms, profiles/r02_opts_ab.txt); below that the K-split f32 tiles keep their latency advantage
+    // (out-projection, ff.3, early AR steps).
     if (o.x6_gemm && p.W3 && (p.K & 7) == 0 && (p.ldw & 7) == 0 && p.pro_act < PRO_LN && p.N > 64) {
         if (t256 >= o.t_x6_256) bi = 37;
         else if (t128 >= o.t_x6_128) bi = 39;

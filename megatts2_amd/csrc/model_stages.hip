@@ -230,8 +230,9 @@ static EncScratch enc_scratch(const Ctx& c, const EncW& e, int M) {
     s.qkv = c.ws.get<float>((size_t)M * 3 * e.d);
     s.att = c.ws.get<float>((size_t)M * e.d);
     s.f = c.ws.get<float>((size_t)M * e.ff);
-    // split-K slabs: choose_split keeps tiles(32x64) * S <= 256, i.e. S * M * d <= 256 * 32 * 64 * (d / 64 tiles)
-    s.parts = c.ws.get<float>((size_t)256 * 32 * 64 + (size_t)16 * 32 * e.d);
+    // split-K slabs [S][M, d]: the f32 rule of choose_split keeps tiles(32x64) * S <= 256 (S * M * d <= 256 * 32 * 64 *
+    // d / 64); the x6 rule splits at most 8 ways at any M
+    s.parts = c.ws.get<float>(std::max((size_t)256 * 32 * 64 + (size_t)16 * 32 * e.d, (size_t)8 * M * e.d));
     return s;
 }
 static void attention_self(const Ctx& c, const EncW& e, const AttnGeom& g, const float* qkv, float* att) {
@@ -282,6 +283,19 @@ static int choose_split(const Ctx& c, int M, int N, int K) {
     // a split GEMM hands its reduction to a stand-alone LayerNorm launch, which the LayerNorm-prologue GEMM
     // (ln_linear) otherwise removes: worth it only for the long K chains (PLM ff.3, K = 4096)
     if (c.m.opts.lnfuse && K < 2048) return 1;
+    // x6 form (large M): the N = d GEMMs of a layer (out-projection, ff.3) have too few 128x128 tiles for the bf16 pipe
+    // (N = 768 / 1024: 6 / 8 column tiles); K slices as GEMM groups bring them to >= t_x6_128 tiles, and the reduction
+    // rides on the next LayerNorm as before (profiles/r02_gemm_sweep_x6.txt: ff.3 at M = 864 does 85 TF/s on the f32
+    // K-split tile; four x6 slices of K = 1024 have the shape of ff.0, 125 TF/s)
+    if (c.m.opts.x6_gemm && c.m.opts.x6_splitk && (N & 127) == 0 && (K & 31) == 0) {
+        const long long t128 = (long long)((M + 127) / 128) * (N / 128);
+        if (t128 < c.m.opts.t_x6_128) {
+            int S = 1;
+            while (S < 8 && t128 * S < 2 * c.m.opts.t_x6_128 && K % (S * 2) == 0 && K / (S * 2) >= 512 && (K / (S * 2)) % 32 == 0)
+                S *= 2;
+            if (S > 1 && t128 * S >= c.m.opts.t_x6_128) return S;
+        }
+    }
     const long long tiles = (long long)((M + 31) / 32) * ((N + 63) / 64);
     int S = 1;
     while (S < 16 && tiles * (S * 2) <= 256 && K % (S * 2) == 0 && K / (S * 2) >= 256 && (K / (S * 2)) % 32 == 0) S *= 2;

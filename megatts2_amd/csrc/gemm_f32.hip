@@ -968,6 +968,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    constexpr bool TWOACC = TM * TN == 1;
+    f32x16 acc2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
 
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
@@ -1014,41 +1018,62 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
                     rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
                 }
         };
-        auto compute = [&](int b) {
+        // Fragment-level software pipeline: the three planes of fragment s+1 are split on the vector pipe WHILE the
+        // matrix pipe works through the 6*TN products of fragment s (sched_group_barrier pins the interleave: hipcc
+        // otherwise issues the 44 VALU of a split as one block in front of its MFMAs and the matrix pipe idles).
+        constexpr int F = 2 * TM, NMF = 6 * TN, VPM = (44 + NMF - 1) / NMF;
+        u32x4 pln[2][3];
+        auto products = [&](int b, int i, const u32x4* pp) {
+            const bf16x8 A1 = __builtin_bit_cast(bf16x8, pp[0]), A2 = __builtin_bit_cast(bf16x8, pp[1]),
+                         A3 = __builtin_bit_cast(bf16x8, pp[2]);
+            // smallest terms first (they meet an accumulator increment of their own size before the big one lands);
+            // column tiles innermost, so that consecutive MFMAs never wait on each other's accumulator
+            constexpr int PA[6] = {3, 1, 2, 2, 1, 1}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                u32x4 a1, a2, a3;
-                split3_bf16<PRO>(ra[b][i][0], ra[b][i][1], pro_slope, a1, a2, a3);
-                const bf16x8 A1 = __builtin_bit_cast(bf16x8, a1), A2 = __builtin_bit_cast(bf16x8, a2),
-                             A3 = __builtin_bit_cast(bf16x8, a3);
+            for (int t = 0; t < 6; ++t) {
+                const bf16x8 At = PA[t] == 1 ? A1 : (PA[t] == 2 ? A2 : A3);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const bf16x8 B1 = __builtin_bit_cast(bf16x8, rb[b][0][j]), B2 = __builtin_bit_cast(bf16x8, rb[b][1][j]),
-                                 B3 = __builtin_bit_cast(bf16x8, rb[b][2][j]);
-                    // smallest terms first: they meet an accumulator increment of their own size before the big one lands
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[i][j], 0, 0, 0);
+                    const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB[t]][j]);
+                    if (TWOACC && (t & 1) == 0) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc2, 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
                 }
             }
         };
-        // block 1 is fetched while block 0 is on the matrix pipe
         fetch(0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         fetch(1);
+        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
         __builtin_amdgcn_sched_barrier(0);
-        compute(0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1);
+#pragma unroll
+        for (int s = 0; s < F; ++s) {
+            const int b = s / TM, i = s % TM;
+            if (s + 1 < F) {
+                const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
+                if (b2 != b) {                   // block 1's fragments were requested a whole step ago
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
+            }
+            products(b, i, pln[s & 1]);
+            if (s + 1 < F) {
+#pragma unroll
+                for (int k = 0; k < NMF; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         st = st + 1 == NST ? 0 : st + 1;
         if (++q == QS) { q = 0; ++tap; }
+    }
+    if constexpr (TWOACC) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
     }
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, 0, m0 + wm * WTM, wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
@@ -1156,6 +1181,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    constexpr bool TWOACC = TM * TN == 1;
+    f32x16 acc2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
 
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
@@ -1201,39 +1230,61 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
                     rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
                 }
         };
-        auto compute = [&](int b) {
+        // Fragment-level software pipeline: the three planes of fragment s+1 are split on the vector pipe WHILE the
+        // matrix pipe works through the 6*TN products of fragment s (sched_group_barrier pins the interleave: hipcc
+        // otherwise issues the 44 VALU of a split as one block in front of its MFMAs and the matrix pipe idles).
+        constexpr int F = 2 * TM, NMF = 6 * TN, VPM = (44 + NMF - 1) / NMF;
+        u32x4 pln[2][3];
+        auto products = [&](int b, int i, const u32x4* pp) {
+            const bf16x8 A1 = __builtin_bit_cast(bf16x8, pp[0]), A2 = __builtin_bit_cast(bf16x8, pp[1]),
+                         A3 = __builtin_bit_cast(bf16x8, pp[2]);
+            // smallest terms first (they meet an accumulator increment of their own size before the big one lands);
+            // column tiles innermost, so that consecutive MFMAs never wait on each other's accumulator
+            constexpr int PA[6] = {3, 1, 2, 2, 1, 1}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                u32x4 a1, a2, a3;
-                split3_bf16<PRO>(ra[b][i][0], ra[b][i][1], pro_slope, a1, a2, a3);
-                const bf16x8 A1 = __builtin_bit_cast(bf16x8, a1), A2 = __builtin_bit_cast(bf16x8, a2),
-                             A3 = __builtin_bit_cast(bf16x8, a3);
+            for (int t = 0; t < 6; ++t) {
+                const bf16x8 At = PA[t] == 1 ? A1 : (PA[t] == 2 ? A2 : A3);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const bf16x8 B1 = __builtin_bit_cast(bf16x8, rb[b][0][j]), B2 = __builtin_bit_cast(bf16x8, rb[b][1][j]),
-                                 B3 = __builtin_bit_cast(bf16x8, rb[b][2][j]);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A3, B1, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B3, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B2, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A2, B1, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B2, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1, B1, acc[i][j], 0, 0, 0);
+                    const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB[t]][j]);
+                    if (TWOACC && (t & 1) == 0) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc2, 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
                 }
             }
         };
-        // block 1 is fetched while block 0 is on the matrix pipe
         fetch(0);
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         fetch(1);
+        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
         __builtin_amdgcn_sched_barrier(0);
-        compute(0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1);
+#pragma unroll
+        for (int s = 0; s < F; ++s) {
+            const int b = s / TM, i = s % TM;
+            if (s + 1 < F) {
+                const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
+                if (b2 != b) {                   // block 1's fragments were requested a whole step ago
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
+            }
+            products(b, i, pln[s & 1]);
+            if (s + 1 < F) {
+#pragma unroll
+                for (int k = 0; k < NMF; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         st = st + 1 == NST ? 0 : st + 1;
+    }
+    if constexpr (TWOACC) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
     }
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);

@@ -1040,9 +1040,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
                 }
             }
         };
+        // The LDS reads are inline asm, so the compiler sees no dependency between "s_waitcnt" and the consumers of the
+        // fragments: instruction selection may linearise a split in front of the wait that makes its input valid
+        // (sched_barrier only binds the machine scheduler).  Passing the registers through an empty asm after the wait
+        // gives every consumer a data dependency on it.
+        auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
+        auto wait_block = [&](int b) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < TM; ++i) tie(b, i);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
+        };
         fetch(0);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_block(0);
         __builtin_amdgcn_sched_barrier(0);
         fetch(1);
         split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
@@ -1053,8 +1067,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
             if (s + 1 < F) {
                 const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
                 if (b2 != b) {                   // block 1's fragments were requested a whole step ago
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wait_block(b2);
                     __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    tie(b2, i2);                 // keeps this split inside this step's scheduling region
                 }
                 split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
             }
@@ -1252,9 +1268,23 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
                 }
             }
         };
+        // The LDS reads are inline asm, so the compiler sees no dependency between "s_waitcnt" and the consumers of the
+        // fragments: instruction selection may linearise a split in front of the wait that makes its input valid
+        // (sched_barrier only binds the machine scheduler).  Passing the registers through an empty asm after the wait
+        // gives every consumer a data dependency on it.
+        auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
+        auto wait_block = [&](int b) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < TM; ++i) tie(b, i);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
+        };
         fetch(0);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_block(0);
         __builtin_amdgcn_sched_barrier(0);
         fetch(1);
         split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
@@ -1265,8 +1295,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
             if (s + 1 < F) {
                 const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
                 if (b2 != b) {                   // block 1's fragments were requested a whole step ago
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wait_block(b2);
                     __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    tie(b2, i2);                 // keeps this split inside this step's scheduling region
                 }
                 split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
             }

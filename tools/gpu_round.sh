@@ -120,6 +120,15 @@ probe)
   echo "probe rc=$?"; grep -v "^W2026\|amdgpu.ids" gpurun_out/probe.log | tail -14
   python tools/pmc_probe_summary.py gpurun_out/probe | tee gpurun_out/probe_summary.txt | cut -c1-400
   find gpurun_out/probe -name "*.csv" -size +4M -delete ;;
+probe_x6)
+  i=0
+  for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_MFMA"; do
+    i=$((i+1)); rm -rf gpurun_out/probe_x6_$i
+    (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/probe_x6_$i -o probe -- python $GRAFT_REPO_ROOT/tools/gemm_probe.py x6) > gpurun_out/probe_x6_$i.log 2>&1
+    echo "probe_x6 $i rc=$?"; grep -v "^W2026\|amdgpu.ids" gpurun_out/probe_x6_$i.log | tail -9
+    python tools/pmc_probe_summary.py gpurun_out/probe_x6_$i | tee gpurun_out/probe_x6_summary_$i.txt | cut -c1-400
+    find gpurun_out/probe_x6_$i -name "*.csv" -size +4M -delete
+  done ;;
 splitk)
   for w in C2 C3; do for f in "" "--no-splitk"; do
     timeout 600 python bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-roofline ${f:+--opt splitk=0} > gpurun_out/bench_sk.log 2>&1

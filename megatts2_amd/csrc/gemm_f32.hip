@@ -968,10 +968,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    constexpr bool TWOACC = TM * TN == 1;
-    f32x16 acc2;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
 
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
@@ -1035,8 +1031,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB[t]][j]);
-                    if (TWOACC && (t & 1) == 0) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc2, 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
                 }
             }
         };
@@ -1059,6 +1054,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
         wait_block(0);
         __builtin_amdgcn_sched_barrier(0);
         fetch(1);
+        if constexpr (TM * TN == 1) {
+            // one tile per wave: 44 VALU per 6 MFMAs is more than fits in the MFMA shadow (measured: interleaving costs
+            // 20 %); split and multiply in turn and let the other wave of the SIMD fill the gaps
+            __builtin_amdgcn_sched_barrier(0);
+            split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
+            products(0, 0, pln[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_block(1);
+            __builtin_amdgcn_sched_barrier(0);
+            split3_bf16<PRO>(ra[1][0][0], ra[1][0][1], pro_slope, pln[1][0], pln[1][1], pln[1][2]);
+            products(1, 0, pln[1]);
+        } else {
         split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1084,12 +1091,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         st = st + 1 == NST ? 0 : st + 1;
         if (++q == QS) { q = 0; ++tap; }
-    }
-    if constexpr (TWOACC) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
     }
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, 0, m0 + wm * WTM, wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
@@ -1165,10 +1169,36 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
     EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
     if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 
+    // Fast path (every production launch): K is a whole number of chunks and a chunk never straddles a tap, so the tap
+    // and the channel offset of a chunk are wave-uniform and advance on the scalar unit - no per-lane division, the
+    // per-piece address is one multiply-add and one select.
+    const bool fast = (Kt % BK == 0) && (!multi_tap || Cin % BK == 0);
+    int s_tap = 0, s_cc = 0;                              // of the next chunk to be issued (chunks are issued in order)
+    const int kl0 = kslot_of(0);
     auto issue = [&](int c, int st) {
         const int kchunk = c * BK;
         float* As = reinterpret_cast<float*>(ring + st * STAGE) + wave * 256;
         char* Bs = ring + st * STAGE + STAGE_A + wave * 1024;
+        if (fast) {
+            const int dsrc = s_tap * dil;
+#pragma unroll
+            for (int j = 0; j < A_IT; ++j) {
+                const int src = abase[j] + dsrc;
+                const int cc = s_cc + (NW % 2 == 0 ? kl0 : kslot_of(j));
+                const long long off = (unsigned)src < (unsigned)Rx ? (long long)src * ldx + cc : zoff_x;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                                 (__attribute__((address_space(3))) void*)(As + j * NW * 256), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < B_IT; ++j) {
+                const long long off = wofs[j] >= 0 ? wofs[j] + (kchunk + wk[j]) : zoff_w;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                                 (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
+            }
+            s_cc += BK;
+            if (multi_tap && s_cc == Cin) { s_cc = 0; ++s_tap; }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
             const int k = kchunk + kslot_of(NW % 2 == 0 ? 0 : j);
@@ -1197,10 +1227,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    constexpr bool TWOACC = TM * TN == 1;
-    f32x16 acc2;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc2[e] = 0.0f;
 
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
@@ -1263,8 +1289,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB[t]][j]);
-                    if (TWOACC && (t & 1) == 0) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc2, 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
                 }
             }
         };
@@ -1287,6 +1312,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
         wait_block(0);
         __builtin_amdgcn_sched_barrier(0);
         fetch(1);
+        if constexpr (TM * TN == 1) {
+            // one tile per wave: 44 VALU per 6 MFMAs is more than fits in the MFMA shadow (measured: interleaving costs
+            // 20 %); split and multiply in turn and let the other wave of the SIMD fill the gaps
+            __builtin_amdgcn_sched_barrier(0);
+            split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
+            products(0, 0, pln[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_block(1);
+            __builtin_amdgcn_sched_barrier(0);
+            split3_bf16<PRO>(ra[1][0][0], ra[1][0][1], pro_slope, pln[1][0], pln[1][1], pln[1][2]);
+            products(1, 0, pln[1]);
+        } else {
         split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1312,11 +1349,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         st = st + 1 == NST ? 0 : st + 1;
-    }
-    if constexpr (TWOACC) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
     }
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
@@ -1426,6 +1460,9 @@ static const TileCfg kCfgs[] = {
     MT2_GX6(128, 128, 4, 2, 2),      // 39: the same with a 2-deep ring: 80 KiB -> 2 workgroups per CU
     MT2_GX6(128, 256, 2, 4, 2),      // 40: 8 waves, 64x64 each; 2 x 64 KiB (wide N: the AR feed-forward / QKV)
     MT2_GX6(256, 128, 8, 2, 2),      // 41: 16 waves, 32x64 each; 2 x 56 KiB (4 waves per SIMD)
+    MT2_GX6(256, 128, 8, 1, 2),      // 42: 8 waves, 32x128 each: every A fragment is split ONCE per workgroup, 24 MFMAs per split
+    MT2_GX6(128, 128, 4, 1, 2),      // 43: 4 waves, 32x128 each; 80 KiB -> 2 workgroups per CU
+    MT2_GX6(128, 256, 4, 1, 2),      // 44: 4 waves, 32x256 each (48 MFMAs per split); 2 x 64 KiB
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 

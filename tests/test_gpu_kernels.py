@@ -237,7 +237,7 @@ def test_window_conv_x6_is_f32_equivalent(rt, k, dil, C, cfg, pro):
     assert rel(x6, f32) < 2e-6
 
 
-@pytest.mark.parametrize("cfg", [37, 38])
+@pytest.mark.parametrize("cfg", [37, 38, 39, 40, 41, 42, 43, 44])
 @pytest.mark.parametrize("M,N,taps,cin,dil", [(300, 512, 1, 256, 1), (77, 96, 1, 104, 1), (1000, 384, 5, 384, 1),
                                                (700, 64, 3, 80, 1), (515, 256, 7, 256, 3), (2240, 4096, 1, 1024, 1)])
 def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
@@ -254,7 +254,7 @@ def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
     valid = (rng.random(M) > 0.1).astype(np.int32)
     kw = dict(valid=dev(valid), shift0=-G, taps=taps, dil=dil, Cin=cin, pro_act=rt.ACT_RELU, epi_act=rt.ACT_NONE)
     x6 = rt.op_conv_x6(dev(X), dev(W), dev(b), dev(R), force_cfg=cfg, **kw).cpu().numpy()
-    f32 = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=16 if cfg == 37 else 17, **kw).cpu().numpy()
+    f32 = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=17 if cfg == 38 else 16, **kw).cpu().numpy()
     a = np.maximum(X, 0).astype(np.float64)
     ap = np.zeros((M + 2 * G, cin))
     ap[G:G + M] = a

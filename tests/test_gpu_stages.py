@@ -6,6 +6,7 @@ Tolerances: floating-point outputs 1e-3 relative L2 as BASELINE.json's north_sta
 path actually lands around 1e-6, asserted at 2e-5 where nothing is amplified); VQ indices, PLM codes
 and integer durations bit-exact.
 """
+import os
 import numpy as np
 import pytest
 
@@ -244,6 +245,9 @@ def test_tiny_vq_quantize_near_ties():
     got = tts.native.vq_quantize(dev(x)).cpu().numpy()
     want = O.vq_quantize(E, x)
     bad = np.nonzero(got != want)[0]
+    if os.path.isdir("gpurun_out"):      # the observed flip count is reported in DESIGN.md (expected: 0)
+        with open("gpurun_out/vq_near_tie_flips.txt", "w") as fh:
+            fh.write(f"rows 4096 (512 exact hits, 512 engineered near-ties): index flips vs oracle = {bad.size}\n")
     assert not np.any(bad >= 1024), "flip on a row that is not an engineered near-tie"
     if bad.size:   # a flip is legitimate only inside the fp32 round-off of the expanded distance itself
         xb = x[bad].astype(np.float64)

@@ -1066,10 +1066,17 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
             MT2_HIP(hipEventRecord(m.ev_join[j], m.aux_streams[j]));
             MT2_HIP(hipStreamWaitEvent(c.s, m.ev_join[j], 0));
         }
+        if (i + 1 == cfg.hg_n_up && m.hg_post.cout == 1 && (ch & 3) == 0 && ch <= 128 && m.hg_post.k <= 15) {
+            // last stage: the mean goes straight into the output layer (one pass over the three resblock outputs)
+            // F.leaky_relu default slope 0.01, conv_post k7, tanh
+            float* wav = c.ws.get<float>((size_t)R);
+            MT2_HIP(launch_conv_post(rb[0], rb[1], rb[2], 1.0f / 3.0f, R, ch, m.hg_post.k, m.hg_post.w, m.hg_post.b, 0.01f,
+                                     valid, wav, c.s));
+            return wav;
+        }
         x = c.ws.get<float>(per);
         MT2_HIP(launch_avg3(rb[0], rb[1], rb[2], 1.0f / 3.0f, x, (long long)per, c.s));
     }
-    // F.leaky_relu default slope 0.01, conv_post k7, tanh
     float* wav = c.ws.get<float>((size_t)R);
     conv_same(c, x, ch, (int)R, m.hg_post, wav, 1, valid, ACT_LRELU, 0.01f, ACT_TANH);
     return wav;

@@ -135,6 +135,9 @@ hipError_t launch_sum_groups(const float* x, long long strideG, int groups, int 
 // dst[r, c] = (a[r,c] + b[r,c] + d[r,c]) * scale  (HiFi-GAN MRF mean)
 hipError_t launch_avg3(const float* a, const float* b, const float* d, float scale, float* out, long long n,
                        hipStream_t s);
+// MRF mean of the last stage + leaky ReLU + conv_post (Cout = 1) + tanh in one pass; x1 = x2 = nullptr: x0 is the mean already
+hipError_t launch_conv_post(const float* x0, const float* x1, const float* x2, float scale, long long R, int ch, int k,
+                            const float* w, const float* bias, float slope, const int* valid, float* out, hipStream_t s);
 // padded [B, Tmax, C] (or channel-major [B, C, Tmax] when cmajor) <-> packed rows; rowmap[r] = b*Tmax + t or -1
 hipError_t launch_pack_rows(const float* src, int C, int Tmax, int cmajor, const int* rowmap, float* dst, int ldd,
                             int R, hipStream_t s);

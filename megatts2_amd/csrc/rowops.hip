@@ -312,6 +312,61 @@ hipError_t launch_avg3(const float* a, const float* b, const float* d, float sca
     return hipGetLastError();
 }
 
+// HiFi-GAN output layer: the last stage's MRF mean, F.leaky_relu, conv_post (Cout = 1, k taps) and tanh in ONE pass
+// (speechbrain HifiganGenerator.forward tail; models/megatts2.py:370).  One output channel is a dot product per row -
+// VALU work bound by the read of the three resblock outputs, not a GEMM: a 256-row block stages its
+// (256 + k - 1) x ch window of lrelu(mean) in LDS (row stride ch + 1: conflict-free), every thread owns one row.
+// The mean keeps avg3_kernel's operation order, so the rows the convolution sees are the same values as before.
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                         const float* __restrict__ x2, float scale, long long R, int ch,
+                                                         int k, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float slope, const int* __restrict__ valid, float* __restrict__ out) {
+    extern __shared__ float sm_post[];
+    const int ld = ch + 1, half = (k - 1) / 2, nrow = 256 + k - 1, c4 = ch >> 2;
+    float* xs = sm_post;
+    float* ws = sm_post + nrow * ld;
+    const long long r0 = (long long)blockIdx.x * 256 - half;
+    for (int i = threadIdx.x; i < nrow * c4; i += 256) {
+        const int rr = i / c4, cq = i - rr * c4;
+        const long long g = r0 + rr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g >= 0 && g < R) {
+            v = *reinterpret_cast<const float4*>(x0 + g * ch + cq * 4);
+            if (x1) {
+                const float4 y = *reinterpret_cast<const float4*>(x1 + g * ch + cq * 4);
+                const float4 z = *reinterpret_cast<const float4*>(x2 + g * ch + cq * 4);
+                v.x = ((v.x + y.x) + z.x) * scale; v.y = ((v.y + y.y) + z.y) * scale;
+                v.z = ((v.z + y.z) + z.z) * scale; v.w = ((v.w + y.w) + z.w) * scale;
+            }
+        }
+        float* d = xs + rr * ld + cq * 4;
+        d[0] = v.x > 0.f ? v.x : v.x * slope; d[1] = v.y > 0.f ? v.y : v.y * slope;
+        d[2] = v.z > 0.f ? v.z : v.z * slope; d[3] = v.w > 0.f ? v.w : v.w * slope;
+    }
+    for (int i = threadIdx.x; i < k * ch; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const long long m = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= R) return;
+    float acc = 0.0f;
+    for (int t = 0; t < k; ++t) {
+        const float* xr = xs + (threadIdx.x + t) * ld;
+        const float* wr = ws + t * ch;
+#pragma unroll 8
+        for (int cidx = 0; cidx < ch; ++cidx) acc = fmaf(xr[cidx], wr[cidx], acc);
+    }
+    acc += bias[0];
+    out[m] = (valid && !valid[m]) ? 0.0f : tanhf(acc);
+}
+hipError_t launch_conv_post(const float* x0, const float* x1, const float* x2, float scale, long long R, int ch, int k,
+                            const float* w, const float* bias, float slope, const int* valid, float* out, hipStream_t s) {
+    if (R <= 0) return hipSuccess;
+    if ((ch & 3) || ch > 128 || k > 15 || !(k & 1)) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)(256 + k - 1) * (ch + 1) + (size_t)k * ch) * sizeof(float);
+    hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), lds, s, x0, x1, x2, scale, R, ch, k, w,
+                       bias, slope, valid, out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // boundary layout conversion: reference tensors are padded batch-first [B, Tmax, C] (or [B, C, Tmax]
 // for the mel decoder / vocoder, "B D T"); internal rows are packed with gap rows.

@@ -500,6 +500,7 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     else if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 
     float* ring = smem + kg * (NST * STAGE);
+    const bool w_nt = p.w_nt != 0;
     auto issue = [&](int rd, int st) {
         const int kchunk = (rd * KS + kg) * BK;
         float* As = ring + st * STAGE + wave * 256;            // + j*NW*256 floats per piece
@@ -521,8 +522,12 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
             const int k = kchunk + kslot_of(NW % 2 == 0 ? 0 : j);
             const bool ok = (k < Kt) & (wofs[j] >= 0);
             const long long off = ok ? wofs[j] + k : zoff_w;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + off),
-                                             (__attribute__((address_space(3))) void*)(Bs + j * NW * 256), 16, 0, 0);
+            if (w_nt)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + off),
+                                                 (__attribute__((address_space(3))) void*)(Bs + j * NW * 256), 16, 0, 2);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + off),
+                                                 (__attribute__((address_space(3))) void*)(Bs + j * NW * 256), 16, 0, 0);
         }
         if constexpr (LNP) {   // piece rows 0 / 1 = gamma / beta of this chunk (rows 0,1 have swizzle 0), rest zero
             if (wave == 0) {
@@ -1173,6 +1178,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
     // and the channel offset of a chunk are wave-uniform and advance on the scalar unit - no per-lane division, the
     // per-piece address is one multiply-add and one select.
     const bool fast = (Kt % BK == 0) && (!multi_tap || Cin % BK == 0);
+    const bool w_nt = p.w_nt != 0;
     int s_tap = 0, s_cc = 0;                              // of the next chunk to be issued (chunks are issued in order)
     const int kl0 = kslot_of(0);
     auto issue = [&](int c, int st) {
@@ -1192,8 +1198,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
 #pragma unroll
             for (int j = 0; j < B_IT; ++j) {
                 const long long off = wofs[j] >= 0 ? wofs[j] + (kchunk + wk[j]) : zoff_w;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
-                                                 (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
+                if (w_nt)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                                     (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 2);
+                else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                                     (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
             }
             s_cc += BK;
             if (multi_tap && s_cc == Cin) { s_cc = 0; ++s_tap; }
@@ -1654,6 +1664,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
         }
     }
     const int tiles = ((p.M + c->bm - 1) / c->bm) * ((p.N + c->bn - 1) / c->bn);
+    p.w_nt = (o.nt_weights && (p.M + c->bm - 1) / c->bm <= o.nt_row_tiles) ? 1 : 0;
     dim3 grid(tiles, 1, p.groups), block(c->threads);
     if (opts) opts->last_cfg = c->name;
     if (opts && opts->trace_on) {

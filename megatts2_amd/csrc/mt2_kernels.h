@@ -29,6 +29,7 @@ struct GemmP {
     const float* X; long long strideX; int ldx; int Rx;
     const int* rowbase; int a_mul; int shift0; int taps; int dil; int Cin;
     const float* W; long long strideW; int ldw;
+    int w_nt = 0;               // weight loads with the non-temporal cache policy (set by launch_gemm: weights streamed ~once per launch)
     const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like
     long long w3_plane = 0;     // W (same ldw / strideW, in bf16 elements), planes w3_plane elements apart (0: N * ldw) -
                                 // lets launch_gemm run on the bf16 matrix pipe in the f32-equivalent 6-product form
@@ -62,6 +63,8 @@ struct EngineOpts {
     bool x6_conv = true;         // ... on the bf16 matrix pipe, f32-equivalent 3-way split (6 products), where W3 planes exist
     bool x6_gemm = true;         // the big-tile implicit GEMMs likewise (gemm_x6_dma_kernel)
     bool x6_splitk = true;       // K slices (through the next LayerNorm) to give the N = d AR GEMMs enough x6 tiles
+    bool nt_weights = false;     // non-temporal weight loads when a launch has at most nt_row_tiles row tiles (AR steps)
+    int nt_row_tiles = 2;
     int t_x6_256 = 160, t_x6_128 = 100;   // ... from this many 256x128 / 128x128 tiles on (profiles/r02_gemm_sweep_x6.txt)
     bool markers = false;        // a named no-op kernel at every stage boundary: lets tools/pmc_stage_summary.py attribute
                                  // the rocprofv3 --pmc rows of one step to stages (measurement only)

@@ -66,6 +66,9 @@ def main(argv):
     launches = defaultdict(int)
     gemm = defaultdict(float)
     gemm_launches = 0
+
+    def is_engine(name):      # the GEMM / implicit-conv engine in all its arithmetic variants (f32 MFMA, x6, window)
+        return any(k in name for k in ("gemm_f32", "gemm_x6", "conv_win"))
     seen_counter_stage = set()
     for spec in ins:
         path, _, keep = spec.partition(":")
@@ -82,11 +85,11 @@ def main(argv):
                 counted_here.add(st)
             for cn, v in d["c"].items():
                 acc[st][cn] += v
-                if "gemm_f32" in d["name"]:
+                if is_engine(d["name"]):
                     gemm[cn] += v
             if counted:
                 launches[st] += 1
-                gemm_launches += "gemm_f32" in d["name"]
+                gemm_launches += is_engine(d["name"])
     res = {"unit": "GB per step; read = 2 x FETCH_SIZE KiB x 1024 (gfx950 correction), write = WRITE_SIZE KiB x 1024",
            "stages": {}, "sources": ins}
     tot_r = tot_w = 0.0

@@ -1366,6 +1366,248 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
+// ===================================================================================================
+// v2c: the x6 engine with the A operand through REGISTERS.  The LDS-DMA path tops out at ~12 B/clk per CU (the x6 tiles'
+// limit); in gemm_x6_dma_kernel 32 of a 256x128 tile's 56 KB per chunk are the f32 A rows.  Here every
+// lane loads the A fragments it multiplies straight from global memory into VGPRs in MFMA operand order (row lane & 31,
+// 8 consecutive k per k-block: two global_load_dwordx4), one chunk ahead, with plain vector loads - L2-resident
+// activations, a separate path from the DMA engine - and only the weight planes travel through the LDS ring.  The loads
+// are inline asm into loop-carried registers ("+v": updated in place; hipcc must not see an ordinary load, it could
+// only wait for it with vmcnt(0) and drain the ring).  In-order vmcnt: A(c+1) is issued BEFORE the ring refill of the
+// same round, so at the top of the next round "all but the youngest B_IT" covers A(c+1) and B(c+1).
+__device__ __attribute__((aligned(128))) float g_zero128[64];
+
+template <int OFF>
+__device__ __forceinline__ void gload_b128(f32x4& v, const float* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(v) : "v"(ptr), "n"(OFF) : "memory");
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST, int PRO>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_areg_kernel(GemmP p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int BPIECES = 3 * BN / 16;                  // bf16 plane pieces: 16 rows x 64 B
+    constexpr int B_IT = (BPIECES + NW - 1) / NW;
+    constexpr int STAGE = B_IT * NW * 1024;               // bytes per ring stage (weight planes only)
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (NST == 2 || NST == 3) && B_IT < 64, "config");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* ring = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int g = blockIdx.z;
+
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const bool nmajor = p.M < p.N;
+    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
+
+    const float* __restrict__ X = p.X + (long long)g * p.strideX;
+    const unsigned short* __restrict__ W3 = reinterpret_cast<const unsigned short*>(p.W3) + (long long)g * p.strideW;
+    const long long zoff_w = (const unsigned short*)g_zero16 - W3;
+    const long long plane = p.w3_plane;
+    const int half = lane >> 5;
+
+    int arow[TM];                                          // source row of this lane's A fragment rows (tap 0)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 32 + (lane & 31);
+        int b = kInvalidRow;
+        if (m < p.M) b = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
+        arow[i] = b;
+    }
+    const int Kt = p.K, ldw = p.ldw;
+    long long wofs[B_IT];
+    int wk[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int pc = j * NW + wave;                    // piece = plane * (BN / 16) + row block
+        const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
+        const int nl = rb * 16 + (lane >> 2);
+        const int n = n0 + nl;
+        wk[j] = ((lane & 3) ^ ((nl >> 2) & 3)) * 8;     // k offset of this lane's 16-byte slot inside a chunk
+        wofs[j] = (pc < BPIECES && n < p.N) ? pl * plane + (long long)n * ldw : -1;
+    }
+    const int nk = (Kt + BK - 1) / BK;
+    const int ldx = p.ldx, Rx = p.Rx, Cin = p.Cin, dil = p.dil;
+    const bool multi_tap = p.taps > 1;
+    wait_vmcnt<0>();
+    constexpr bool PRET = TM * TN <= 2;
+    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
+    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+
+    const bool fast = (Kt % BK == 0) && (!multi_tap || Cin % BK == 0);
+    const bool w_nt = p.w_nt != 0;
+    auto issue_b = [&](int c, int st) {
+        const int kchunk = c * BK;
+        char* Bs = ring + st * STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const int k = kchunk + wk[j];
+            const bool ok = (k < Kt) & (wofs[j] >= 0);
+            const long long off = ok ? wofs[j] + k : zoff_w;
+            if (w_nt)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                                 (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 2);
+            else
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                                 (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
+        }
+    };
+    // A fragments of one chunk: [k-block][row tile][16-byte half]; lane (row, half) holds k = 16*b + 8*half + 0..7
+    f32x4 ra_n[2][TM][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ra_n[b][i][j][e] = 0.0f;
+    int s_tap = 0, s_cc = 0;                              // of the next chunk whose A is loaded (chunks in order)
+    auto load_a = [&](int c) {
+        if (fast) {
+            const int dsrc = s_tap * dil;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int src = arow[i] + dsrc;
+                const float* ptr = (unsigned)src < (unsigned)Rx ? X + (long long)src * ldx + (s_cc + half * 8) : g_zero128;
+                gload_b128<0>(ra_n[0][i][0], ptr);
+                gload_b128<16>(ra_n[0][i][1], ptr);
+                gload_b128<64>(ra_n[1][i][0], ptr);
+                gload_b128<80>(ra_n[1][i][1], ptr);
+            }
+            s_cc += BK;
+            if (multi_tap && s_cc == Cin) { s_cc = 0; ++s_tap; }
+            return;
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int k = c * BK + b * 16 + half * 8 + j * 4;
+                    int tap = 0, cc = k;
+                    if (multi_tap) { tap = k / Cin; cc = k - tap * Cin; }
+                    const int src = arow[i] + tap * dil;
+                    const bool ok = (k < Kt) & ((unsigned)src < (unsigned)Rx);
+                    gload_b128<0>(ra_n[b][i][j], ok ? X + (long long)src * ldx + cc : g_zero128);
+                }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    load_a(0);
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+        if (st < nk) issue_b(st, st);
+
+    const float pro_slope = p.pro_slope;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
+    const int nrow = wn * WTN + (lane & 31);
+    const int swzb = (nrow >> 2) & 3;
+    const unsigned b_lane = lds0 + nrow * 64;
+    unsigned koffb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+
+    int st = 0;
+    for (int c = 0; c < nk; ++c) {
+        // A(c) and B(c) have landed once at most the youngest ring refill (B(c+1), NST = 3) is still in flight
+        if (NST == 3 && c + 1 < nk) wait_vmcnt<B_IT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        f32x4 ra[2][TM][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    asm volatile("" : "+v"(ra_n[b][i][j]));          // consumers depend on the wait above
+                    ra[b][i][j] = ra_n[b][i][j];
+                    asm volatile("" : "+v"(ra[b][i][j]));            // a real copy, made before the registers are reloaded
+                }
+        const unsigned sb = b_lane + (unsigned)st * STAGE;
+        if (c + 1 < nk) load_a(c + 1);                                // older than this round's refill in the vmcnt order
+        if (c + NST - 1 < nk) issue_b(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+        u32x4 rb[2][3][TN];
+        auto fetch = [&](int b) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
+                    rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
+                }
+        };
+        constexpr int F = 2 * TM, NMF = 6 * TN, VPM = (44 + NMF - 1) / NMF;
+        u32x4 pln[2][3];
+        auto products = [&](int b, int i, const u32x4* pp) {
+            const bf16x8 A1 = __builtin_bit_cast(bf16x8, pp[0]), A2 = __builtin_bit_cast(bf16x8, pp[1]),
+                         A3 = __builtin_bit_cast(bf16x8, pp[2]);
+            constexpr int PA[6] = {3, 1, 2, 2, 1, 1}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const bf16x8 At = PA[t] == 1 ? A1 : (PA[t] == 2 ? A2 : A3);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB[t]][j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
+                }
+            }
+        };
+        auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
+        auto wait_block = [&](int b) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
+        };
+        fetch(0);
+        fetch(1);
+        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);   // beside the LDS latency
+        __builtin_amdgcn_sched_barrier(0);
+        wait_block(0);
+        wait_block(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < F; ++s) {
+            const int b = s / TM, i = s % TM;
+            if (s + 1 < F) {
+                const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
+                tie(b2, i2);                     // keeps this split inside this step's scheduling region
+                split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
+            }
+            products(b, i, pln[s & 1]);
+            if (TM * TN > 1) {                  // pins the MFMA order (column tiles alternate) and, before the last step,
+#pragma unroll                                  // the split of the next fragment between them
+                for (int k = 0; k < NMF; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (s + 1 < F) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        st = st + 1 == NST ? 0 : st + 1;
+    }
+    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side: tile-configuration choice and launch
 
@@ -1414,6 +1656,11 @@ struct TileCfg {
       "x6dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                          \
       { gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_NONE>, gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
         gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
+#define MT2_GX6R(BM_, BN_, WM_, WN_, NST_)                                                                     \
+    { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (size_t)((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024, \
+      "x6areg" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                         \
+      { gemm_x6_areg_kernel<BM_, BN_, WM_, WN_, NST_, ACT_NONE>, gemm_x6_areg_kernel<BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
+        gemm_x6_areg_kernel<BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
 #define MT2_WX6(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024),   \
       "x6win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                     \
@@ -1473,6 +1720,13 @@ static const TileCfg kCfgs[] = {
     MT2_GX6(256, 128, 8, 1, 2),      // 42: 8 waves, 32x128 each: every A fragment is split ONCE per workgroup, 24 MFMAs per split
     MT2_GX6(128, 128, 4, 1, 2),      // 43: 4 waves, 32x128 each; 80 KiB -> 2 workgroups per CU
     MT2_GX6(128, 256, 4, 1, 2),      // 44: 4 waves, 32x256 each (48 MFMAs per split); 2 x 64 KiB
+    // v2c: x6 with the A operand through registers (plain vector loads), weight planes through the ring
+    MT2_GX6R(256, 128, 8, 1, 3),     // 45: 8 waves, 32x128 each; ring 3 x 24 KiB
+    MT2_GX6R(256, 128, 4, 2, 3),     // 46: 8 waves, 64x64 each
+    MT2_GX6R(128, 128, 4, 2, 3),     // 47: 8 waves, 32x64 each; 72 KiB -> 2 workgroups per CU
+    MT2_GX6R(128, 128, 4, 1, 3),     // 48: 4 waves, 32x128 each
+    MT2_GX6R(64, 128, 2, 2, 3),      // 49: 4 waves, 32x64 each; 72 KiB -> 2 workgroups per CU: mid-size AR launches
+    MT2_GX6R(128, 256, 4, 2, 2),     // 50: 8 waves, 32x128 each; ring 2 x 48 KiB
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 

@@ -1379,7 +1379,7 @@ __device__ __attribute__((aligned(128))) float g_zero128[64];
 
 template <int OFF>
 __device__ __forceinline__ void gload_b128(f32x4& v, const float* ptr) {
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(v) : "v"(ptr), "n"(OFF) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(ptr), "n"(OFF) : "memory");
 }
 
 template <int BM, int BN, int WGM, int WGN, int NST, int PRO>
@@ -1458,18 +1458,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_areg_kernel(GemmP p) {
                                                  (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
         }
     };
-    // A fragments of one chunk: [k-block][row tile][16-byte half]; lane (row, half) holds k = 16*b + 8*half + 0..7
-    f32x4 ra_n[2][TM][2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ra_n[b][i][j][e] = 0.0f;
+    // A fragments of one chunk: [k-block][row tile][16-byte half]; lane (row, half) holds k = 16*b + 8*half + 0..7.
+    // TWO register buffers that alternate between "being loaded" and "being multiplied" (the K loop is unrolled by two):
+    // no register copy of a buffer ever exists in the source, so none can be scheduled between a load's issue and its
+    // landing (a copy of the in-flight registers - as a loop-carried rename produces - reads garbage, and the late
+    // write then lands on whatever lives there).
+    typedef f32x4 AFrag[2][TM][2];
+    AFrag ra0, ra1;
     int s_tap = 0, s_cc = 0;                              // of the next chunk whose A is loaded (chunks in order)
-    auto load_a = [&](int c) {
+    auto load_a = [&](int c, AFrag& ra_n) {
         if (fast) {
             const int dsrc = s_tap * dil;
 #pragma unroll
@@ -1508,7 +1505,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_areg_kernel(GemmP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    load_a(0);
+    load_a(0, ra0);
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
         if (st < nk) issue_b(st, st);
@@ -1523,25 +1520,20 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_areg_kernel(GemmP p) {
     for (int b = 0; b < 2; ++b) koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
 
     int st = 0;
-    for (int c = 0; c < nk; ++c) {
+    auto round = [&](int c, AFrag& ra, AFrag& ra_n) {
         // A(c) and B(c) have landed once at most the youngest ring refill (B(c+1), NST = 3) is still in flight
         if (NST == 3 && c + 1 < nk) wait_vmcnt<B_IT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        f32x4 ra[2][TM][2];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    asm volatile("" : "+v"(ra_n[b][i][j]));          // consumers depend on the wait above
-                    ra[b][i][j] = ra_n[b][i][j];
-                    asm volatile("" : "+v"(ra[b][i][j]));            // a real copy, made before the registers are reloaded
-                }
+                for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(ra[b][i][j]));      // consumers depend on the wait above
         const unsigned sb = b_lane + (unsigned)st * STAGE;
-        if (c + 1 < nk) load_a(c + 1);                                // older than this round's refill in the vmcnt order
+        if (c + 1 < nk) load_a(c + 1, ra_n);                                // older than this round's refill in the vmcnt order
         if (c + NST - 1 < nk) issue_b(c + NST - 1, st == 0 ? NST - 1 : st - 1);
         u32x4 rb[2][3][TN];
         auto fetch = [&](int b) {
@@ -1603,6 +1595,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_areg_kernel(GemmP p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         st = st + 1 == NST ? 0 : st + 1;
+    };
+    for (int c = 0; c < nk; c += 2) {
+        round(c, ra0, ra1);
+        if (c + 1 < nk) round(c + 1, ra1, ra0);
     }
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);

@@ -209,7 +209,7 @@ def main() -> None:
 
     ev = None if dry else [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
-    def step(time_vqpe=False):
+    def step(time_vqpe=False, exchange=True):
         # configs[2] "full VQ-PE -> ...": VQProsodyEncoder.forward (conv stacks + codebook L2-argmin) on the 431-frame
         # prompt mel - the prosody codes a prompt-conditioned PLM / stage-2 extraction consume.  Same work either way:
         # "overlap" runs it inside the synthesis call on an internal stream beside the ADM, "separate" in front.
@@ -223,7 +223,7 @@ def main() -> None:
         out = model.synthesize_batch(phone, pl, mel_in, ml, forced_dur=dur, forced_codes=codes, run_plm=full,
                                      vocoder=full, tm_cap=shape.Tm, skip_adm=args.skip_adm, prompt_vqpe=side)
         mel, lens = out[0], out[1]
-        if world > 1:   # the path's only exchange: ONE fixed-capacity RCCL all-gather over xGMI, lengths stay on the device
+        if world > 1 and exchange:   # the path's only exchange: ONE fixed-capacity RCCL all-gather over xGMI, lengths stay on the device
             mel, lens = gather_mels(mel, lens, b_cap=B, t_cap=shape.Tm, host_lens=False)
         return mel, lens
 
@@ -282,8 +282,9 @@ def main() -> None:
         result["data"] = "DRY RUN on CPU with a stand-in engine: not a measurement"
     if rank == 0 and not args.no_roofline and not dry:
         # (1) one PROFILED step (events at the stage boundaries only - no per-launch instrumentation)
+        # (rank 0 only: these extra steps must not enter the collective the other ranks have already left)
         model.set_profiling(True)
-        step(time_vqpe=True)
+        step(time_vqpe=True, exchange=False)
         torch.cuda.synchronize()
         stage_ms = {k: v for k, v in model.last_stage_ms().items()}
         if full and args.vqpe == "separate":
@@ -295,7 +296,7 @@ def main() -> None:
         # (2) one TRACED step: HIP events around every GEMM/conv launch -> per tile configuration breakdown.  The
         # traced step is slower than the timed ones (10k event pairs); it only apportions, it is never the denominator.
         model.gemm_trace_begin()
-        step()
+        step(exchange=False)
         torch.cuda.synchronize()
         shapes = model.gemm_trace_shapes(14)
         tr = model.gemm_trace_end()
@@ -388,6 +389,7 @@ def main() -> None:
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
+        dist.barrier()          # rank 0 may still be in its local roofline steps: leave together
         dist.destroy_process_group()
 
 

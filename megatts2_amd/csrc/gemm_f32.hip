@@ -1859,7 +1859,7 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     // (out-projection, ff.3, early AR steps).
     if (o.x6_gemm && p.W3 && (p.K & 7) == 0 && (p.ldw & 7) == 0 && p.pro_act < PRO_LN && p.N > 64) {
         if (t256 >= o.t_x6_256) bi = 37;
-        else if (t128 >= o.t_x6_128) bi = 39;
+        else if (t128 >= o.t_x6_128) bi = t128 <= o.t_x6_64 ? 49 : 39;   // few 128x128 tiles: 64x128, two workgroups per CU
     }
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;
     *idx_out = bi;

@@ -1710,7 +1710,7 @@ static const TileCfg kCfgs[] = {
     // v2b: implicit GEMM on the bf16 pipe, f32-equivalent; stage = BM x 128 B (A, f32) + 3 x BN x 64 B (B planes)
     MT2_GX6(256, 128, 4, 2, 2),      // 37: 8 waves, 64x64 each; 2 x 56 KiB
     MT2_GX6(128, 128, 4, 2, 3),      // 38: 8 waves, 32x64 each; 3 x 40 KiB
-    MT2_GX6(128, 128, 4, 2, 2),      // 39: the same with a 2-deep ring: 80 KiB -> 2 workgroups per CU
+    MT2_GX6(128, 128, 4, 2, 2),      // 39: the same with a 2-deep ring: 80 KiB (LDS would admit two workgroups per CU, its 197 VGPRs one)
     MT2_GX6(128, 256, 2, 4, 2),      // 40: 8 waves, 64x64 each; 2 x 64 KiB (wide N: the AR feed-forward / QKV)
     MT2_GX6(256, 128, 8, 2, 2),      // 41: 16 waves, 32x64 each; 2 x 56 KiB (4 waves per SIMD)
     MT2_GX6(256, 128, 8, 1, 2),      // 42: 8 waves, 32x128 each: every A fragment is split ONCE per workgroup, 24 MFMAs per split

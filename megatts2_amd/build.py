@@ -21,6 +21,7 @@ LIB = os.path.join(LIBDIR, "libmegatts2_hip.so")
 UNITS = ["gemm_f32.hip", "attention.hip", "rowops.hip", "model_load.hip", "model_stages.hip"]
 DEPS = ["mt2_kernels.h", "mt2_model.h", "capi.inc", os.path.join("..", "..", "include", "megatts2_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("MT2_EXTRA_HIPCC_FLAGS", "").split()      # e.g. -DMT2_PHASE_TIMING (tools/x6_phase_timing.py)
 
 
 def _hipcc() -> str:

@@ -1258,14 +1258,28 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
         koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
     }
 
+#ifdef MT2_PHASE_TIMING
+    // per-phase cycle sums of wave 0 of one workgroup in the middle of the grid (s_memtime; each stamp also drains lgkmcnt,
+    // so stamps sit only where the kernel waits anyway)
+    const bool timing = p.dbg != nullptr && bid == (int)(gridDim.x / 2) && wave == 0;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define MT2_T(i_) do { if (timing) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i_] += t_ - tprev; tprev = t_; } } while (0)
+    if (timing) tprev = __builtin_readcyclecounter();
+#else
+#define MT2_T(i_) do { } while (0)
+#endif
     int st = 0;
     for (int c = 0; c < nk; ++c) {
+        MT2_T(5);                                   // rest of the previous chunk (MFMA steps)
         if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();
         else wait_vmcnt<0>();
+        MT2_T(0);                                   // DMA wait
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        MT2_T(1);                                   // barrier
         const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
         if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);     // refill the stage freed by the barrier
+        MT2_T(2);                                   // refill issue
         f32x4 ra[2][TM][2];
         u32x4 rb[2][3][TN];
         auto fetch = [&](int b) {
@@ -1321,6 +1335,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
         __builtin_amdgcn_sched_barrier(0);
         wait_block(0);
         __builtin_amdgcn_sched_barrier(0);
+        MT2_T(3);                                   // first fragment fetch (LDS latency)
         fetch(1);
         if constexpr (TM * TN == 1) {
             // one tile per wave: 44 VALU per 6 MFMAs is more than fits in the MFMA shadow (measured: interleaving costs
@@ -1336,6 +1351,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
         } else {
         split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
         __builtin_amdgcn_sched_barrier(0);
+        MT2_T(4);                                   // second fetch issued + first split (drains the second fetch too)
 #pragma unroll
         for (int s = 0; s < F; ++s) {
             const int b = s / TM, i = s % TM;
@@ -1362,6 +1378,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
         }
         st = st + 1 == NST ? 0 : st + 1;
     }
+#ifdef MT2_PHASE_TIMING
+    MT2_T(5);
+    if (timing && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p.dbg[i] = tacc[i];
+        p.dbg[6] = (unsigned long long)nk;
+    }
+#endif
+#undef MT2_T
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 }

@@ -29,6 +29,7 @@ struct GemmP {
     const float* X; long long strideX; int ldx; int Rx;
     const int* rowbase; int a_mul; int shift0; int taps; int dil; int Cin;
     const float* W; long long strideW; int ldw;
+    unsigned long long* dbg = nullptr;   // MT2_PHASE_TIMING builds only: per-phase cycle sums of one wave (tools/x6_phase_timing.py)
     int w_nt = 0;               // weight loads with the non-temporal cache policy (set by launch_gemm: weights streamed ~once per launch)
     const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like
     long long w3_plane = 0;     // W (same ldw / strideW, in bf16 elements), planes w3_plane elements apart (0: N * ldw) -

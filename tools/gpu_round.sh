@@ -129,6 +129,11 @@ probe_x6)
     python tools/pmc_probe_summary.py gpurun_out/probe_x6_$i | tee gpurun_out/probe_x6_summary_$i.txt | cut -c1-400
     find gpurun_out/probe_x6_$i -name "*.csv" -size +4M -delete
   done ;;
+phase)
+  # instrumented build in a scratch copy of the package (the in-tree library stays the production one)
+  rm -rf /tmp/mt2_phase && mkdir -p /tmp/mt2_phase && cp -r megatts2_amd include tools /tmp/mt2_phase/
+  (cd /tmp/mt2_phase && rm -rf megatts2_amd/lib && MT2_EXTRA_HIPCC_FLAGS=-DMT2_PHASE_TIMING python -m megatts2_amd.build > $GRAFT_REPO_ROOT/gpurun_out/build_phase.log 2>&1 && MT2_EXTRA_HIPCC_FLAGS=-DMT2_PHASE_TIMING timeout 300 python tools/x6_phase_timing.py) > gpurun_out/x6_phase_timing.txt 2>&1
+  echo "phase rc=$?"; grep -v amdgpu.ids gpurun_out/x6_phase_timing.txt ;;
 splitk)
   for w in C2 C3; do for f in "" "--no-splitk"; do
     timeout 600 python bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-roofline ${f:+--opt splitk=0} > gpurun_out/bench_sk.log 2>&1

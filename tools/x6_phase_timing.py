@@ -1,0 +1,13 @@
+"""Where a wave of the x6 GEMM kernel spends its cycles: per-phase s_memtime sums of one wave (DMA wait, barrier, refill
+issue, first fragment fetch, second fetch + first split, MFMA steps) per 32-deep chunk.  Needs a library built with
+MT2_EXTRA_HIPCC_FLAGS=-DMT2_PHASE_TIMING (tools/gpu_round.sh phase):  python tools/x6_phase_timing.py"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from megatts2_amd import runtime as rt
+
+rt.device_check()
+for name, M, N, K, taps, cfg in [("big", 4096, 4096, 4096, 1, 37), ("big", 4096, 4096, 4096, 1, 39), ("big", 4096, 4096, 4096, 1, 42),
+                                 ("decoder", 13858, 512, 2560, 5, 37), ("plm_ff0", 1728, 4096, 1024, 1, 37),
+                                 ("plm_ff0", 864, 4096, 1024, 1, 39), ("plm_qkv", 864, 3072, 1024, 1, 39)]:
+    ms, cn = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=4, w_copies=2, flags=4)
+    print(f"{name} {M}x{N}x{K} {cn}: {ms * 1e3:.1f} us {2.0 * M * N * K / ms / 1e9:.1f} TF/s  ({ms * 1e-3 * 2.1e9 / ((K + 31) // 32):.0f} cycles per chunk at 2.1 GHz, one tile per CU pass)", flush=True)

@@ -23,6 +23,7 @@
 // between utterances supply the zero padding (mt2_kernels.h).  Epilogue: bias, activation, scale,
 // residual add, gap-row mask, all fused.
 #include "mt2_kernels.h"
+#include <type_traits>
 
 #include <algorithm>
 #include <atomic>
@@ -1230,6 +1231,29 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
         }
     };
 
+    // One piece of the refill (fast path), so that the K loop can spread a chunk's L LDS-DMA instructions over its MFMA
+    // steps: measured with s_memtime (tools/x6_phase_timing.py), issuing all of them at the top of the chunk stalls every
+    // wave ~140 cycles per instruction (the CU's address path takes the 8 waves' 56 KB at ~58 B/clk) - 970 of a 256x128
+    // chunk's 5270 cycles with the matrix pipe idle.  r_dsrc / r_cc: tap row offset and channel offset of that chunk.
+    auto issue_piece = [&](int idx, int c, int st, int r_dsrc, int r_cc) {
+        if (idx < A_IT) {
+            const int j = idx;
+            float* As = reinterpret_cast<float*>(ring + st * STAGE) + wave * 256;
+            const int src = abase[j] + r_dsrc;
+            const int cc = r_cc + (NW % 2 == 0 ? kl0 : kslot_of(j));
+            const long long off = (unsigned)src < (unsigned)Rx ? (long long)src * ldx + cc : zoff_x;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                             (__attribute__((address_space(3))) void*)(As + j * NW * 256), 16, 0, 0);
+        } else {
+            const int j = idx - A_IT;
+            char* Bs = ring + st * STAGE + STAGE_A + wave * 1024;
+            const long long off = wofs[j] >= 0 ? wofs[j] + (c * BK + wk[j]) : zoff_w;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                             (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
+        }
+    };
+    constexpr bool SPREAD = TM * TN > 1;          // the pipelined K loop below has 2 * TM steps to spread the pieces over
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1269,7 +1293,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
 #define MT2_T(i_) do { } while (0)
 #endif
     int st = 0;
-    for (int c = 0; c < nk; ++c) {
+    // one chunk; SP: refill spread over the MFMA steps (fast path), RF: this chunk refills (compile-time in the spread
+    // loops, so that a step stays ONE basic block and the sched_group_barrier pattern can place the pieces)
+    auto chunk = [&](int c, auto sp_c, auto rf_c) {
+        constexpr bool SP = decltype(sp_c)::value, RF = decltype(rf_c)::value;
         MT2_T(5);                                   // rest of the previous chunk (MFMA steps)
         if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();
         else wait_vmcnt<0>();
@@ -1278,7 +1305,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
         asm volatile("" ::: "memory");
         MT2_T(1);                                   // barrier
         const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
-        if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);     // refill the stage freed by the barrier
+        // refill of the stage freed by the barrier: as one block (general path), or piece by piece between the MFMA steps
+        const int rst = st == 0 ? NST - 1 : st - 1;
+        int r_dsrc = 0, r_cc = 0;
+        if constexpr (!SP) {
+            if (c + NST - 1 < nk) issue(c + NST - 1, rst);
+        } else if constexpr (RF) {
+            r_dsrc = s_tap * dil;
+            r_cc = s_cc;
+            s_cc += BK;
+            if (multi_tap && s_cc == Cin) { s_cc = 0; ++s_tap; }
+        }
         MT2_T(2);                                   // refill issue
         f32x4 ra[2][TM][2];
         u32x4 rb[2][3][TN];
@@ -1365,18 +1402,37 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
                 }
                 split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
             }
+            constexpr int PPS = (L + F - 1) / F;          // refill pieces issued in this step
+            if constexpr (SP && RF) {
+#pragma unroll
+                for (int q = 0; q < PPS; ++q)
+                    if (s * PPS + q < L) issue_piece(s * PPS + q, c + NST - 1, rst, r_dsrc, r_cc);
+            }
             products(b, i, pln[s & 1]);
-            if (s + 1 < F) {
+            {
+                constexpr int VPM2 = (44 + 10 * PPS + NMF - 1) / NMF;     // + the pieces' address arithmetic
 #pragma unroll
                 for (int k = 0; k < NMF; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM2, 0);
+                    if (SP && RF && k >= 1 && k <= PPS) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // one LDS-DMA piece behind an MFMA
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         }
         st = st + 1 == NST ? 0 : st + 1;
+    };
+    {
+        using T_ = std::integral_constant<bool, true>;
+        using F_ = std::integral_constant<bool, false>;
+        int c = 0;
+        if (SPREAD && fast) {
+            for (; c + NST - 1 < nk; ++c) chunk(c, T_{}, T_{});
+            for (; c < nk; ++c) chunk(c, T_{}, F_{});
+        } else {
+            for (; c < nk; ++c) chunk(c, F_{}, F_{});
+        }
     }
 #ifdef MT2_PHASE_TIMING
     MT2_T(5);

@@ -1252,7 +1252,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
                                              (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
         }
     };
-    constexpr bool SPREAD = TM * TN > 1;          // the pipelined K loop below has 2 * TM steps to spread the pieces over
+    // MEASURED SLOWER, so compiled out: with the pieces placed one behind an MFMA the refill phase at the chunk top
+    // disappears (968 -> 72 cycles) but every piece then stalls its wave ~230 cycles INSIDE the MFMA phase (2098 -> 3710
+    // cycles), 256x128: 178 -> 167 TF/s, 128x128: 153 -> 136 (profiles/r02_x6_phase_timing.txt).  An LDS-DMA instruction
+    // costs its issuing wave 140-230 cycles wherever it sits; only loader waves of their own would take it off the
+    // compute waves.
+    constexpr bool SPREAD = false;
 
     f32x16 acc[TM][TN];
 #pragma unroll

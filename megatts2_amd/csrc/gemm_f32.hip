@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
         // Fragment-level software pipeline: the three planes of fragment s+1 are split on the vector pipe WHILE the
         // matrix pipe works through the 6*TN products of fragment s (sched_group_barrier pins the interleave: hipcc
         // otherwise issues the 44 VALU of a split as one block in front of its MFMAs and the matrix pipe idles).
-        constexpr int F = 2 * TM, NMF = 6 * TN, VPM = (44 + NMF - 1) / NMF;
+        constexpr int F = 2 * TM, NMF = 6 * TN;
         u32x4 pln[2][3];
         auto products = [&](int b, int i, const u32x4* pp) {
             const bf16x8 A1 = __builtin_bit_cast(bf16x8, pp[0]), A2 = __builtin_bit_cast(bf16x8, pp[1]),

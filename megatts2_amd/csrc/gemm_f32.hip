@@ -1414,8 +1414,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
                     if (s * PPS + q < L) issue_piece(s * PPS + q, c + NST - 1, rst, r_dsrc, r_cc);
             }
             products(b, i, pln[s & 1]);
-            {
-                constexpr int VPM2 = (44 + 10 * PPS + NMF - 1) / NMF;     // + the pieces' address arithmetic
+            if (SP || s + 1 < F) {
+                constexpr int VPM2 = (44 + (SP && RF ? 10 * PPS : 0) + NMF - 1) / NMF;     // + the pieces' address arithmetic
 #pragma unroll
                 for (int k = 0; k < NMF; ++k) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

@@ -1690,6 +1690,249 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_areg_kernel(GemmP p) {
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
+// ===================================================================================================
+// v2d: the x6 engine with LOADER WAVES.  Measured with s_memtime (profiles/r02_x6_phase_timing.txt): an LDS-DMA
+// instruction costs the wave that issues it 140-230 cycles wherever it is placed - 970 of a 256x128 chunk's 5270 cycles
+// when the 8 compute waves issue the refill themselves, with the matrix pipe idle meanwhile.  Here NL extra waves do
+// nothing but the ring refill (all address state lives in them) and the NW compute waves never issue a vector-memory
+// instruction inside the K loop: per chunk everybody meets at ONE s_barrier - a loader arrives once its pieces of the
+// chunk have landed (counted vmcnt), a compute wave once it has finished the previous chunk - then the loaders refill
+// the stage that barrier freed while the compute waves fetch, split and multiply.  Arithmetic, LDS layout and fragment
+// pipeline are gemm_x6_dma_kernel's.
+template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO>
+__global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(GemmP p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int PA = BM / 8;                            // f32 A pieces per chunk: 8 rows x 128 B
+    constexpr int PB = 3 * BN / 16;                       // bf16 plane pieces per chunk: 16 rows x 64 B
+    constexpr int A_IT = (PA + NL - 1) / NL, B_IT = (PB + NL - 1) / NL;   // per loader wave
+    constexpr int L = A_IT + B_IT;
+    constexpr int STAGE_A = BM * BK * 4, STAGE_B = PB * 1024, STAGE = STAGE_A + STAGE_B;   // bytes
+    static_assert(PA % NL == 0 && PB % NL == 0 && WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64 &&
+                  TM * TN > 1, "config");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* ring = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.z;
+
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const bool nmajor = p.M < p.N;
+    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
+    const int Kt = p.K;
+    const int nk = (Kt + BK - 1) / BK;
+
+    if (wave_all >= NW) {
+        // ------------------------------------------------------------------ loader wave lw: pieces lw, lw + NL, ...
+        const int lw = wave_all - NW;
+        const float* __restrict__ X = p.X + (long long)g * p.strideX;
+        const unsigned short* __restrict__ W3 = reinterpret_cast<const unsigned short*>(p.W3) + (long long)g * p.strideW;
+        const long long zoff_x = (const float*)g_zero16 - X;
+        const long long zoff_w = (const unsigned short*)g_zero16 - W3;
+        const long long plane = p.w3_plane;
+        const int lrow = lane >> 3;
+        const int ldx = p.ldx, Rx = p.Rx, Cin = p.Cin, dil = p.dil, ldw = p.ldw;
+        const bool multi_tap = p.taps > 1;
+        int abase[A_IT], akl[A_IT];
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            const int pc = j * NL + lw;                      // A piece: rows pc*8 .. pc*8+7
+            const int m = m0 + pc * 8 + lrow;
+            int b = kInvalidRow;
+            if (m < p.M) b = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
+            abase[j] = b;
+            akl[j] = ((lane & 7) ^ ((pc * 4 + (lane >> 4)) & 7)) * 4;       // k offset of this lane's 16-byte slot
+        }
+        long long wofs[B_IT];
+        int wk[B_IT];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const int pc = j * NL + lw;                      // B piece = plane * (BN / 16) + row block
+            const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
+            const int nl = rb * 16 + (lane >> 2);
+            const int n = n0 + nl;
+            wk[j] = ((lane & 3) ^ ((nl >> 2) & 3)) * 8;
+            wofs[j] = n < p.N ? pl * plane + (long long)n * ldw : -1;
+        }
+        wait_vmcnt<0>();                                     // the rowbase loads
+        const bool fast = (Kt % BK == 0) && (!multi_tap || Cin % BK == 0);
+        int s_tap = 0, s_cc = 0;
+        auto issue = [&](int c, int st) {
+            const int kchunk = c * BK;
+            float* As = reinterpret_cast<float*>(ring + st * STAGE) + lw * 256;
+            char* Bs = ring + st * STAGE + STAGE_A + lw * 1024;
+            if (fast) {
+                const int dsrc = s_tap * dil;
+#pragma unroll
+                for (int j = 0; j < A_IT; ++j) {
+                    const int src = abase[j] + dsrc;
+                    const long long off = (unsigned)src < (unsigned)Rx ? (long long)src * ldx + (s_cc + akl[j]) : zoff_x;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                                     (__attribute__((address_space(3))) void*)(As + j * NL * 256), 16, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < B_IT; ++j) {
+                    const long long off = wofs[j] >= 0 ? wofs[j] + (kchunk + wk[j]) : zoff_w;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                                     (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16, 0, 0);
+                }
+                s_cc += BK;
+                if (multi_tap && s_cc == Cin) { s_cc = 0; ++s_tap; }
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < A_IT; ++j) {
+                const int k = kchunk + akl[j];
+                int tap = 0, cc = k;
+                if (multi_tap) { tap = k / Cin; cc = k - tap * Cin; }
+                const int src = abase[j] + tap * dil;
+                const bool ok = (k < Kt) & ((unsigned)src < (unsigned)Rx);
+                const long long off = ok ? (long long)src * ldx + cc : zoff_x;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                                 (__attribute__((address_space(3))) void*)(As + j * NL * 256), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < B_IT; ++j) {
+                const int k = kchunk + wk[j];
+                const bool ok = (k < Kt) & (wofs[j] >= 0);
+                const long long off = ok ? wofs[j] + k : zoff_w;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                                 (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nk) issue(st, st);
+        int st = 0;
+        for (int c = 0; c < nk; ++c) {
+            if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();       // this wave's pieces of chunk c have landed
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                            // chunk c complete; chunk c-1's stage is free
+            if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute wave
+    const int wave = wave_all;
+    const int wm = wave / WGN, wn = wave % WGN;
+    constexpr bool PRET = TM * TN <= 2;
+    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
+    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const float pro_slope = p.pro_slope;
+    const int half = lane >> 5;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
+    const int swza = (lane >> 1) & 7;
+    const unsigned a_lane = lds0 + ((wm * WTM + (lane & 31)) * BK) * 4;
+    const int nrow = wn * WTN + (lane & 31);
+    const int swzb = (nrow >> 2) & 3;
+    const unsigned b_lane = lds0 + STAGE_A + nrow * 64;
+    unsigned koffa[2][2], koffb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        koffa[b][0] = (unsigned)(((b * 4 + half * 2) ^ swza) * 16);
+        koffa[b][1] = (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
+        koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+    }
+
+    int st = 0;
+    for (int c = 0; c < nk; ++c) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
+        f32x4 ra[2][TM][2];
+        u32x4 rb[2][3][TN];
+        auto fetch = [&](int b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ra[b][i][0] = lds_read_b128(sa + koffa[b][0] + i * 32 * BK * 4);
+                ra[b][i][1] = lds_read_b128(sa + koffa[b][1] + i * 32 * BK * 4);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
+                    rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
+                }
+        };
+        constexpr int F = 2 * TM, NMF = 6 * TN, VPM = (44 + NMF - 1) / NMF;
+        u32x4 pln[2][3];
+        auto products = [&](int b, int i, const u32x4* pp) {
+            const bf16x8 A1 = __builtin_bit_cast(bf16x8, pp[0]), A2 = __builtin_bit_cast(bf16x8, pp[1]),
+                         A3 = __builtin_bit_cast(bf16x8, pp[2]);
+            constexpr int PA_[6] = {3, 1, 2, 2, 1, 1}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const bf16x8 At = PA_[t] == 1 ? A1 : (PA_[t] == 2 ? A2 : A3);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB_[t]][j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
+                }
+            }
+        };
+        auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
+        auto wait_block = [&](int b) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < TM; ++i) tie(b, i);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
+        };
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_block(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(1);
+        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < F; ++s) {
+            const int b = s / TM, i = s % TM;
+            if (s + 1 < F) {
+                const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
+                if (b2 != b) {
+                    wait_block(b2);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    tie(b2, i2);
+                }
+                split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
+            }
+            products(b, i, pln[s & 1]);
+            if (s + 1 < F) {
+#pragma unroll
+                for (int k = 0; k < NMF; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        st = st + 1 == NST ? 0 : st + 1;
+    }
+    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side: tile-configuration choice and launch
 
@@ -1743,6 +1986,11 @@ struct TileCfg {
       "x6areg" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                         \
       { gemm_x6_areg_kernel<BM_, BN_, WM_, WN_, NST_, ACT_NONE>, gemm_x6_areg_kernel<BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
         gemm_x6_areg_kernel<BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
+#define MT2_GX6L(BM_, BN_, WM_, WN_, NL_, NST_)                                                                \
+    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),       \
+      "x6ldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
+      { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
+        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
 #define MT2_WX6(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024),   \
       "x6win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                     \
@@ -1809,6 +2057,12 @@ static const TileCfg kCfgs[] = {
     MT2_GX6R(128, 128, 4, 1, 3),     // 48: 4 waves, 32x128 each
     MT2_GX6R(64, 128, 2, 2, 3),      // 49: 4 waves, 32x64 each; 72 KiB -> 2 workgroups per CU: mid-size AR launches
     MT2_GX6R(128, 256, 4, 2, 2),     // 50: 8 waves, 32x128 each; ring 2 x 48 KiB
+    // v2d: x6 with loader waves (the compute waves issue no vector-memory instruction inside the K loop)
+    MT2_GX6L(256, 128, 4, 2, 4, 2),  // 51: 8 compute + 4 loader waves
+    MT2_GX6L(256, 128, 4, 2, 2, 2),  // 52: 8 + 2
+    MT2_GX6L(128, 128, 4, 2, 4, 2),  // 53: 8 + 4
+    MT2_GX6L(128, 128, 4, 2, 2, 2),  // 54: 8 + 2
+    MT2_GX6L(128, 128, 4, 2, 4, 3),  // 55: 8 + 4, 3-deep ring (120 KiB)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 

@@ -2198,8 +2198,9 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     // 295.2 ms, profiles/r02_opts_ab.txt); below that the K-split f32 tiles keep their latency advantage
     // (out-projection, ff.3, early AR steps).
     if (o.x6_gemm && p.W3 && (p.K & 7) == 0 && (p.ldw & 7) == 0 && p.pro_act < PRO_LN && p.N > 64) {
-        if (t256 >= o.t_x6_256) bi = 37;
-        else if (t128 >= o.t_x6_128) bi = t128 <= o.t_x6_64 ? 49 : 39;   // few 128x128 tiles: 64x128, two workgroups per CU
+        // loader-wave variants (profiles/r02_gemm_sweep_x6_v5_ldr.txt: +10..12 % over 37, +16..20 % over 39)
+        if (t256 >= o.t_x6_256) bi = o.x6_loaders ? 51 : 37;
+        else if (t128 >= o.t_x6_128) bi = t128 <= o.t_x6_64 ? 49 : (o.x6_loaders ? 55 : 39);
     }
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;
     *idx_out = bi;

@@ -64,6 +64,7 @@ struct EngineOpts {
     bool x6_conv = true;         // ... on the bf16 matrix pipe, f32-equivalent 3-way split (6 products), where W3 planes exist
     bool x6_gemm = true;         // the big-tile implicit GEMMs likewise (gemm_x6_dma_kernel)
     bool x6_splitk = true;       // K slices (through the next LayerNorm) to give the N = d AR GEMMs enough x6 tiles
+    bool x6_loaders = true;      // x6 GEMM tiles with loader waves (gemm_x6_ldr_kernel) instead of self-refilling compute waves
     bool nt_weights = false;     // non-temporal weight loads when a launch has at most nt_row_tiles row tiles (AR steps)
     int nt_row_tiles = 2;
     int t_x6_64 = 0;             // up to this many 128x128 tiles an x6 launch uses 64x128 tiles (A through registers, 2 WG/CU):

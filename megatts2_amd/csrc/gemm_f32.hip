@@ -1699,7 +1699,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_areg_kernel(GemmP p) {
 // chunk have landed (counted vmcnt), a compute wave once it has finished the previous chunk - then the loaders refill
 // the stage that barrier freed while the compute waves fetch, split and multiply.  Arithmetic, LDS layout and fragment
 // pipeline are gemm_x6_dma_kernel's.
-template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO>
+template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO, bool XP = false>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(GemmP p) {
     constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -1711,6 +1711,11 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     constexpr int STAGE_A = BM * BK * 4, STAGE_B = PB * 1024, STAGE = STAGE_A + STAGE_B;   // bytes
     static_assert(PA % NL == 0 && PB % NL == 0 && WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64 &&
                   TM * TN > 1, "config");
+    // XP (cross-chunk prefetch, 3-deep ring): the loaders run one chunk further ahead (chunks <= c+1 are in LDS at the
+    // barrier in front of chunk c, chunk c+2 in flight), so a compute wave fetches and splits the FIRST fragments of chunk
+    // c+1 beside the last MFMAs of chunk c - the fetch latency (~400 cycles) and the first split (~270) leave the serial
+    // phase at the top of every chunk; only the barrier remains there.
+    static_assert(!XP || NST == 3, "cross-chunk prefetch needs the 3-deep ring");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ring = reinterpret_cast<char*>(smem);
@@ -1810,8 +1815,8 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
             if (st < nk) issue(st, st);
         int st = 0;
         for (int c = 0; c < nk; ++c) {
-            if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();       // this wave's pieces of chunk c have landed
-            else wait_vmcnt<0>();
+            if (!XP && c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();   // this wave's pieces of chunk c have landed
+            else wait_vmcnt<0>();                                        // XP: of chunk c+1 as well
             __builtin_amdgcn_s_barrier();                            // chunk c complete; chunk c-1's stage is free
             if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
             st = st + 1 == NST ? 0 : st + 1;
@@ -1851,63 +1856,90 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     }
 
     int st = 0;
-    for (int c = 0; c < nk; ++c) {
+    f32x4 ra[2][TM][2];
+    u32x4 rb[2][3][TN];
+    u32x4 pln[2][3];
+    constexpr int F = 2 * TM, NMF = 6 * TN, VPM = (44 + NMF - 1) / NMF;
+    auto fetch = [&](int b, unsigned sa, unsigned sb) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ra[b][i][0] = lds_read_b128(sa + koffa[b][0] + i * 32 * BK * 4);
+            ra[b][i][1] = lds_read_b128(sa + koffa[b][1] + i * 32 * BK * 4);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
+                rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
+            }
+    };
+    // products t0 <= t < t1 of fragment (b, i) with the column tiles of k-block b
+    auto products = [&](int b, int i, const u32x4* pp, int t0, int t1) {
+        const bf16x8 A1 = __builtin_bit_cast(bf16x8, pp[0]), A2 = __builtin_bit_cast(bf16x8, pp[1]),
+                     A3 = __builtin_bit_cast(bf16x8, pp[2]);
+        constexpr int PA_[6] = {3, 1, 2, 2, 1, 1}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            if (t < t0 || t >= t1) continue;
+            const bf16x8 At = PA_[t] == 1 ? A1 : (PA_[t] == 2 ? A2 : A3);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB_[t]][j]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
+    auto wait_block = [&](int b) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) tie(b, i);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
+    };
+    auto pattern = [&](int nmf) {
+#pragma unroll
+        for (int k = 0; k < NMF; ++k) {
+            if (k >= nmf) break;
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        }
+    };
+    if constexpr (XP) {       // first fragments of chunk 0 (the only exposed fetch + split)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
-        f32x4 ra[2][TM][2];
-        u32x4 rb[2][3][TN];
-        auto fetch = [&](int b) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ra[b][i][0] = lds_read_b128(sa + koffa[b][0] + i * 32 * BK * 4);
-                ra[b][i][1] = lds_read_b128(sa + koffa[b][1] + i * 32 * BK * 4);
-            }
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
-                    rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
-                }
-        };
-        constexpr int F = 2 * TM, NMF = 6 * TN, VPM = (44 + NMF - 1) / NMF;
-        u32x4 pln[2][3];
-        auto products = [&](int b, int i, const u32x4* pp) {
-            const bf16x8 A1 = __builtin_bit_cast(bf16x8, pp[0]), A2 = __builtin_bit_cast(bf16x8, pp[1]),
-                         A3 = __builtin_bit_cast(bf16x8, pp[2]);
-            constexpr int PA_[6] = {3, 1, 2, 2, 1, 1}, PB_[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const bf16x8 At = PA_[t] == 1 ? A1 : (PA_[t] == 2 ? A2 : A3);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB_[t]][j]);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
-                }
-            }
-        };
-        auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
-        auto wait_block = [&](int b) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < TM; ++i) tie(b, i);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
-        };
-        fetch(0);
+        fetch(0, a_lane, b_lane);
         __builtin_amdgcn_sched_barrier(0);
         wait_block(0);
         __builtin_amdgcn_sched_barrier(0);
-        fetch(1);
         split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int c = 0; c < nk; ++c) {
+        const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
+        const int stn = st + 1 == NST ? 0 : st + 1;
+        if constexpr (!XP) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            fetch(0, sa, sb);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_block(0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(1, sa, sb);
+            split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            fetch(1, sa, sb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int s = 0; s < F; ++s) {
             const int b = s / TM, i = s % TM;
-            if (s + 1 < F) {
+            const bool last = s + 1 == F;
+            if (!last) {
                 const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
                 if (b2 != b) {
                     wait_block(b2);
@@ -1916,16 +1948,33 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
                     tie(b2, i2);
                 }
                 split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
+                products(b, i, pln[s & 1], 0, 6);
+                pattern(NMF);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (XP && c + 1 < nk) {
+                // last fragment of the chunk: block 0's registers are dead (every MFMA that reads them has been issued;
+                // the LDS data arrive long after those have read their operands) - request chunk c+1's block 0 into
+                // them, run the first half of the products, then split the next chunk's first fragment beside the rest
+                fetch(0, a_lane + (unsigned)stn * STAGE, b_lane + (unsigned)stn * STAGE);
+                __builtin_amdgcn_sched_barrier(0);
+                products(b, i, pln[s & 1], 0, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                wait_block(0);
+                __builtin_amdgcn_sched_barrier(0);
+                split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
+                products(b, i, pln[s & 1], 3, 6);
+                pattern(NMF / 2);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                products(b, i, pln[s & 1], 0, 6);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            products(b, i, pln[s & 1]);
-            if (s + 1 < F) {
-#pragma unroll
-                for (int k = 0; k < NMF; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-                }
+        }
+        if constexpr (XP) {
+            if (c + 1 < nk) {                      // stage st is free for the loaders; chunk c+2 has landed
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         st = st + 1 == NST ? 0 : st + 1;
     }
@@ -1991,6 +2040,11 @@ struct TileCfg {
       "x6ldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
       { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
         gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
+#define MT2_GX6LX(BM_, BN_, WM_, WN_, NL_)                                                                     \
+    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)3 * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),          \
+      "x6ldrx" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s3",                                                      \
+      { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_NONE, true>, gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_RELU, true>, \
+        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_LRELU, true>, nullptr, nullptr }, 0, true }
 #define MT2_WX6(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024),   \
       "x6win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                     \
@@ -2063,6 +2117,8 @@ static const TileCfg kCfgs[] = {
     MT2_GX6L(128, 128, 4, 2, 4, 2),  // 53: 8 + 4
     MT2_GX6L(128, 128, 4, 2, 2, 2),  // 54: 8 + 2
     MT2_GX6L(128, 128, 4, 2, 4, 3),  // 55: 8 + 4, 3-deep ring (120 KiB)
+    MT2_GX6LX(128, 128, 4, 2, 4),    // 56: the same with cross-chunk prefetch of the first fragments
+    MT2_GX6LX(128, 128, 4, 2, 2),    // 57: 8 + 2 loader waves
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 

@@ -205,7 +205,7 @@ int mt2_synthesize_batch(mt2_model* m, void* stream, const int64_t* phone, const
  * independent kernel chains on internal HIP streams that fork from and join back into `stream`; results do not
  * depend on it), "lnalg" (0: algebraic LayerNorm in the AR layers), "splitk" (1), "lnfuse" (0), "voc_streams" (3),
  * "x6_conv" (1: window convolutions on the bf16 matrix pipe in the f32-equivalent 6-product form), "x6_gemm" (1: the same for
- * the implicit-GEMM launches with enough big tiles), "x6_splitk" (1), "t_x6_256" (128), "t_x6_128" (72), "t_x6_64" (0: tile-count thresholds of
+ * the implicit-GEMM launches with enough big tiles), "x6_splitk" (1), "t_x6_256" (160), "t_x6_128" (72), "t_x6_64" (0: tile-count thresholds of
  * the two x6 tile shapes), "nt_weights" (0) / "nt_row_tiles" (2: non-temporal weight loads for launches with at most that many
  * row tiles), "win_conv" (1), "stage_markers" (0), "force_gemm_config" (-1), "lnalg_rows" (4),
  * "t_ks4", "t_ks2", "t32", "t32x32" (tile-choice thresholds).  Unknown names are an error. */

@@ -895,19 +895,24 @@ __device__ __forceinline__ void split3_bf16(const f32x4& lo, const f32x4& hi, fl
     }
 }
 
-template <int QS, int BM, int BN, int WGM, int WGN, int NST, int PRO>
-__global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
+// NL > 0: NL loader waves refill the weight ring (and help load the window); the compute waves issue no LDS-DMA in the
+// K loop (see gemm_x6_ldr_kernel).
+template <int QS, int BM, int BN, int WGM, int WGN, int NST, int PRO, int NL = 0>
+__global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x6_kernel(GemmP p) {
     constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int BPIECES = 3 * BN / 16;                  // 1-KiB pieces of one weight chunk: 3 planes x BN rows x 64 B
-    constexpr int B_IT = (BPIECES + NW - 1) / NW;
-    constexpr int STAGE_B = B_IT * NW * 1024;             // BYTES per ring stage (dummy slots included)
+    constexpr int NI = NL > 0 ? NL : NW;                  // waves that issue the ring refill
+    constexpr int B_IT = (BPIECES + NI - 1) / NI;
+    constexpr int STAGE_B = B_IT * NI * 1024;             // BYTES per ring stage (dummy slots included)
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * B_IT < 64 && BN == 32 * QS, "config");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = NL > 0 && wave_all >= NW;
+    const int wave = loader ? wave_all - NW : wave_all;   // index among the loaders / among the compute waves
     const int wm = wave / WGN, wn = wave % WGN;
     const int taps = p.taps, dil = p.dil;
     const int WR = BM + (taps - 1) * dil, WRp = (WR + 7) & ~7;
@@ -931,7 +936,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
         const int lrow = lane >> 3;
         const int ppq = WRp >> 3, pieces = QS * ppq;
         const int row_first = m0 + p.shift0;
-        for (int pc = wave; pc < pieces; pc += NW) {
+        for (int pc = wave_all; pc < pieces; pc += NW + NL) {
             const int q = pc / ppq, r8 = pc - q * ppq;
             const int row = r8 * 8 + lrow;
             const int grow = row_first + row;
@@ -948,7 +953,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
     long long wofs[B_IT];
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
-        const int pc = j * NW + wave;                    // piece = plane * (BN / 16) + row block
+        const int pc = j * NI + wave;                    // piece = plane * (BN / 16) + row block
         const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
         const int n = rb * 16 + (lane >> 2);
         const int sl = (lane & 3) ^ ((n >> 2) & 3);
@@ -960,9 +965,24 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
         for (int j = 0; j < B_IT; ++j) {
             const long long off = wofs[j] >= 0 ? wofs[j] + c * 32 : zoff_w;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
-                                             (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(Bs + j * NI * 1024), 16, 0, 0);
         }
     };
+    const int nk_l = Kt / 32;
+    if (NL > 0 && loader) {        // ---- loader wave: window pieces above, then nothing but the ring
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nk_l) issue(st, st);
+        int st = 0;
+        for (int c = 0; c < nk_l; ++c) {
+            if (c + NST - 2 < nk_l) wait_vmcnt<(NST - 2) * B_IT>();   // window pieces (older) and chunk c have landed
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (c + NST - 1 < nk_l) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+        return;
+    }
     constexpr bool PRET = TM * TN <= 2;
     EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
     if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, 0, m0 + wm * WTM, wn * WTN, lane);
@@ -975,9 +995,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
+    if constexpr (NL == 0) {
 #pragma unroll
-    for (int st = 0; st < NST - 1; ++st)
-        if (st < nk) issue(st, st);
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nk) issue(st, st);
+    } else {
+        wait_vmcnt<0>();               // this compute wave's window pieces, before the first barrier
+    }
 
     const float pro_slope = p.pro_slope;
     const int half = lane >> 5;
@@ -994,8 +1018,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
 
     int st = 0, tap = 0, q = 0;
     for (int c = 0; c < nk; ++c) {
-        if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * B_IT>();
-        else wait_vmcnt<0>();
+        if constexpr (NL == 0) {
+            if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * B_IT>();
+            else wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int arow = arow0 + tap * dil;
@@ -1003,7 +1029,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_win_x6_kernel(GemmP p) {
         const unsigned sa = lds_win + (unsigned)((q * WRp + arow) * BK) * 4;
         const unsigned sb = b_lane + (unsigned)st * STAGE_B;
         // the stage consumed in the previous iteration is free once everyone has passed the barrier: refill it first
-        if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+        if (NL == 0 && c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
         f32x4 ra[2][TM][2];
         u32x4 rb[2][3][TN];
         auto fetch = [&](int b) {
@@ -2040,6 +2066,11 @@ struct TileCfg {
       "x6ldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
       { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
         gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
+#define MT2_WX6L(QS_, BM_, BN_, WM_, WN_, NST_, NL_)                                                         \
+    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * (((3 * BN_ / 16 + NL_ - 1) / NL_) * NL_ * 1024),                 \
+      "x6winl" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                           \
+      { conv_win_x6_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_NONE, NL_>, conv_win_x6_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_RELU, NL_>, \
+        conv_win_x6_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_LRELU, NL_>, nullptr, nullptr }, QS_, true }
 #define MT2_GX6LX(BM_, BN_, WM_, WN_, NL_)                                                                     \
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)3 * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),          \
       "x6ldrx" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s3",                                                      \
@@ -2119,6 +2150,11 @@ static const TileCfg kCfgs[] = {
     MT2_GX6L(128, 128, 4, 2, 4, 3),  // 55: 8 + 4, 3-deep ring (120 KiB)
     MT2_GX6LX(128, 128, 4, 2, 4),    // 56: the same with cross-chunk prefetch of the first fragments
     MT2_GX6LX(128, 128, 4, 2, 2),    // 57: 8 + 2 loader waves
+    // v3c: x6 window convolutions with loader waves
+    MT2_WX6L(2, 256, 64, 8, 1, 3, 4),   // 58: 8 compute + 4 loader waves
+    MT2_WX6L(4, 128, 128, 4, 2, 2, 4),  // 59
+    MT2_WX6L(4, 128, 128, 4, 2, 3, 4),  // 60: 3-deep ring (72 KiB of ring + window)
+    MT2_WX6L(2, 256, 64, 8, 1, 3, 2),   // 61: 8 + 2
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 

@@ -69,7 +69,7 @@ struct EngineOpts {
     int nt_row_tiles = 2;
     int t_x6_64 = 0;             // up to this many 128x128 tiles an x6 launch uses 64x128 tiles (A through registers, 2 WG/CU):
                                  // +10 % on the isolated kernels, -1 % inside the model (profiles/r02_opts_ab.txt): off
-    int t_x6_256 = 128, t_x6_128 = 72;   // ... from this many 256x128 / 128x128 tiles on (profiles/r02_gemm_sweep_x6.txt)
+    int t_x6_256 = 160, t_x6_128 = 72;   // ... from this many 256x128 / 128x128 tiles on (profiles/r02_gemm_sweep_x6.txt)
     bool markers = false;        // a named no-op kernel at every stage boundary: lets tools/pmc_stage_summary.py attribute
                                  // the rocprofv3 --pmc rows of one step to stages (measurement only)
     bool trace_on = false;       // HIP events around every GEMM launch (measurement only)

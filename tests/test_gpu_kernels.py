@@ -190,7 +190,9 @@ def test_gemm_with_layernorm_prologue(rt, cfg, M, N, K):
 
 
 @pytest.mark.parametrize("k,dil,C,cfg", [(3, 1, 32, 34), (7, 3, 32, 34), (11, 5, 32, -1), (3, 5, 64, 35), (7, 1, 64, -1),
-                                         (11, 5, 64, 35), (3, 3, 128, 36), (7, 5, 128, -1), (11, 1, 128, 36)])
+                                         (11, 5, 64, 35), (3, 3, 128, 36), (7, 5, 128, -1), (11, 1, 128, 36),
+                                         (3, 5, 64, 58), (11, 5, 64, 58), (7, 1, 64, 61), (3, 3, 128, 59), (11, 5, 128, 59),
+                                         (7, 5, 128, 60), (11, 1, 128, 60)])
 @pytest.mark.parametrize("pro", ["none", "lrelu"])
 def test_window_conv_x6_is_f32_equivalent(rt, k, dil, C, cfg, pro):
     """The window convolution on the bf16 matrix pipe (weights as three bf16 planes, activations split in registers,

@@ -33,7 +33,7 @@ if mode == "x6":       # the bf16-pipe (f32-equivalent) configurations against t
               ("adm_qkv", 1120, 2304, 768, 1), ("adm_ff0", 2240, 1024, 768, 1), ("adm_out", 2240, 768, 768, 1),
               ("big", 4096, 4096, 4096, 1)]
 elif mode == "x6win":
-    cfgs = [30, 34, 31, 35, 32, 36]
+    cfgs = [35, 58, 61, 36, 59, 60]
     shapes = [("hifi_s4k3", 3552000, 32, 96, 3), ("hifi_s4k11", 3552000, 32, 352, 11), ("hifi_s3k3", 1776000, 64, 192, 3),
               ("hifi_s3k11", 1776000, 64, 704, 11), ("hifi_s2k3", 888000, 128, 384, 3), ("hifi_s2k7", 888000, 128, 896, 7),
               ("hifi_s2k11", 888000, 128, 1408, 11)]

@@ -2153,7 +2153,7 @@ static const TileCfg kCfgs[] = {
     // v3c: x6 window convolutions with loader waves
     MT2_WX6L(2, 256, 64, 8, 1, 3, 4),   // 58: 8 compute + 4 loader waves
     MT2_WX6L(4, 128, 128, 4, 2, 2, 4),  // 59
-    MT2_WX6L(4, 128, 128, 4, 2, 3, 4),  // 60: 3-deep ring (72 KiB of ring + window)
+    MT2_WX6L(4, 128, 128, 4, 2, 2, 2),  // 60: 8 + 2
     MT2_WX6L(2, 256, 64, 8, 1, 3, 2),   // 61: 8 + 2
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -2264,7 +2264,11 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     int bi = 12;                                                        // dma64x64_2x2_s3
     if (o.win_conv && win_eligible(p) && !(o.force_cfg >= 0 && o.force_cfg < kNumCfgs)) {
         bi = p.Cin == 32 ? 30 : (p.Cin == 64 ? 31 : 32);
-        if (o.x6_conv && p.W3) bi += 4;                                 // the bf16-pipe form of the same tile
+        if (o.x6_conv && p.W3) {
+            bi += 4;                                                    // the bf16-pipe form of the same tile
+            if (o.x6_loaders && bi == 35) bi = 58;                      // ... with loader waves (+5..14 %, sweep v2 of x6win)
+            if (o.x6_loaders && bi == 36) bi = 59;                      // (+2..6 %)
+        }
         *idx_out = bi;
         return &kCfgs[bi];
     }

@@ -24,7 +24,7 @@ if mode == "vocx":     # the vocoder's real launches: dilation, leaky-ReLU prolo
             print(f"{name} dil={dil} prologue={flags & 1} epilogue={flags >> 1}: {cn} {ms * 1e3:.1f} us {2.0 * M * N * K / ms / 1e9:.1f} TF/s", flush=True)
     sys.exit(0)
 if mode == "x6":       # the bf16-pipe (f32-equivalent) configurations against their f32 counterparts
-    cfgs = [39, 51, 55, 56, 57]
+    cfgs = [16, 37, 39, 51, 55, 56]
     shapes = [("mrte_stack", 14064, 512, 1536, 3), ("decoder", 13858, 512, 2560, 5), ("vqpe", 13858, 384, 1920, 5),
               ("hifi_s1", 111000, 256, 1792, 7), ("hifi_s1k11", 111000, 256, 2816, 11),
               ("plm_ff0", 1728, 4096, 1024, 1), ("plm_ff0", 864, 4096, 1024, 1), ("plm_ff0", 432, 4096, 1024, 1),
@@ -33,7 +33,7 @@ if mode == "x6":       # the bf16-pipe (f32-equivalent) configurations against t
               ("adm_qkv", 1120, 2304, 768, 1), ("adm_ff0", 2240, 1024, 768, 1), ("adm_out", 2240, 768, 768, 1),
               ("big", 4096, 4096, 4096, 1)]
 elif mode == "x6win":
-    cfgs = [35, 58, 61, 36, 59, 60]
+    cfgs = [34, 35, 58, 61, 36, 59, 60]
     shapes = [("hifi_s4k3", 3552000, 32, 96, 3), ("hifi_s4k11", 3552000, 32, 352, 11), ("hifi_s3k3", 1776000, 64, 192, 3),
               ("hifi_s3k11", 1776000, 64, 704, 11), ("hifi_s2k3", 888000, 128, 384, 3), ("hifi_s2k7", 888000, 128, 896, 7),
               ("hifi_s2k11", 888000, 128, 1408, 11)]

@@ -577,13 +577,24 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) koff[kk] = (unsigned)(((2 * kk + half) ^ swz) * 16);
 
+#ifdef MT2_PHASE_TIMING
+    const bool timing = p.dbg != nullptr && bid == (int)(gridDim.x / 2) && wave_all == 0;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define MT2_T(i_) do { if (timing) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i_] += t_ - tprev; tprev = t_; } } while (0)
+    if (timing) tprev = __builtin_readcyclecounter();
+#else
+#define MT2_T(i_) do { } while (0)
+#endif
     int st = 0;
     for (int rd = 0; rd < nr; ++rd) {
+        MT2_T(5);                                   // MFMA groups of the previous round
         // round rd has landed once at most NST-2 younger rounds of this wave are still in flight
         if (rd + NST - 2 < nr) wait_vmcnt<(NST - 2) * L>();
         else wait_vmcnt<0>();
+        MT2_T(0);                                   // DMA wait
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        MT2_T(1);                                   // barrier
         // first operand fetch of this round goes out BEFORE the address arithmetic of the next DMA issue, so
         // its LDS latency is covered by that VALU work instead of adding to it
         const unsigned sa = a_lane + (unsigned)st * (STAGE * 4), sb = b_lane + (unsigned)st * (STAGE * 4);
@@ -595,6 +606,7 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
         for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128(sb + koff[0] + j * 32 * BK * 4);
         if constexpr (LNP) { fg[0] = lds_read_b128(sg); fbt[0] = lds_read_b128(sg + 128); }
         if (rd + NST - 1 < nr) issue(rd + NST - 1, st == 0 ? NST - 1 : st - 1);
+        MT2_T(2);                                   // first fragment reads issued + refill issue (drains those reads)
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
             const int cur = kk & 1, nxt = cur ^ 1;
@@ -635,6 +647,15 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
         }
         st = st + 1 == NST ? 0 : st + 1;
     }
+#ifdef MT2_PHASE_TIMING
+    MT2_T(5);
+    if (timing && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p.dbg[i] = tacc[i];
+        p.dbg[6] = (unsigned long long)nr;
+    }
+#endif
+#undef MT2_T
     // LN-A correction of an accumulator element of row r (tile-local), column n: rstd_r * (acc - mean_r * s_n)
     auto lna_fix = [&](float acc_v, int row_local, float s_n) {
         const float* stat = smem + KS * NST * STAGE;

@@ -132,7 +132,7 @@ probe_x6)
 phase)
   # instrumented build in a scratch copy of the package (the in-tree library stays the production one)
   rm -rf /tmp/mt2_phase && mkdir -p /tmp/mt2_phase && cp -r megatts2_amd include tools /tmp/mt2_phase/
-  (cd /tmp/mt2_phase && rm -rf megatts2_amd/lib && MT2_EXTRA_HIPCC_FLAGS=-DMT2_PHASE_TIMING python -m megatts2_amd.build > $GRAFT_REPO_ROOT/gpurun_out/build_phase.log 2>&1 && MT2_EXTRA_HIPCC_FLAGS=-DMT2_PHASE_TIMING timeout 300 python tools/x6_phase_timing.py) > gpurun_out/x6_phase_timing.txt 2>&1
+  (cd /tmp/mt2_phase && rm -rf megatts2_amd/lib && MT2_EXTRA_HIPCC_FLAGS=-DMT2_PHASE_TIMING python -m megatts2_amd.build > $GRAFT_REPO_ROOT/gpurun_out/build_phase.log 2>&1 && MT2_EXTRA_HIPCC_FLAGS=-DMT2_PHASE_TIMING timeout 300 python tools/x6_phase_timing.py $PHASE_ARGS) > gpurun_out/x6_phase_timing.txt 2>&1
   echo "phase rc=$?"; grep -v amdgpu.ids gpurun_out/x6_phase_timing.txt ;;
 splitk)
   for w in C2 C3; do for f in "" "--no-splitk"; do

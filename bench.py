@@ -338,8 +338,8 @@ def main() -> None:
                               "launches_per_step": ge["launches"], "source": os.path.relpath(pmc_path, ROOT)}
         result["roofline"] = {
             "bound": "mfma",
-            "kernel": "gemm_x6_dma_kernel / conv_win_x6_kernel (implicit-GEMM conv/linear engine on the bf16 matrix pipe, "
-                      "f32-equivalent) + gemm_f32_dma_kernel (f32 MFMA) for the latency-bound AR launches",
+            "kernel": "gemm_x6_ldr_kernel / conv_win_x6_kernel (implicit-GEMM conv/linear engine on the bf16 matrix pipe, "
+                      "f32-equivalent, loader waves) + gemm_f32_dma_kernel (f32 MFMA) for the latency-bound AR launches",
             "achieved": round(achieved, 2), "peak": round(X6_EQUIV_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
             "frac": round(achieved / X6_EQUIV_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
             "method": "achieved = algorithmic GEMM FLOPs of the step (SURVEY 8d, reference semantics, f32 multiply-adds) / "

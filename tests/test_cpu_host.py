@@ -23,6 +23,25 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.mt2_version()
 
 
+def test_tile_configuration_table_matches_the_indices_the_chooser_uses():
+    """choose_cfg (gemm_f32.hip) and the kernel tests address tile configurations by table index: pin index -> name, so
+    that inserting a configuration in the middle of the table cannot silently re-route launches (no GPU needed)."""
+    from megatts2_amd.build import build
+    lib = ctypes.CDLL(build(verbose=False))
+    lib.mt2_gemm_config_name.restype = ctypes.c_char_p
+    n = lib.mt2_gemm_config_count()
+    names = [lib.mt2_gemm_config_name(i).decode() for i in range(n)]
+    assert len(set(names)) == n, "duplicate tile configuration names"
+    want = {12: "dma64x64_2x2_s3", 15: "dma128x32_4x1_s4", 16: "dma256x128_4x2_s3", 17: "dma128x128_4x2_s4",
+            18: "dma64x64_2x2_k2_s2", 20: "dma64x64_2x2_k4_s2", 22: "dma32x64_1x2_k4_s2", 23: "dma256x64_4x2_s3",
+            28: "dma32x32_1x1_k8_s2", 30: "win256x32_8x1_s3", 31: "win256x64_8x1_s3", 32: "win128x128_4x2_s3",
+            34: "x6win256x32_8x1_s3", 35: "x6win256x64_8x1_s3", 36: "x6win128x128_4x2_s2", 37: "x6dma256x128_4x2_s2",
+            39: "x6dma128x128_4x2_s2", 49: "x6areg64x128_2x2_s3", 51: "x6ldr256x128_4x2+4_s2",
+            55: "x6ldr128x128_4x2+4_s3", 58: "x6winl256x64_8x1+4_s3", 59: "x6winl128x128_4x2+4_s2"}
+    for i, name in want.items():
+        assert names[i] == name, (i, names[i], name)
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -1955,6 +1955,14 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
             __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
         }
     };
+#ifdef MT2_PHASE_TIMING
+    const bool timing = p.dbg != nullptr && bid == (int)(gridDim.x / 2) && wave == 0;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+#define MT2_T(i_) do { if (timing) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i_] += t_ - tprev; tprev = t_; } } while (0)
+    if (timing) tprev = __builtin_readcyclecounter();
+#else
+#define MT2_T(i_) do { } while (0)
+#endif
     if constexpr (XP) {       // first fragments of chunk 0 (the only exposed fetch + split)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1969,15 +1977,19 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
         const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
         const int stn = st + 1 == NST ? 0 : st + 1;
         if constexpr (!XP) {
+            MT2_T(5);                               // MFMA steps of the previous chunk
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            MT2_T(1);                               // barrier (loaders' landing wait included)
             fetch(0, sa, sb);
             __builtin_amdgcn_sched_barrier(0);
             wait_block(0);
             __builtin_amdgcn_sched_barrier(0);
+            MT2_T(3);                               // first fragment fetch
             fetch(1, sa, sb);
             split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
             __builtin_amdgcn_sched_barrier(0);
+            MT2_T(4);                               // second fetch + first split
         } else {
             fetch(1, sa, sb);
             __builtin_amdgcn_sched_barrier(0);
@@ -2025,6 +2037,15 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
         }
         st = st + 1 == NST ? 0 : st + 1;
     }
+#ifdef MT2_PHASE_TIMING
+    MT2_T(5);
+    if (timing && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) p.dbg[i] = tacc[i];
+        p.dbg[6] = (unsigned long long)nk;
+    }
+#endif
+#undef MT2_T
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 }

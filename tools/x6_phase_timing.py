@@ -9,7 +9,10 @@ rt.device_check()
 CASES_F32 = [("adm_qkv", 256, 2304, 768, 1, 22), ("adm_qkv", 512, 2304, 768, 1, 20), ("plm_qkv", 256, 3072, 1024, 1, 22),
              ("plm_qkv", 400, 3072, 1024, 1, 20), ("plm_ff1", 400, 1024, 4096, 1, 20), ("plm_qkv", 32, 3072, 1024, 1, 28),
              ("adm_qkv", 1120, 2304, 768, 1, 55), ("plm_ff0", 864, 4096, 1024, 1, 55)]
-for name, M, N, K, taps, cfg in CASES_F32 if len(sys.argv) > 1 and sys.argv[1] == "f32" else [("big", 4096, 4096, 4096, 1, 37), ("big", 4096, 4096, 4096, 1, 39), ("big", 4096, 4096, 4096, 1, 42),
+CASES_LDR = [("big", 4096, 4096, 4096, 1, 51), ("big", 4096, 4096, 4096, 1, 55), ("decoder", 13858, 512, 2560, 5, 51),
+             ("plm_ff0", 864, 4096, 1024, 1, 55), ("plm_qkv", 864, 3072, 1024, 1, 55), ("adm_out", 2240, 768, 768, 1, 55)]
+MODE = sys.argv[1] if len(sys.argv) > 1 else ""
+for name, M, N, K, taps, cfg in CASES_F32 if MODE == "f32" else CASES_LDR if MODE == "ldr" else [("big", 4096, 4096, 4096, 1, 37), ("big", 4096, 4096, 4096, 1, 39), ("big", 4096, 4096, 4096, 1, 42),
                                  ("decoder", 13858, 512, 2560, 5, 37), ("plm_ff0", 1728, 4096, 1024, 1, 37),
                                  ("plm_ff0", 864, 4096, 1024, 1, 39), ("plm_qkv", 864, 3072, 1024, 1, 39)]:
     ms, cn = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=4, w_copies=2, flags=4)

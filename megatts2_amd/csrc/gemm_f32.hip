@@ -2050,6 +2050,254 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 }
 
+// ===================================================================================================
+// v2e: the loader-wave x6 kernel with the two halves of the compute waves DE-PHASED (128x128 tile, 3-deep ring).
+template <int BM, int BN, int WGM, int WGN, int NL, int PRO>
+__global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldrd_kernel(GemmP p) {
+    constexpr int NST = 3;
+    constexpr bool XP = false;
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int PA = BM / 8;                            // f32 A pieces per chunk: 8 rows x 128 B
+    constexpr int PB = 3 * BN / 16;                       // bf16 plane pieces per chunk: 16 rows x 64 B
+    constexpr int A_IT = (PA + NL - 1) / NL, B_IT = (PB + NL - 1) / NL;   // per loader wave
+    constexpr int L = A_IT + B_IT;
+    constexpr int STAGE_A = BM * BK * 4, STAGE_B = PB * 1024, STAGE = STAGE_A + STAGE_B;   // bytes
+    static_assert(PA % NL == 0 && PB % NL == 0 && WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64 &&
+                  TM * TN > 1, "config");
+    static_assert(TM == 1 && NW == 8, "de-phased variant: one row tile per wave, two groups of four waves");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* ring = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.z;
+
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const bool nmajor = p.M < p.N;
+    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
+    const int Kt = p.K;
+    const int nk = (Kt + BK - 1) / BK;
+
+    if (wave_all >= NW) {
+        // ------------------------------------------------------------------ loader wave lw: pieces lw, lw + NL, ...
+        const int lw = wave_all - NW;
+        const float* __restrict__ X = p.X + (long long)g * p.strideX;
+        const unsigned short* __restrict__ W3 = reinterpret_cast<const unsigned short*>(p.W3) + (long long)g * p.strideW;
+        const long long zoff_x = (const float*)g_zero16 - X;
+        const long long zoff_w = (const unsigned short*)g_zero16 - W3;
+        const long long plane = p.w3_plane;
+        const int lrow = lane >> 3;
+        const int ldx = p.ldx, Rx = p.Rx, Cin = p.Cin, dil = p.dil, ldw = p.ldw;
+        const bool multi_tap = p.taps > 1;
+        int abase[A_IT], akl[A_IT];
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            const int pc = j * NL + lw;                      // A piece: rows pc*8 .. pc*8+7
+            const int m = m0 + pc * 8 + lrow;
+            int b = kInvalidRow;
+            if (m < p.M) b = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
+            abase[j] = b;
+            akl[j] = ((lane & 7) ^ ((pc * 4 + (lane >> 4)) & 7)) * 4;       // k offset of this lane's 16-byte slot
+        }
+        long long wofs[B_IT];
+        int wk[B_IT];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const int pc = j * NL + lw;                      // B piece = plane * (BN / 16) + row block
+            const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
+            const int nl = rb * 16 + (lane >> 2);
+            const int n = n0 + nl;
+            wk[j] = ((lane & 3) ^ ((nl >> 2) & 3)) * 8;
+            wofs[j] = n < p.N ? pl * plane + (long long)n * ldw : -1;
+        }
+        wait_vmcnt<0>();                                     // the rowbase loads
+        const bool fast = (Kt % BK == 0) && (!multi_tap || Cin % BK == 0);
+        int s_tap = 0, s_cc = 0;
+        auto issue = [&](int c, int st) {
+            const int kchunk = c * BK;
+            float* As = reinterpret_cast<float*>(ring + st * STAGE) + lw * 256;
+            char* Bs = ring + st * STAGE + STAGE_A + lw * 1024;
+            if (fast) {
+                const int dsrc = s_tap * dil;
+#pragma unroll
+                for (int j = 0; j < A_IT; ++j) {
+                    const int src = abase[j] + dsrc;
+                    const long long off = (unsigned)src < (unsigned)Rx ? (long long)src * ldx + (s_cc + akl[j]) : zoff_x;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                                     (__attribute__((address_space(3))) void*)(As + j * NL * 256), 16, 0, 0);
+                }
+#pragma unroll
+                for (int j = 0; j < B_IT; ++j) {
+                    const long long off = wofs[j] >= 0 ? wofs[j] + (kchunk + wk[j]) : zoff_w;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                                     (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16, 0, 0);
+                }
+                s_cc += BK;
+                if (multi_tap && s_cc == Cin) { s_cc = 0; ++s_tap; }
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < A_IT; ++j) {
+                const int k = kchunk + akl[j];
+                int tap = 0, cc = k;
+                if (multi_tap) { tap = k / Cin; cc = k - tap * Cin; }
+                const int src = abase[j] + tap * dil;
+                const bool ok = (k < Kt) & ((unsigned)src < (unsigned)Rx);
+                const long long off = ok ? (long long)src * ldx + cc : zoff_x;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                                 (__attribute__((address_space(3))) void*)(As + j * NL * 256), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < B_IT; ++j) {
+                const int k = kchunk + wk[j];
+                const bool ok = (k < Kt) & (wofs[j] >= 0);
+                const long long off = ok ? wofs[j] + k : zoff_w;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
+                                                 (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < NST; ++st)
+            if (st < nk) issue(st, st);
+        // barriers B_0 .. B_{2 nk}: group A reads chunk c from LDS in [B_2c, B_2c+1) and multiplies in [B_2c+1, B_2c+2),
+        // group B reads it in [B_2c+1, B_2c+2) and multiplies in [B_2c+2, B_2c+3); the stage of chunk c is free after
+        // B_2c+2 and receives chunk c+3, which must have landed before B_2c+6 (two chunk periods of flight)
+        for (int j = 0; j <= 2 * nk; ++j) {
+            const bool even = (j & 1) == 0;
+            if (even && (j >> 1) < nk) {
+                if ((j >> 1) + 1 < nk) wait_vmcnt<L>();              // chunk j/2 landed (chunk j/2+1 may be in flight)
+                else wait_vmcnt<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+            if (even && j >= 2) {
+                const int cn = (j >> 1) + 2;
+                if (cn < nk) issue(cn, cn % NST);
+            }
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute wave
+    const int wave = wave_all;
+    const int wm = wave / WGN, wn = wave % WGN;
+    constexpr bool PRET = TM * TN <= 2;
+    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
+    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const float pro_slope = p.pro_slope;
+    const int half = lane >> 5;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
+    const int swza = (lane >> 1) & 7;
+    const unsigned a_lane = lds0 + ((wm * WTM + (lane & 31)) * BK) * 4;
+    const int nrow = wn * WTN + (lane & 31);
+    const int swzb = (nrow >> 2) & 3;
+    const unsigned b_lane = lds0 + STAGE_A + nrow * 64;
+    unsigned koffa[2][2], koffb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        koffa[b][0] = (unsigned)(((b * 4 + half * 2) ^ swza) * 16);
+        koffa[b][1] = (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
+        koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+    }
+
+    int st = 0;
+    f32x4 ra[2][TM][2];
+    u32x4 rb[2][3][TN];
+    u32x4 pln[2][3];
+    constexpr int F = 2 * TM, NMF = 6 * TN, VPM = (44 + NMF - 1) / NMF;
+    auto fetch = [&](int b, unsigned sa, unsigned sb) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ra[b][i][0] = lds_read_b128(sa + koffa[b][0] + i * 32 * BK * 4);
+            ra[b][i][1] = lds_read_b128(sa + koffa[b][1] + i * 32 * BK * 4);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
+                rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
+            }
+    };
+    // products t0 <= t < t1 of fragment (b, i) with the column tiles of k-block b
+    auto products = [&](int b, int i, const u32x4* pp, int t0, int t1) {
+        const bf16x8 A1 = __builtin_bit_cast(bf16x8, pp[0]), A2 = __builtin_bit_cast(bf16x8, pp[1]),
+                     A3 = __builtin_bit_cast(bf16x8, pp[2]);
+        constexpr int PA_[6] = {3, 1, 2, 2, 1, 1}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            if (t < t0 || t >= t1) continue;
+            const bf16x8 At = PA_[t] == 1 ? A1 : (PA_[t] == 2 ? A2 : A3);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB_[t]][j]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
+    auto wait_block = [&](int b) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) tie(b, i);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
+    };
+    auto pattern = [&](int nmf) {
+#pragma unroll
+        for (int k = 0; k < NMF; ++k) {
+            if (k >= nmf) break;
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        }
+    };
+    // Two groups of four compute waves, half a chunk out of phase: the waves w and w + 4 share a SIMD, and in every
+    // barrier interval one of them fetches and splits its chunk's fragments (vector pipe, LDS) while the other issues its
+    // 24 MFMAs (matrix pipe) - the serial phase of a chunk (17-25 % of it with both waves in lockstep,
+    // profiles/r02_x6_phase_timing.txt) runs beside the partner's products.
+    const int grp = wave >> 2;
+    if (grp == 1) __builtin_amdgcn_s_barrier();        // B_0: group B starts one interval later
+    for (int c = 0; c < nk; ++c) {
+        __builtin_amdgcn_s_barrier();                  // A: B_2c, B: B_2c+1 - chunk c is in LDS
+        asm volatile("" ::: "memory");
+        const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
+        fetch(0, sa, sb);
+        fetch(1, sa, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_block(0);
+        wait_block(1);
+        __builtin_amdgcn_sched_barrier(0);
+        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
+        split3_bf16<PRO>(ra[1][0][0], ra[1][0][1], pro_slope, pln[1][0], pln[1][1], pln[1][2]);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                  // A: B_2c+1, B: B_2c+2 - the partner group starts its fetch
+        __builtin_amdgcn_sched_barrier(0);
+        products(0, 0, pln[0], 0, 6);
+        products(1, 0, pln[1], 0, 6);
+        __builtin_amdgcn_sched_barrier(0);
+        st = st + 1 == NST ? 0 : st + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();        // B_2nk
+    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+}
+
+
 // ---------------------------------------------------------------------------------------------------
 // host side: tile-configuration choice and launch
 
@@ -2118,6 +2366,11 @@ struct TileCfg {
       "x6ldrx" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s3",                                                      \
       { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_NONE, true>, gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_RELU, true>, \
         gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_LRELU, true>, nullptr, nullptr }, 0, true }
+#define MT2_GX6LD(BM_, BN_, WM_, WN_, NL_)                                                                     \
+    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)3 * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),          \
+      "x6ldrd" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s3",                                                      \
+      { gemm_x6_ldrd_kernel<BM_, BN_, WM_, WN_, NL_, ACT_NONE>, gemm_x6_ldrd_kernel<BM_, BN_, WM_, WN_, NL_, ACT_RELU>, \
+        gemm_x6_ldrd_kernel<BM_, BN_, WM_, WN_, NL_, ACT_LRELU>, nullptr, nullptr }, 0, true }
 #define MT2_WX6(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024),   \
       "x6win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                     \
@@ -2197,6 +2450,8 @@ static const TileCfg kCfgs[] = {
     MT2_WX6L(4, 128, 128, 4, 2, 2, 4),  // 59
     MT2_WX6L(4, 128, 128, 4, 2, 2, 2),  // 60: 8 + 2
     MT2_WX6L(2, 256, 64, 8, 1, 3, 2),   // 61: 8 + 2
+    // v2e: loader waves + de-phased compute groups
+    MT2_GX6LD(128, 128, 4, 2, 4),       // 62
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 

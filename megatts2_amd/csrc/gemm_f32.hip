@@ -2055,7 +2055,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
 template <int BM, int BN, int WGM, int WGN, int NL, int PRO>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldrd_kernel(GemmP p) {
     constexpr int NST = 3;
-    constexpr bool XP = false;
     constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -2217,7 +2216,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldrd_kernel(Gem
     f32x4 ra[2][TM][2];
     u32x4 rb[2][3][TN];
     u32x4 pln[2][3];
-    constexpr int F = 2 * TM, NMF = 6 * TN, VPM = (44 + NMF - 1) / NMF;
     auto fetch = [&](int b, unsigned sa, unsigned sb) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -2257,14 +2255,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldrd_kernel(Gem
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
             for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
-    };
-    auto pattern = [&](int nmf) {
-#pragma unroll
-        for (int k = 0; k < NMF; ++k) {
-            if (k >= nmf) break;
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-        }
     };
     // Two groups of four compute waves, half a chunk out of phase: the waves w and w + 4 share a SIMD, and in every
     // barrier interval one of them fetches and splits its chunk's fragments (vector pipe, LDS) while the other issues its

@@ -24,7 +24,7 @@ if mode == "vocx":     # the vocoder's real launches: dilation, leaky-ReLU prolo
             print(f"{name} dil={dil} prologue={flags & 1} epilogue={flags >> 1}: {cn} {ms * 1e3:.1f} us {2.0 * M * N * K / ms / 1e9:.1f} TF/s", flush=True)
     sys.exit(0)
 if mode == "x6":       # the bf16-pipe (f32-equivalent) configurations against their f32 counterparts
-    cfgs = [55, 62]
+    cfgs = [16, 37, 39, 51, 55, 62]
     shapes = [("mrte_stack", 14064, 512, 1536, 3), ("decoder", 13858, 512, 2560, 5), ("vqpe", 13858, 384, 1920, 5),
               ("hifi_s1", 111000, 256, 1792, 7), ("hifi_s1k11", 111000, 256, 2816, 11),
               ("plm_ff0", 1728, 4096, 1024, 1), ("plm_ff0", 864, 4096, 1024, 1), ("plm_ff0", 432, 4096, 1024, 1),

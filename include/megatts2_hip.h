@@ -258,9 +258,11 @@ int mt2_gemm_config_count(void);
 const char* mt2_gemm_config_name(int idx);
 /* time `iters` back-to-back launches of one GEMM / conv (taps, dilation) with HIP events on `stream`, cycling
  * through `w_copies` copies of the weight matrix (> 1: weights are not L2-resident from the previous launch);
- * flags bit0: leaky-ReLU prologue, bit1: bias + residual + row-mask epilogue; average ms */
+ * flags bit0: leaky-ReLU prologue, bit1: bias + residual + row-mask epilogue, bit2: clock probe - one wave of the
+ * loader-wave x6 kernel reads s_memtime and s_memrealtime around its K loop; `sustained_ghz` (nullable) receives the
+ * shader clock that launch ran at (0 when the configuration has no probe), bit3: no stderr report; average ms */
 int mt2_bench_gemm(void* stream, int M, int N, int K, int taps, int dil, int flags, int force_cfg, int iters,
-                   int w_copies, float* avg_ms, char* cfg_name, int cfg_name_cap);
+                   int w_copies, float* avg_ms, char* cfg_name, int cfg_name_cap, double* sustained_ghz);
 
 #ifdef __cplusplus
 }

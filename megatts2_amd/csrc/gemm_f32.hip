@@ -579,9 +579,12 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
 
 #ifdef MT2_PHASE_TIMING
     const bool timing = p.dbg != nullptr && bid == (int)(gridDim.x / 2) && wave_all == 0;
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, treal0 = 0, tcyc0 = 0;
 #define MT2_T(i_) do { if (timing) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i_] += t_ - tprev; tprev = t_; } } while (0)
-    if (timing) tprev = __builtin_readcyclecounter();
+    if (timing) {
+        treal0 = __builtin_amdgcn_s_memrealtime();
+        tcyc0 = tprev = __builtin_readcyclecounter();
+    }
 #else
 #define MT2_T(i_) do { } while (0)
 #endif
@@ -653,6 +656,8 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
 #pragma unroll
         for (int i = 0; i < 6; ++i) p.dbg[i] = tacc[i];
         p.dbg[6] = (unsigned long long)nr;
+        p.dbg[7] = __builtin_amdgcn_s_memrealtime() - treal0;
+        p.dbg[8] = __builtin_readcyclecounter() - tcyc0;
     }
 #endif
 #undef MT2_T
@@ -902,6 +907,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int PRO>
 __device__ __forceinline__ void split3_bf16(const f32x4& lo, const f32x4& hi, float slope, u32x4& p1, u32x4& p2, u32x4& p3) {
+#if defined(MT2_ABLATE) && MT2_ABLATE == 3     // ablation: no split arithmetic (wrong numbers, same MFMA / LDS / DMA work)
+    p1 = __builtin_bit_cast(u32x4, lo); p2 = __builtin_bit_cast(u32x4, hi); p3 = p1;
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float x = apply_act<PRO>(i < 2 ? lo[2 * i] : hi[2 * i - 4], slope);
@@ -1865,7 +1874,11 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
             if (!XP && c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();   // this wave's pieces of chunk c have landed
             else wait_vmcnt<0>();                                        // XP: of chunk c+1 as well
             __builtin_amdgcn_s_barrier();                            // chunk c complete; chunk c-1's stage is free
+#if defined(MT2_ABLATE) && MT2_ABLATE == 2                           // ablation: no operand ingest inside the K loop
+            if (c + NST - 1 < nk && c < 1) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+#else
             if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+#endif
             st = st + 1 == NST ? 0 : st + 1;
         }
         return;
@@ -1933,6 +1946,11 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB_[t]][j]);
+#if defined(MT2_ABLATE) && MT2_ABLATE == 4     // ablation: fetch + split, no matrix instructions (operands kept live)
+                asm volatile("" :: "v"(At), "v"(Bt));
+                if (Kt < 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
+                continue;
+#endif
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
             }
         }
@@ -1957,11 +1975,22 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     };
 #ifdef MT2_PHASE_TIMING
     const bool timing = p.dbg != nullptr && bid == (int)(gridDim.x / 2) && wave == 0;
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, treal0 = 0, tcyc0 = 0;
 #define MT2_T(i_) do { if (timing) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i_] += t_ - tprev; tprev = t_; } } while (0)
-    if (timing) tprev = __builtin_readcyclecounter();
+    if (timing) {
+        treal0 = __builtin_amdgcn_s_memrealtime();      // constant-rate counter (hipDeviceAttributeWallClockRate): the
+        tcyc0 = tprev = __builtin_readcyclecounter();   // ratio to s_memtime is the shader clock the K loop ran at
+    }
 #else
 #define MT2_T(i_) do { } while (0)
+    // clock probe (always built, two scalar reads when requested): shader cycles (s_memtime) and constant-rate ticks
+    // (s_memrealtime) across the whole K loop of one wave -> the clock the matrix pipe actually sustained (bench.py)
+    const bool probe = p.dbg != nullptr && bid == (int)(gridDim.x / 2) && wave == 0;
+    unsigned long long treal0 = 0, tcyc0 = 0;
+    if (probe) {
+        treal0 = __builtin_amdgcn_s_memrealtime();
+        tcyc0 = __builtin_readcyclecounter();
+    }
 #endif
     if constexpr (XP) {       // first fragments of chunk 0 (the only exposed fetch + split)
         __builtin_amdgcn_s_barrier();
@@ -1976,6 +2005,13 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     for (int c = 0; c < nk; ++c) {
         const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
         const int stn = st + 1 == NST ? 0 : st + 1;
+#if defined(MT2_ABLATE) && MT2_ABLATE == 1                                   // ablation: ingest only - the compute waves just
+        if (c + 1 < nk) {                                                    // keep the barrier cadence (the last chunk runs the
+            __builtin_amdgcn_s_barrier();                                    // real body so that the accumulators stay live)
+            st = stn;
+            continue;
+        }
+#endif
         if constexpr (!XP) {
             MT2_T(5);                               // MFMA steps of the previous chunk
             __builtin_amdgcn_s_barrier();
@@ -2043,6 +2079,14 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
 #pragma unroll
         for (int i = 0; i < 6; ++i) p.dbg[i] = tacc[i];
         p.dbg[6] = (unsigned long long)nk;
+        p.dbg[7] = __builtin_amdgcn_s_memrealtime() - treal0;
+        p.dbg[8] = __builtin_readcyclecounter() - tcyc0;
+    }
+#else
+    if (probe && lane == 0) {
+        p.dbg[6] = (unsigned long long)nk;
+        p.dbg[7] = __builtin_amdgcn_s_memrealtime() - treal0;
+        p.dbg[8] = __builtin_readcyclecounter() - tcyc0;
     }
 #endif
 #undef MT2_T

@@ -546,41 +546,70 @@ static void ensure_aux(mt2_model& m, int n_streams) {
     }
 }
 
-// Range check of caller-supplied indices BEFORE they are used as gather offsets: the reference raises IndexError
-// from nn.Embedding / F.embedding (modules/embedding.py:43-47, core_vq.py:188-190); here an out-of-range id would
-// read HBM out of bounds.  One tiny kernel per id tensor ORs a bit into a device flag; ids_finish copies the flag
-// to the host and synchronises the stream ONCE per API call (the call has enqueued nothing else yet).
+// Range check of caller-supplied gather indices: the reference raises IndexError from nn.Embedding / F.embedding
+// (modules/embedding.py:43-47, core_vq.py:188-190).  Here every gather kernel CLAMPS the id into its table (never an
+// out-of-bounds read), and a tiny kernel per id tensor ORs a bit into a device flag.  The checks depend on the call's
+// INPUTS only, so they run on the handle's own id stream, forked from the caller's stream at the first check of the
+// call; the verdict (ids_verdict) is read at the END of the API call - a host wait for the id stream only, i.e. for
+// what was queued on the caller's stream BEFORE this call, never for the call's own kernels.  A server can therefore
+// enqueue batch k+1 behind batch k; the error still comes back from the call that carried the bad id.
 enum IdBit { ID_PHONE = 1, ID_CODE = 2, ID_PREFIX = 4 };
-struct IdCheck { int* flag = nullptr; };
-static IdCheck ids_begin(const Ctx& c) {
-    IdCheck k;
-    k.flag = c.ws.get<int>(4);
-    MT2_HIP(hipMemsetAsync(k.flag, 0, 4 * sizeof(int), c.s));
-    return k;
+static void ids_begin(const Ctx& c) {
+    mt2_model& m = c.m;
+    if (m.id_open) return;
+    if (!m.id_stream) {
+        MT2_HIP(hipStreamCreateWithFlags(&m.id_stream, hipStreamNonBlocking));
+        MT2_HIP(hipEventCreateWithFlags(&m.ev_id_fork, hipEventDisableTiming));
+        MT2_HIP(hipEventCreateWithFlags(&m.ev_id_done, hipEventDisableTiming));
+        MT2_HIP(hipMalloc((void**)&m.id_flag_dev, 4 * sizeof(int)));
+        MT2_HIP(hipHostMalloc((void**)&m.id_flag_host, 4 * sizeof(int), hipHostMallocDefault));
+    }
+    MT2_HIP(hipEventRecord(m.ev_id_fork, c.s));                  // the ids may be produced by earlier work on c.s
+    MT2_HIP(hipStreamWaitEvent(m.id_stream, m.ev_id_fork, 0));
+    MT2_HIP(hipMemsetAsync(m.id_flag_dev, 0, 4 * sizeof(int), m.id_stream));
+    m.id_open = true;
 }
-static void ids_check(const Ctx& c, const IdCheck& k, const int64_t* ids, const int* map, long long R, long long hi,
-                      int bit) {
+// ids[map[r]] for r < R with map[r] >= 0 (map == nullptr: ids[r]); `map` is a HOST array, uploaded on the id stream
+static void ids_check(const Ctx& c, const int64_t* ids, const std::vector<int>* map, long long R, long long hi, int bit) {
     MT2_REQUIRE(R < (1ll << 31), "id tensor too large");
-    MT2_HIP(launch_check_ids(ids, map, (int)R, hi, k.flag, bit, c.s));
+    if (R <= 0) return;
+    ids_begin(c);
+    const int* dmap = nullptr;
+    if (map) {
+        MT2_REQUIRE((long long)map->size() >= R, "id map shorter than the id range");
+        int* hm = static_cast<int*>(c.m.pinned().alloc((size_t)R * sizeof(int)));
+        std::memcpy(hm, map->data(), (size_t)R * sizeof(int));
+        int* dm = c.ws.get<int>((size_t)R);
+        MT2_HIP(hipMemcpyAsync(dm, hm, (size_t)R * sizeof(int), hipMemcpyHostToDevice, c.m.id_stream));
+        dmap = dm;
+    }
+    MT2_HIP(launch_check_ids(ids, dmap, (int)R, hi, c.m.id_flag_dev, bit, c.m.id_stream));
 }
-static void ids_finish(const Ctx& c, const IdCheck& k) {
-    int* h = static_cast<int*>(c.m.pinned().alloc(sizeof(int)));
-    *h = 0;
-    MT2_HIP(hipMemcpyAsync(h, k.flag, sizeof(int), hipMemcpyDeviceToHost, c.s));
-    MT2_HIP(hipStreamSynchronize(c.s));
-    if (*h == 0) return;
+// end of the API call (also on its error paths, without throwing: CallScope): wait for the id stream, read the flag
+static int ids_wait(mt2_model& m) {
+    if (!m.id_open) return 0;
+    m.id_open = false;
+    *m.id_flag_host = 0;
+    if (hipMemcpyAsync(m.id_flag_host, m.id_flag_dev, sizeof(int), hipMemcpyDeviceToHost, m.id_stream) != hipSuccess) return -1;
+    if (hipEventRecord(m.ev_id_done, m.id_stream) != hipSuccess) return -1;
+    if (hipEventSynchronize(m.ev_id_done) != hipSuccess) return -1;
+    return *m.id_flag_host;
+}
+static void ids_verdict(const Ctx& c) {
+    const int f = ids_wait(c.m);
+    MT2_REQUIRE(f >= 0, "id range check could not be read back");
+    if (f == 0) return;
     std::string what = "index out of range in embedding lookup:";
-    if (*h & ID_PHONE) what += " phone id >= phone_vocab_size (or negative);";
-    if (*h & ID_CODE) what += " prosody code >= vq_bins (or negative);";
-    if (*h & ID_PREFIX) what += " prompt prosody code >= vq_bins + 2 (or negative);";
+    if (f & ID_PHONE) what += " phone id >= phone_vocab_size (or negative);";
+    if (f & ID_CODE) what += " prosody code >= vq_bins (or negative);";
+    if (f & ID_PREFIX) what += " prompt prosody code >= vq_bins + 2 (or negative);";
     throw Error(what);
 }
 
 // MRTE.tc_latent (modules/mrte.py:154-171) -> packed rows [P.R, hidden] (gap rows zero)
 struct TcResult { float* rows; RowSet P; };
 static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* phone_lens, int Np_max,
-                               const float* mel, const int* mel_lens, int Tp_max, int B,
-                               const IdCheck* pending = nullptr) {
+                               const float* mel, const int* mel_lens, int Tp_max, int B) {
     mt2_model& m = c.m;
     const mt2_config& cfg = m.cfg;
     const int H = cfg.mrte_hidden;
@@ -589,7 +618,10 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
     RowSet P = make_rows(phone_lens, B, 2);
     MT2_REQUIRE(P.maxlen <= cfg.max_positions, "phone sequence longer than the positional table");
     RowPlanOffsets oP = plan_rows(ip, P);
-    const int o_idmap = plan_rowmap(ip, P, Np_max);
+    std::vector<int> idmap(P.R, -1);                 // row -> index into the padded [B, Np_max] id tensor (gap rows: -1)
+    for (int b = 0; b < B; ++b)
+        for (int t = 0; t < P.len[b]; ++t) idmap[P.off[b] + t] = b * Np_max + t;
+    const int o_idmap = ip.add(idmap);
     std::vector<int> pos(P.R, 0);
     for (int b = 0; b < B; ++b) {
         MT2_REQUIRE(phone_lens[b] >= 1 && phone_lens[b] <= Np_max, "phone length out of range");
@@ -600,11 +632,8 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
     bind_rows(ip, mp.oF, mp.F);
     bind_rows(ip, mp.oX, mp.X);
     bind_rows(ip, oP, P);
-    {   // phone ids index the embedding table: check them (and whatever the caller queued) before anything runs
-        const IdCheck k = pending ? *pending : ids_begin(c);
-        ids_check(c, k, phone, ip.dev(o_idmap), P.R, cfg.phone_vocab, ID_PHONE);
-        ids_finish(c, k);
-    }
+    // phone ids index the embedding table: range check on the id stream (verdict at the end of the API call)
+    ids_check(c, phone, &idmap, P.R, cfg.phone_vocab, ID_PHONE);
 
     // The phone branch (embedding, conv-FF transformer, query projection: ~60 small launches) does not depend on
     // the mel encoder: it runs on a side stream and fills the CUs the mel stack's big launches leave idle
@@ -612,6 +641,7 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
     ensure_aux(m, 1);
     hipStream_t side = m.aux_streams[0];
     MT2_HIP(hipEventRecord(m.ev_fork, c.s));
+    m.aux_forked = true;
     MT2_HIP(hipStreamWaitEvent(side, m.ev_fork, 0));
     const Ctx cp{m, side, c.ws};
 
@@ -622,7 +652,7 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
 
     // phone embedding + PE, conv-FF transformer (mrte.py:159-160,165)
     float* x = c.ws.get<float>((size_t)P.R * H);
-    MT2_HIP(launch_embed_pe(m.phone_emb, H, phone, ip.dev(o_idmap), ip.dev(o_pos), m.pe_mrte, x, H, P.R, side));
+    MT2_HIP(launch_embed_pe(m.phone_emb, H, phone, ip.dev(o_idmap), ip.dev(o_pos), m.pe_mrte, x, H, P.R, cfg.phone_vocab, side));
     EncScratch sc = enc_scratch(c, m.phone_enc, P.R);
     AttnGeom g;
     g.start = P.d_start; g.len = P.d_len; g.B = B; g.max_len = P.maxlen;
@@ -692,6 +722,7 @@ static ArGroups ar_groups(mt2_model& m, hipStream_t main, const ArOrder& ord, in
 static void ar_fork(mt2_model& m, const ArGroups& g) {
     if (g.G <= 1) return;
     MT2_HIP(hipEventRecord(m.ev_fork, g.stream[0]));
+    m.aux_forked = true;
     for (int i = 1; i < g.G; ++i) MT2_HIP(hipStreamWaitEvent(g.stream[i], m.ev_fork, 0));
 }
 static void ar_join(mt2_model& m, const ArGroups& g) {
@@ -846,7 +877,7 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
             if (q.A == 0) continue;
             Ctx cg{m, grp.stream[g], c.ws};
             MT2_HIP(launch_plm_step_input(cond, ld_c, ip.dev(q.o_crow), m.plm_emb, q.codes, cstride, m.pe_plm, q.x, Dc,
-                                          De, n, q.A, cg.s));
+                                          De, n, q.A, NB + 2, cg.s));
             const float* y = ar_step_layers(cg, e, q.x, n, q.A, q.qkv0, q.nmax, q.sc, q.ylast, t == pre.P && pre.P > 0);
             // predict_layer on the last position of each sequence only (:178 takes [:, -1:]), then argmax
             GemmP p{};
@@ -1043,6 +1074,7 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
         ensure_aux(m, nside);
         if (nside) {
             MT2_HIP(hipEventRecord(m.ev_fork, c.s));
+            m.aux_forked = true;
             for (int j = 0; j < nside; ++j) MT2_HIP(hipStreamWaitEvent(m.aux_streams[j], m.ev_fork, 0));
         }
         for (int j = 0; j < 3; ++j) {
@@ -1070,9 +1102,10 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
             // last stage: the mean goes straight into the output layer (one pass over the three resblock outputs)
             // F.leaky_relu default slope 0.01, conv_post k7, tanh
             float* wav = c.ws.get<float>((size_t)R);
-            MT2_HIP(launch_conv_post(rb[0], rb[1], rb[2], 1.0f / 3.0f, R, ch, m.hg_post.k, m.hg_post.w, m.hg_post.b, 0.01f,
-                                     valid, wav, c.s));
-            return wav;
+            const hipError_t e = launch_conv_post(rb[0], rb[1], rb[2], 1.0f / 3.0f, R, ch, m.hg_post.k, m.hg_post.w,
+                                                  m.hg_post.b, 0.01f, valid, wav, c.s);
+            if (e == hipSuccess) return wav;
+            if (e != hipErrorNotSupported) MT2_HIP(e);      // not supported (LDS): the two-launch form below
         }
         x = c.ws.get<float>(per);
         MT2_HIP(launch_avg3(rb[0], rb[1], rb[2], 1.0f / 3.0f, x, (long long)per, c.s));

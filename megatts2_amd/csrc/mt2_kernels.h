@@ -129,7 +129,7 @@ hipError_t launch_attention(const AttnP& p, hipStream_t s);
 // ---- row utilities (rowops.hip) ------------------------------------------------------------------
 // out[r, :] = table[ids[idmap[r]], :] + pe[pos[r], :]   (idmap[r] < 0 -> zero row)
 hipError_t launch_embed_pe(const float* table, int C, const int64_t* ids, const int* idmap, const int* pos,
-                           const float* pe, float* out, int ldo, int R, hipStream_t s);
+                           const float* pe, float* out, int ldo, int R, int vocab, hipStream_t s);
 // out[r, 0:C] = src[map[r], 0:C] (map[r] < 0 -> zeros);  generic row gather
 hipError_t launch_gather_rows(const float* src, int lds_, const int* map, float* out, int ldo, int C, int R,
                               hipStream_t s);
@@ -158,7 +158,7 @@ hipError_t launch_adm_step_input(const float* tc_emb, int ld_tc, const int* tc_r
 //   PLM: x[j*n+i] = [cond[cond_row[j]+i, 0:Dc], emb[codes[j*cstride+i], 0:De]] + pe[i]
 hipError_t launch_plm_step_input(const float* cond, int ld_c, const int* cond_row, const float* emb,
                                  const int64_t* codes, int cstride, const float* pe, float* x, int Dc, int De,
-                                 int n, int A, hipStream_t s);
+                                 int n, int A, int emb_rows, hipStream_t s);
 // ADM head: p[j*pstride + n] = dot(x[j*xn + xn-1, 0:D], w)    (predict_layer, last position only; xn = rows
 // per sequence in x: n for the full step matrix, 1 for the last-row matrix of the last layer)
 hipError_t launch_adm_predict(const float* x, int D, const float* w, float* p, int pstride, int n, int xn, int A,
@@ -197,10 +197,10 @@ hipError_t launch_vq_argmin(const float* x, int ldx, int D, const float* xe, int
 hipError_t launch_row_sqnorm(const float* E, int D, float* ee, int N, hipStream_t s);
 // decoder input (models/megatts2.py:361-366): out[r] = [tc[tcmap[r]], E[codes[codemap[r]]]]
 hipError_t launch_decoder_input(const float* tc, int ld_tc, const int* tcmap, const float* E, const int64_t* codes,
-                                const int* codemap, float* out, int Dc, int Dq, int R, hipStream_t s);
+                                const int* codemap, float* out, int Dc, int Dq, int R, int bins, hipStream_t s);
 // zq rows (modules/vqpe.py:59-61): out[r] = E[codes[codemap[r]]]
 hipError_t launch_codebook_rows(const float* E, const int64_t* codes, const int* codemap, float* out, int ldo,
-                                int Dq, int R, hipStream_t s);
+                                int Dq, int R, int bins, hipStream_t s);
 // mel front-end helpers (rowops.hip)
 hipError_t launch_reflect_pad_blocks(const float* wav, long long wstride, const int* blk_b, const int* blk_t,
                                      const int* len, int hop, int pad, float* out, int R, hipStream_t s);

@@ -174,6 +174,17 @@ struct mt2_model {
     // dedicated stream of the optional prompt VQ-PE of mt2_synthesize_batch (runs beside the ADM)
     hipStream_t vq_stream = nullptr;
     hipEvent_t ev_vq_fork = nullptr, ev_vq_join = nullptr, ev_vq_t0 = nullptr, ev_vq_t1 = nullptr;
+    // internal streams that were forked from the caller's stream during the current API call and may still hold work:
+    // CallScope's destructor joins them back on EVERY exit path (an exception thrown between a fork and its join must not
+    // leave kernels that read the arena - or write caller buffers - running behind the call)
+    bool aux_forked = false, vq_forked = false;
+    // range check of caller-supplied gather indices: runs on its own stream (it depends on the call's INPUTS only), so
+    // the verdict is read at the end of the call without waiting for the call's own kernels (model_stages.hip, IdCheck)
+    hipStream_t id_stream = nullptr;
+    hipEvent_t ev_id_fork = nullptr, ev_id_done = nullptr;
+    int* id_flag_dev = nullptr;
+    int* id_flag_host = nullptr;       // hipHostMalloc
+    bool id_open = false;              // checks enqueued, verdict not read yet
 
     // mel front-end constants for the last mt2_audio_config seen (windowed DFT basis, mel filterbank)
     mt2_audio_config fe_cfg{};

@@ -181,16 +181,20 @@ static inline dim3 row_grid(long long work) {
     return dim3((unsigned)blocks);
 }
 
+// Caller-supplied ids are clamped into the table by every gather (the range check that turns a bad id into an error
+// runs beside the call, model_stages.hip ids_check): an out-of-range id never becomes an out-of-bounds read.
+__device__ __forceinline__ long long clamp_id(long long v, int hi) { return v < 0 ? 0 : (v >= hi ? hi - 1 : v); }
+
 // TokenEmbedding + SinePositionalEmbedding (modules/embedding.py:43-47,94-98; mrte.py:159-160)
 __global__ void embed_pe_kernel(const float* table, int C, const int64_t* ids, const int* idmap, const int* pos,
-                                const float* pe, float* out, int ldo, int R) {
+                                const float* pe, float* out, int ldo, int R, int vocab) {
     const int c4n = C >> 2;
     MT2_ROW_LOOP(R, C) {
         const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int im = idmap[r];
         if (im >= 0) {
-            const float4 e = *reinterpret_cast<const float4*>(table + (long long)ids[im] * C + c);
+            const float4 e = *reinterpret_cast<const float4*>(table + clamp_id(ids[im], vocab) * C + c);
             const float4 q = *reinterpret_cast<const float4*>(pe + (long long)pos[r] * C + c);
             v.x = e.x * 1.0f + q.x; v.y = e.y * 1.0f + q.y; v.z = e.z * 1.0f + q.z; v.w = e.w * 1.0f + q.w;
         }
@@ -198,10 +202,10 @@ __global__ void embed_pe_kernel(const float* table, int C, const int64_t* ids, c
     }
 }
 hipError_t launch_embed_pe(const float* table, int C, const int64_t* ids, const int* idmap, const int* pos,
-                           const float* pe, float* out, int ldo, int R, hipStream_t s) {
+                           const float* pe, float* out, int ldo, int R, int vocab, hipStream_t s) {
     if (R <= 0) return hipSuccess;
     hipLaunchKernelGGL(embed_pe_kernel, row_grid((long long)R * (C >> 2)), dim3(256), 0, s, table, C, ids, idmap,
-                       pos, pe, out, ldo, R);
+                       pos, pe, out, ldo, R, vocab);
     return hipGetLastError();
 }
 
@@ -362,6 +366,9 @@ hipError_t launch_conv_post(const float* x0, const float* x1, const float* x2, f
     if (R <= 0) return hipSuccess;
     if ((ch & 3) || ch > 128 || k > 15 || !(k & 1)) return hipErrorInvalidValue;
     const size_t lds = ((size_t)(256 + k - 1) * (ch + 1) + (size_t)k * ch) * sizeof(float);
+    // the default dynamic-LDS limit is 64 KiB and this kernel does not raise it: wider last stages (a checkpoint with
+    // upsample_initial_channel 1024 / 2048 -> ch 64 / 128) take the avg3 + conv_same path instead (hifigan_rows)
+    if (lds > 64 * 1024) return hipErrorNotSupported;
     hipLaunchKernelGGL(conv_post_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), lds, s, x0, x1, x2, scale, R, ch, k, w,
                        bias, slope, valid, out);
     return hipGetLastError();
@@ -461,7 +468,7 @@ hipError_t launch_adm_step_input(const float* tc_emb, int ld_tc, const int* tc_r
 // MegaPLM.infer step input (models/megatts2.py:173-175): cat([cond[:t+1], pc_embedding(codes)]) + pe
 __global__ void plm_step_input_kernel(const float* cond, int ld_c, const int* cond_row, const float* emb,
                                       const int64_t* codes, int cstride, const float* pe, float* x, int Dc, int De,
-                                      int n, int A) {
+                                      int n, int A, int emb_rows) {
     const int D = Dc + De, c4n = D >> 2;
     MT2_ROW_LOOP(A * n, D) {
         const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
@@ -470,7 +477,7 @@ __global__ void plm_step_input_kernel(const float* cond, int ld_c, const int* co
         if (c < Dc) {
             v = *reinterpret_cast<const float4*>(cond + (long long)(cond_row[j] + i) * ld_c + c);
         } else {
-            v = *reinterpret_cast<const float4*>(emb + (long long)codes[(long long)j * cstride + i] * De + (c - Dc));
+            v = *reinterpret_cast<const float4*>(emb + clamp_id(codes[(long long)j * cstride + i], emb_rows) * De + (c - Dc));
         }
         const float4 q = *reinterpret_cast<const float4*>(pe + (long long)i * D + c);
         v.x = v.x * 1.0f + q.x; v.y = v.y * 1.0f + q.y; v.z = v.z * 1.0f + q.z; v.w = v.w * 1.0f + q.w;
@@ -479,10 +486,10 @@ __global__ void plm_step_input_kernel(const float* cond, int ld_c, const int* co
 }
 hipError_t launch_plm_step_input(const float* cond, int ld_c, const int* cond_row, const float* emb,
                                  const int64_t* codes, int cstride, const float* pe, float* x, int Dc, int De,
-                                 int n, int A, hipStream_t s) {
+                                 int n, int A, int emb_rows, hipStream_t s) {
     if (A <= 0) return hipSuccess;
     hipLaunchKernelGGL(plm_step_input_kernel, row_grid((long long)A * n * ((Dc + De) >> 2)), dim3(256), 0, s, cond,
-                       ld_c, cond_row, emb, codes, cstride, pe, x, Dc, De, n, A);
+                       ld_c, cond_row, emb, codes, cstride, pe, x, Dc, De, n, A, emb_rows);
     return hipGetLastError();
 }
 
@@ -746,7 +753,8 @@ hipError_t launch_row_sqnorm(const float* E, int D, float* ee, int N, hipStream_
 
 // decoder input rows (models/megatts2.py:361-366): [tc_latent_expand (gather), zq (codebook row, x8 repeat)]
 __global__ void decoder_input_kernel(const float* tc, int ld_tc, const int* tcmap, const float* E,
-                                     const int64_t* codes, const int* codemap, float* out, int Dc, int Dq, int R) {
+                                     const int64_t* codes, const int* codemap, float* out, int Dc, int Dq, int R,
+                                     int bins) {
     const int D = Dc + Dq, c4n = D >> 2;
     MT2_ROW_LOOP(R, D) {
         const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
@@ -754,36 +762,36 @@ __global__ void decoder_input_kernel(const float* tc, int ld_tc, const int* tcma
         const int tr = tcmap[r];
         if (tr >= 0) {
             if (c < Dc) v = *reinterpret_cast<const float4*>(tc + (long long)tr * ld_tc + c);
-            else v = *reinterpret_cast<const float4*>(E + (long long)codes[codemap[r]] * Dq + (c - Dc));
+            else v = *reinterpret_cast<const float4*>(E + clamp_id(codes[codemap[r]], bins) * Dq + (c - Dc));
         }
         *reinterpret_cast<float4*>(out + (long long)r * D + c) = v;
     }
 }
 hipError_t launch_decoder_input(const float* tc, int ld_tc, const int* tcmap, const float* E, const int64_t* codes,
-                                const int* codemap, float* out, int Dc, int Dq, int R, hipStream_t s) {
+                                const int* codemap, float* out, int Dc, int Dq, int R, int bins, hipStream_t s) {
     if (R <= 0) return hipSuccess;
     hipLaunchKernelGGL(decoder_input_kernel, row_grid((long long)R * ((Dc + Dq) >> 2)), dim3(256), 0, s, tc, ld_tc,
-                       tcmap, E, codes, codemap, out, Dc, Dq, R);
+                       tcmap, E, codes, codemap, out, Dc, Dq, R, bins);
     return hipGetLastError();
 }
 
 // EuclideanCodebook.dequantize (core_vq.py:188-190) + the x8 repeat of vqpe.py:59-61 via codemap
 __global__ void codebook_rows_kernel(const float* E, const int64_t* codes, const int* codemap, float* out, int ldo,
-                                     int Dq, int R) {
+                                     int Dq, int R, int bins) {
     const int c4n = Dq >> 2;
     MT2_ROW_LOOP(R, Dq) {
         const int r = (int)(i_ / c4n), c = (int)(i_ % c4n) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int cm = codemap[r];
-        if (cm >= 0) v = *reinterpret_cast<const float4*>(E + (long long)codes[cm] * Dq + c);
+        if (cm >= 0) v = *reinterpret_cast<const float4*>(E + clamp_id(codes[cm], bins) * Dq + c);
         *reinterpret_cast<float4*>(out + (long long)r * ldo + c) = v;
     }
 }
 hipError_t launch_codebook_rows(const float* E, const int64_t* codes, const int* codemap, float* out, int ldo,
-                                int Dq, int R, hipStream_t s) {
+                                int Dq, int R, int bins, hipStream_t s) {
     if (R <= 0) return hipSuccess;
     hipLaunchKernelGGL(codebook_rows_kernel, row_grid((long long)R * (Dq >> 2)), dim3(256), 0, s, E, codes, codemap,
-                       out, ldo, Dq, R);
+                       out, ldo, Dq, R, bins);
     return hipGetLastError();
 }
 

@@ -269,6 +269,9 @@ class HIFIGAN:
         if os.environ.get("MEGATTS2_HIFIGAN_DIR"):
             cands.append(os.environ["MEGATTS2_HIFIGAN_DIR"])
         cands.append(os.path.join("pretrained_models", os.path.basename(source.rstrip("/"))))
+        # speechbrain's fetch() default cache: pretrained_models/<ClassName>-<md5(source)>
+        import hashlib
+        cands.append(os.path.join("pretrained_models", f"{cls.__name__}-{hashlib.md5(source.encode('UTF-8', errors='replace')).hexdigest()}"))
         for d in cands:
             if d and os.path.isfile(os.path.join(d, "hyperparams.yaml")):
                 cfg, sd = weights.load_speechbrain_hifigan(d)

@@ -622,5 +622,9 @@ def bench_gemm(M, N, K, taps=1, force_cfg=-1, iters=20, w_copies=1, dil=1, flags
     lib = load_library()
     ms = C.c_float(0)
     name = C.create_string_buffer(64)
-    _check(lib.mt2_bench_gemm(_stream(), M, N, K, taps, dil, flags, force_cfg, iters, w_copies, C.byref(ms), name, 64))
+    ghz = C.c_double(0.0)
+    _check(lib.mt2_bench_gemm(_stream(), M, N, K, taps, dil, flags, force_cfg, iters, w_copies, C.byref(ms), name, 64,
+                              C.byref(ghz)))
+    if flags & 4:
+        return ms.value, name.value.decode(), ghz.value
     return ms.value, name.value.decode()

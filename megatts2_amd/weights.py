@@ -377,7 +377,10 @@ def load_speechbrain_hifigan(source: str):
     cfg = hifigan_config_from_speechbrain(hp)
     import torch
 
-    raw = torch.load(ck, map_location="cpu", weights_only=False)
+    # a speechbrain generator.ckpt is a plain tensor state dict: never unpickle arbitrary objects from a model directory
+    # the caller (or the CWD, or an environment variable) points at; opt in explicitly for a legacy pickled checkpoint
+    unsafe = os.environ.get("MEGATTS2_UNSAFE_PICKLE", "") == "1"
+    raw = torch.load(ck, map_location="cpu", weights_only=not unsafe)
     if isinstance(raw, dict) and "state_dict" in raw and not any(k.startswith("conv_pre") for k in raw):
         raw = raw["state_dict"]
     return cfg, convert_speechbrain_hifigan(raw, cfg)

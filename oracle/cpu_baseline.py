@@ -27,6 +27,7 @@ def main() -> None:
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--budget", type=float, default=20.0, help="stop starting new utterances after this many seconds")
     ap.add_argument("--max-utts", type=int, default=8)
+    ap.add_argument("--min-utts", type=int, default=3, help="at least this many utterances even beyond the budget")
     ap.add_argument("--backend", default="aten", choices=["aten", "numpy"])
     a = ap.parse_args()
     # one pool only: ATen's.  numpy's BLAS pool would busy-wait beside it (measured: 256 + 128 spinning threads
@@ -51,22 +52,32 @@ def main() -> None:
     if a.backend == "aten":
         O.enable_torch_kernels(a.threads)
     n_utt, frames, t0 = 0, 0, time.perf_counter()
+    sec = {"vqpe": 0.0, "mrte+adm+plm+decoder" if full else "mrte+adm+decoder": 0.0, "vocoder": 0.0}
+    k_syn = [k for k in sec if k.startswith("mrte")][0]
     for u in utts:
+        t1 = time.perf_counter()
         if full:    # configs[2] "full VQ-PE -> ...": the prosody encoder on the prompt mel, as bench.py's step does
             O.vqpe_forward(sd_g, g, u.prompt_mel)
+        t2 = time.perf_counter()
         ref = O.synthesize(sd_g, sd_p, sd_a, g, p, d, u.phone, u.prompt_mel, forced_durations=u.durations,
                            forced_codes=None if full else u.p_codes, run_plm=full)
+        t3 = time.perf_counter()
         if full:
             O.hifigan(sd_h, h, ref["mel"])
+        t4 = time.perf_counter()
+        sec["vqpe"] += t2 - t1; sec[k_syn] += t3 - t2; sec["vocoder"] += t4 - t3
         n_utt += 1
         frames += ref["mel"].shape[0]
-        if time.perf_counter() - t0 > a.budget:
+        if time.perf_counter() - t0 > a.budget and n_utt >= min(a.min_utts, len(utts)):
             break
     cpu_s = time.perf_counter() - t0
+    per_stage = ", ".join(f"{k} {v:.2f} s" for k, v in sec.items() if v > 0)
     print(json.dumps({"value": round(frames / cpu_s, 2), "unit": "mel-frames/s", "cores": a.threads, "kind": "port",
+                      "stage_cpu_s": {k: round(v, 3) for k, v in sec.items() if v > 0},
                       "sample": f"{n_utt} of the {shape.B} utterances of {a.workload} (Np={shape.Np}, Tp={shape.Tp}, "
-                                f"Tm={shape.Tm}) one after the other, oracle port, dense primitives on "
-                                f"{'ATen' if a.backend == 'aten' else 'numpy/OpenBLAS'}, {a.threads} threads, {cpu_s:.1f} s"
+                                f"Tm={shape.Tm}) one after the other, oracle port, every dense primitive and the whole "
+                                f"vocoder on {'ATen' if a.backend == 'aten' else 'numpy/OpenBLAS'}, {a.threads} threads, "
+                                f"{cpu_s:.1f} s ({per_stage})"
                                 + ("; stages vqpe+mrte+adm+plm+decoder+vocoder" if full else "; stages mrte+adm+decoder")
                                 + "; kind 'port' because /root/reference is absent on the GPU box - the port is pinned to "
                                   "the live reference by tests/golden/*"}))

@@ -39,3 +39,13 @@ def long_inputs(codebook: np.ndarray, seed: int = LONG_SEED) -> dict:
     return out
 
 
+
+
+C5_UTT_SEED = 5055
+
+
+def c5_utterance(seed: int = C5_UTT_SEED):
+    """The ONE whole C5 utterance of tests/golden/prod_c5_utt.npz (834 phones / 2584-frame prompt / 5168 frames,
+    forced durations); shared by oracle/make_golden.py --extra-long and the tests."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return synth.make_utterance(rng, LONG_NP, LONG_TP, LONG_TM)

@@ -251,9 +251,68 @@ def make_prod_extra() -> None:
           "plm argmax", [int(out[f"plm_logits_{n}"].argmax()) for n in PLM_STEPS])
 
 
+# ------------------------------------------------------------------------------------------------
+# ONE whole C5 utterance, free-running (`python oracle/make_golden.py --extra-long`; ~100 TFLOP on the CPU):
+# 834 phones / 2584-frame prompt / 5168 frames through MRTE -> ADM (834 float-feedback steps) -> regulate (forced
+# durations) -> pool -> PLM (646 greedy steps) -> decode -> decoder (models/megatts2.py:353-368).  Inputs are re-derived
+# from `fixtures.c5_utterance()`; stored are the discrete outputs, the ADM float trajectory, the PLM arg-max margins
+# (so that a test can tell a near-tie from an error) and the mel.
+
+def make_prod_c5_utterance() -> None:
+    from fixtures import c5_utterance
+    ref = ref_shim.load()
+    from modules.mrte import LengthRegulator
+    G, plm, adm, sd_g, sd_p, sd_a = build_reference("prod")
+    emb = np.load(os.path.join(GOLDEN, "codebook_prod.npy"))
+    install_codebook(G, sd_g, emb)
+    utt = c5_utterance()
+    adm_float, margins, top1 = [], [], []
+
+    def plm_hook(m, i, o):
+        v = torch.topk(o[0, -1], 2).values
+        margins.append(float(v[0] - v[1]))
+        top1.append(float(v[0]))
+    h1 = adm.predict_layer.register_forward_hook(lambda m, i, o: adm_float.append(o[0, -1, 0].item()))
+    h2 = plm.predict_layer.register_forward_hook(plm_hook)
+    import time
+    t0 = time.time()
+    out = {}
+    with torch.no_grad():
+        phone = torch.from_numpy(utt.phone)[None]
+        mel = torch.from_numpy(utt.prompt_mel)[None]
+        tc = G.mrte.tc_latent(phone, mel)                                   # :354
+        dt = adm.infer(tc)[..., 0]                                          # :355
+        print("adm done", time.time() - t0, flush=True)
+        out["adm_dur"] = dt[0].numpy().astype(np.int32)
+        out["adm_float"] = np.asarray(adm_float, np.float32)
+        lr = LengthRegulator(256, 16000, 16.0)
+        tc_expand = lr(tc, torch.from_numpy(utt.durations)[None])           # :356 (forced durations)
+        cond = F.max_pool1d(tc_expand.transpose(1, 2), 8, ceil_mode=True).transpose(1, 2)   # :357-358
+        codes = plm.infer(cond)                                             # :359
+        print("plm done", time.time() - t0, flush=True)
+        out["p_codes"] = codes[0].numpy()
+        out["plm_margin"] = np.asarray(margins, np.float32)
+        out["plm_top1"] = np.asarray(top1, np.float32)
+        zq = G.vqpe.vq.decode(codes.unsqueeze(0))                           # :361
+        zq = zq.transpose(1, 2).unsqueeze(2).contiguous().expand(-1, -1, 8, -1)
+        zq = zq.reshape(zq.shape[0], -1, zq.shape[-1])
+        x = torch.cat([tc_expand, zq[:, :tc_expand.shape[1], :]], dim=-1)   # :365-366
+        out["mel"] = G.decoder(x.transpose(1, 2))[0].transpose(0, 1).numpy()  # :368
+        out["tc_latent_rows"] = tc[0, ::64].numpy()                          # every 64th phone row (spot check)
+    h1.remove()
+    h2.remove()
+    np.savez_compressed(os.path.join(GOLDEN, "prod_c5_utt.npz"), **out)
+    print("prod_c5_utt", {k: v.shape for k, v in out.items()}, "seconds", time.time() - t0)
+    print("   dur", out["adm_dur"][:16], "codes", out["p_codes"][:12], "min margin", out["plm_margin"].min(),
+          "adm float nearest to .5:", np.abs((out["adm_float"] + 0.5) % 1.0).min())
+
+
 def main() -> None:
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
+    if "--extra-long" in sys.argv:
+        make_prod_c5_utterance()
+        return
     if "--extra" in sys.argv:
         make_prod_extra()
         return

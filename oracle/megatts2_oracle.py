@@ -541,7 +541,7 @@ _NUMPY_PRIMS = {}
 
 
 def enable_torch_kernels(threads: Optional[int] = None) -> None:
-    """Route linear / conv1d / layer_norm / attention through ATen on the CPU - the very kernels the
+    """Route linear / conv1d / layer_norm / attention and the whole vocoder through ATen on the CPU - the very kernels the
     reference's path dispatches to (layer L1: F.linear, F.conv1d, F.layer_norm,
     F.scaled_dot_product_attention; oneDNN / MKL, multi-threaded).  The structure of the port (every
     function above) is unchanged; only these four primitives are swapped.  The numpy primitives stay
@@ -553,7 +553,7 @@ def enable_torch_kernels(threads: Optional[int] = None) -> None:
         torch.set_num_threads(int(threads))
     g = globals()
     if not _NUMPY_PRIMS:
-        _NUMPY_PRIMS.update({k: g[k] for k in ("linear", "conv1d", "layer_norm", "mha")})
+        _NUMPY_PRIMS.update({k: g[k] for k in ("linear", "conv1d", "layer_norm", "mha", "hifigan")})
 
     def t(a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=F32))
@@ -584,7 +584,35 @@ def enable_torch_kernels(threads: Optional[int] = None) -> None:
             o = o.transpose(1, 2).reshape(q.shape[0], n_heads * hd)
             return Fn.linear(o, t(sd[f"{p}.out_proj.0.weight"]), t(sd[f"{p}.out_proj.0.bias"])).numpy()
 
-    g.update(linear=linear_t, conv1d=conv1d_t, layer_norm=layer_norm_t, mha=mha_t)
+    def hifigan_t(sd, cfg, mel):
+        """The vocoder leg on ATen, channels-first from end to end (what a PyTorch HiFi-GAN module - speechbrain's, or
+        transformers.SpeechT5HifiGan, the stand-in of BASELINE.md section 3 - dispatches to): F.conv1d,
+        F.conv_transpose1d, F.leaky_relu.  Same structure and arithmetic as `hifigan` above."""
+        slope = cfg.leaky_relu_slope
+        nk = len(cfg.resblock_kernel_sizes)
+        with torch.no_grad():
+            w = {k: t(v) for k, v in sd.items()}
+            x = Fn.conv1d(t(mel).T.unsqueeze(0), w["conv_pre.weight"], w["conv_pre.bias"], padding=3)
+            for i, (r, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+                x = Fn.leaky_relu(x, slope)
+                x = Fn.conv_transpose1d(x, w[f"upsampler.{i}.weight"], w[f"upsampler.{i}.bias"], stride=r,
+                                        padding=(k - r) // 2)
+                acc = None
+                for j, (rk, dils) in enumerate(zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes)):
+                    q = f"resblocks.{i * nk + j}"
+                    h = x
+                    for n, d in enumerate(dils):
+                        y = Fn.conv1d(Fn.leaky_relu(h, slope), w[f"{q}.convs1.{n}.weight"], w[f"{q}.convs1.{n}.bias"],
+                                      padding=(rk * d - d) // 2, dilation=d)
+                        y = Fn.conv1d(Fn.leaky_relu(y, slope), w[f"{q}.convs2.{n}.weight"], w[f"{q}.convs2.{n}.bias"],
+                                      padding=(rk - 1) // 2)
+                        h = y + h
+                    acc = h if acc is None else acc + h
+                x = acc / nk
+            x = Fn.conv1d(Fn.leaky_relu(x, 0.01), w["conv_post.weight"], w["conv_post.bias"], padding=3)
+            return torch.tanh(x[0, 0]).numpy()
+
+    g.update(linear=linear_t, conv1d=conv1d_t, layer_norm=layer_norm_t, mha=mha_t, hifigan=hifigan_t)
 
 
 def disable_torch_kernels() -> None:

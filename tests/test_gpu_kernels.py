@@ -269,6 +269,67 @@ def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
     assert not x6[valid == 0].any()
 
 
+@pytest.mark.parametrize("cfg", [51, 55, 39])
+def test_gemm_x6_corner_cases(rt, cfg):
+    """Documented corner behaviour of the 3-plane split (DESIGN 4.2 "Corner cases"), against the f32-MFMA kernel and float64:
+      * magnitudes 1e+30 / 1e-30 (all three planes normal bf16 numbers): f32-equivalent like any other input, and the
+        MAX-ABS error on rows that cancel (x . w + x . (-w) + small) stays at the f32 kernel's level;
+      * |a| < 2^-110 (third plane a bf16 denormal) / < 2^-118 (second plane too): the value is carried by fewer planes -
+        the error of such a term is bounded by 2^-8 |a||b|, i.e. ABSOLUTELY below 2^-126 |b|: invisible next to any
+        normal-range term of the same dot product (asserted in absolute terms);
+      * +-inf: a1 = inf, a - a1 = NaN -> the x6 row is NaN where the f32 MFMA gives +-inf (or NaN for inf * 0); NaN
+        inputs give NaN in both.  Rows without such an element are bit-identical to a run without the poisoned rows."""
+    rng = np.random.default_rng(cfg)
+    M, N, K = 384, 256, 512
+    W = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    z = dev(np.zeros(N, np.float32))
+    zr = dev(np.zeros((M, N), np.float32))
+    kw = dict(shift0=0, taps=1, dil=1, Cin=K, pro_act=rt.ACT_NONE, epi_act=rt.ACT_NONE)
+
+    def both(X, Wm=W):
+        x6 = rt.op_conv_x6(dev(X), dev(Wm), z, zr, force_cfg=cfg, **kw).cpu().numpy()
+        f32 = rt.op_gemm(dev(X), dev(Wm), z, zr, force_cfg=16, **kw).cpu().numpy()
+        return x6, f32
+
+    base = rng.standard_normal((M, K)).astype(np.float32)
+    for scale in (1e30, 1e-30):
+        X = (base * np.float32(scale)).astype(np.float32)
+        x6, f32 = both(X)
+        ref = X.astype(np.float64) @ W.T.astype(np.float64)
+        e6, e32 = rel(x6, ref), rel(f32, ref)
+        assert np.isfinite(x6).all() and e6 < 1e-6 and e6 <= 2.0 * e32 + 1e-7, (scale, e6, e32)
+    # cancelling rows: [x, x] . [w, -w + d] = x . d with |d| = 1e-4 |w|: max-abs error relative to the size of the
+    # cancelled terms, x6 no worse than twice the f32 kernel's
+    Xc = np.concatenate([base[:, :K // 2], base[:, :K // 2]], axis=1)
+    d = (rng.standard_normal((N, K // 2)) * 1e-4 / math.sqrt(K)).astype(np.float32)
+    Wc = np.concatenate([W[:, :K // 2], -W[:, :K // 2] + d], axis=1).astype(np.float32)
+    x6, f32 = both(Xc, Wc)
+    ref = Xc.astype(np.float64) @ Wc.T.astype(np.float64)
+    big = np.abs(Xc[:, :K // 2].astype(np.float64)) @ np.abs(Wc[:, :K // 2].T.astype(np.float64))     # size of what cancels
+    m6, m32 = (np.abs(x6 - ref) / big).max(), (np.abs(f32 - ref) / big).max()
+    assert m6 < 4e-7 and m6 <= 2.0 * m32 + 2e-8, (m6, m32)
+    # denormal planes: every A element below 2^-118 (second and third plane bf16-denormal)
+    for scale in (2.0 ** -112, 2.0 ** -120):
+        X = (base * np.float32(scale)).astype(np.float32)
+        x6, f32 = both(X)
+        ref = X.astype(np.float64) @ W.T.astype(np.float64)
+        bound = (np.abs(X.astype(np.float64)) @ np.abs(W.T.astype(np.float64))) * 2.0 ** -8 + 2.0 ** -126
+        assert np.isfinite(x6).all() and (np.abs(x6 - ref) <= bound).all(), (scale, np.abs(x6 - ref).max(), bound.min())
+        assert np.abs(x6 - ref).max() < 2.0 ** -120                      # absolutely negligible: below 1e-36
+    # inf / NaN: poisoned rows are non-finite in both kernels, every other row is untouched
+    X = base.copy()
+    clean6, clean32 = both(X)
+    X[5, 17] = np.inf
+    X[40, 300] = -np.inf
+    X[200, 3] = np.nan
+    x6, f32 = both(X)
+    bad = np.zeros(M, bool)
+    bad[[5, 40, 200]] = True
+    assert np.isnan(x6[bad]).all()                                       # x6: inf -> NaN (documented), NaN -> NaN
+    assert not np.isfinite(f32[bad]).any() and np.isnan(f32[200]).all()  # f32 MFMA: +-inf (NaN where inf * 0), NaN -> NaN
+    assert np.array_equal(x6[~bad], clean6[~bad]) and np.array_equal(f32[~bad], clean32[~bad])
+
+
 @pytest.mark.parametrize("cfg", [-1, 12, 16, 17, 18, 20, 21, 22, 24, 27, 28, 29])
 @pytest.mark.parametrize("M,N,K", [(70, 2304, 768), (33, 96, 100), (300, 1024, 1024), (5, 64, 64), (1120, 768, 768)])
 def test_gemm_with_algebraic_layernorm(rt, cfg, M, N, K):

@@ -524,9 +524,21 @@ def test_prod_c3_batch_free_running_plm_and_vocoder():
     phone, pl = pad_stack([u.phone for u in utts])
     mel, ml = pad_stack([u.prompt_mel for u in utts])
     dur, _ = pad_stack([u.durations for u in utts])
-    out, lens, aux = tts.native.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, vocoder=True, return_aux=True)
+    out, lens, aux = tts.native.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, vocoder=True, return_aux=True,
+                                                 prompt_vqpe=True)
     out = out.cpu().numpy()
     assert lens.tolist() == [431] * 32
+    # the prompt's VQ-PE codes (modules/vqpe.py:50-62) at the benchmark's batch geometry (32 x 431 frames through the x6
+    # conv stacks): bit-exact against the oracle for utterances 0 / 7 / 31
+    pc = aux["prompt_codes"].cpu().numpy()
+    assert pc.shape == (32, 54)
+    O.enable_torch_kernels()
+    try:
+        for i in (0, 7, 31):
+            want = O.vqpe_forward(sd_g, g, utts[i].prompt_mel)[1]
+            assert np.array_equal(pc[i, :want.size], want), f"prompt VQ-PE codes of utterance {i}"
+    finally:
+        O.disable_torch_kernels()
     assert np.array_equal(aux["dur"][0].cpu().numpy(), z["adm_dur"])
     assert np.array_equal(aux["codes"][0, :54].cpu().numpy(), z["p_codes"])
     assert O.rel_l2(out[0, :431], z["mel"]) < NORTH_STAR
@@ -606,6 +618,47 @@ def test_prod_long_shapes_c5_geometry():
             assert np.allclose(flt[b, :252].cpu().numpy(), want[:252], rtol=1e-4, atol=1e-4)
     finally:
         O.disable_torch_kernels()
+
+
+def test_prod_c5_utterance_free_running():
+    """BASELINE configs[4] end to end: ONE 834-phone / 2584-frame-prompt / 5168-frame utterance through MRTE -> ADM (834
+    float-feedback steps) -> regulate (forced durations) -> PLM (646 greedy steps) -> decoder, against the fixture made by
+    the LIVE reference modules (oracle/make_golden.py --extra-long).  Alone and as slot 0 of the B = 8 C5 batch:
+    durations and prosody codes bit-exact, ADM float trajectory 1e-4, mel within 1e-3."""
+    import fixtures
+    from megatts2_amd import synth
+    tts = model("prod")
+    z = load_golden("prod_c5_utt.npz")
+    u = fixtures.c5_utterance()
+    assert u.phone.size == 834 and u.prompt_mel.shape[0] == 2584 and int(u.durations.sum()) == 5168
+
+    def check(out, lens, aux, slot, what):
+        assert int(lens[slot]) == 5168
+        dur = aux["dur"][slot, :834].cpu().numpy()
+        codes = aux["codes"][slot, :646].cpu().numpy()
+        bad = np.nonzero(codes != z["p_codes"])[0]
+        first = int(bad[0]) if bad.size else -1
+        assert np.array_equal(dur, z["adm_dur"]), f"{what}: durations differ at {np.nonzero(dur != z['adm_dur'])[0][:8]}"
+        assert bad.size == 0, (f"{what}: {bad.size} prosody codes differ, first at step {first} "
+                               f"(reference arg-max margin there {float(z['plm_margin'][first]):.3g})")
+        assert O.rel_l2(out[slot, :5168].cpu().numpy(), z["mel"]) < NORTH_STAR
+
+    out, lens, aux = tts.native.synthesize_batch(dev(u.phone[None]), None, dev(u.prompt_mel[None]), None,
+                                                 forced_dur=u.durations[None], return_aux=True)
+    check(out, lens, aux, 0, "alone")
+    # the float trajectory of the ADM and a spot check of tc_latent rows, through the stage calls
+    tc = tts.generator.mrte.tc_latent(dev(u.phone[None]), dev(u.prompt_mel[None]))
+    assert O.rel_l2(tc[0, ::64].cpu().numpy(), z["tc_latent_rows"]) < TIGHT
+    _, flt = tts.native.adm_infer(tc, return_float=True)
+    assert np.allclose(flt[0].cpu().numpy(), z["adm_float"], rtol=1e-4, atol=1e-4)
+    del out, aux, tc
+    utts = synth.make_batch(synth.C5, seed=1005)
+    utts[0] = u
+    phone, pl = pad_stack([v.phone for v in utts])
+    mel, ml = pad_stack([v.prompt_mel for v in utts])
+    dur, _ = pad_stack([v.durations for v in utts])
+    out, lens, aux = tts.native.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, return_aux=True)
+    check(out, lens, aux, 0, "slot 0 of the B = 8 batch")
 
 
 def test_prod_plm_prompt_conditioned():

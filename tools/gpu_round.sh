@@ -129,6 +129,18 @@ probe_x6)
     python tools/pmc_probe_summary.py gpurun_out/probe_x6_$i | tee gpurun_out/probe_x6_summary_$i.txt | cut -c1-400
     find gpurun_out/probe_x6_$i -name "*.csv" -size +4M -delete
   done ;;
+ablate)
+  # measurement builds made in the build container (tools/build_variant.sh): which resource bounds a chunk of the x6 tile
+  : > gpurun_out/x6_ablate.txt
+  timeout 300 python tools/x6_ablate.py prod 2>&1 | grep -v amdgpu.ids >> gpurun_out/x6_ablate.txt
+  for v in abl1 abl2 abl3 abl4; do
+    [ -d variants/$v ] && (cd variants/$v && timeout 300 python tools/x6_ablate.py $v 2>&1 | grep -v amdgpu.ids) >> gpurun_out/x6_ablate.txt
+  done
+  echo "ablate rc=$?"; cat gpurun_out/x6_ablate.txt ;;
+clock)
+  # phase timer + clock probe (s_memtime vs s_memrealtime) in the MT2_PHASE_TIMING variant
+  (cd variants/phase && timeout 300 python tools/x6_phase_timing.py ldr && timeout 300 python tools/x6_phase_timing.py f32) > gpurun_out/clock_probe.txt 2>&1
+  echo "clock rc=$?"; grep -v amdgpu.ids gpurun_out/clock_probe.txt ;;
 phase)
   # instrumented build in a scratch copy of the package (the in-tree library stays the production one)
   rm -rf /tmp/mt2_phase && mkdir -p /tmp/mt2_phase && cp -r megatts2_amd include tools /tmp/mt2_phase/

@@ -15,5 +15,5 @@ MODE = sys.argv[1] if len(sys.argv) > 1 else ""
 for name, M, N, K, taps, cfg in CASES_F32 if MODE == "f32" else CASES_LDR if MODE == "ldr" else [("big", 4096, 4096, 4096, 1, 37), ("big", 4096, 4096, 4096, 1, 39), ("big", 4096, 4096, 4096, 1, 42),
                                  ("decoder", 13858, 512, 2560, 5, 37), ("plm_ff0", 1728, 4096, 1024, 1, 37),
                                  ("plm_ff0", 864, 4096, 1024, 1, 39), ("plm_qkv", 864, 3072, 1024, 1, 39)]:
-    ms, cn = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=4, w_copies=2, flags=4)
+    ms, cn, ghz = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=4, w_copies=2, flags=4)
     print(f"{name} {M}x{N}x{K} {cn}: {ms * 1e3:.1f} us {2.0 * M * N * K / ms / 1e9:.1f} TF/s  ({ms * 1e-3 * 2.1e9 / ((K + 31) // 32):.0f} cycles per chunk at 2.1 GHz, one tile per CU pass)", flush=True)

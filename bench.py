@@ -116,6 +116,57 @@ def gemm_flops_model(g, adm, plm, hg, utts, stages):
     return sum(gemm.values()), sum(attn.values())
 
 
+def sub_workload(model, cfgs, name, steps, warmup, dev):
+    """One of the other BASELINE.json configurations on the SAME handle, timed like the main line (W warm-up steps, K
+    timed steps between device synchronisations, inputs resident in HBM): C2 = configs[1] (MRTE + ADM + decoder, forced
+    prosody codes), C1 = configs[0] as infer.py runs it (one utterance, the whole path incl. PLM + vocoder), C5 =
+    configs[4] (8 x 834 phones / 2584-frame prompt / 5168 frames, the whole path)."""
+    import torch
+    from megatts2_amd import synth
+    g, p, a, h = cfgs
+    shape = synth.SHAPES[name]
+    full = name != "C2"
+    utts = synth.make_batch(shape, seed=1000 + int(name[1]), batch=shape.B)
+    phone = torch.from_numpy(np.stack([u.phone for u in utts])).to(dev)
+    mel_in = torch.from_numpy(np.stack([u.prompt_mel for u in utts])).to(dev)
+    dur = np.stack([u.durations for u in utts]).astype(np.int32)
+    codes = None if full else torch.from_numpy(np.stack([u.p_codes for u in utts])).to(dev)
+    pl, ml = np.full(shape.B, shape.Np, np.int32), np.full(shape.B, shape.Tp, np.int32)
+    vq = name in ("C3", "C5")          # infer.py (C1) never runs the prosody encoder on the prompt (models/megatts2.py:353-372)
+    stages = [s_ for s_ in STAGES_FULL if vq or s_ != "vqpe"] if full else ["mrte", "adm", "decoder"]
+    model.workspace_reserve(model.workspace_query(shape.B, shape.Np, shape.Tp, shape.Tm, run_plm=full, vocoder=full,
+                                                  prompt_vqpe=vq))
+
+    def step():
+        return model.synthesize_batch(phone, pl, mel_in, ml, forced_dur=dur, forced_codes=codes, run_plm=full, vocoder=full,
+                                      tm_cap=shape.Tm, prompt_vqpe=vq)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    model.set_profiling(True)
+    step()
+    torch.cuda.synchronize()
+    stage_ms = dict(model.last_stage_ms())
+    model.set_profiling(False)
+    if "vqpe_side" in stage_ms:
+        stage_ms["vqpe"] = stage_ms.pop("vqpe_side")
+    frames = int(dur.sum())
+    alg_s, _ = stage_flops_model(g, a, p, h, utts, stages)
+    alg = sum(alg_s.values())
+    return {"workload": f"{name}: B={shape.B}, Np={shape.Np}, Tp={shape.Tp}, Tm={shape.Tm}; stages " + "+".join(stages)
+                        + "; forced durations" + ("" if full else " and prosody codes"),
+            "value": round(frames / (ms * 1e-3), 1), "unit": "mel-frames/s", "ms_per_step": round(ms, 3), "steps": steps,
+            "warmup": warmup, "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "algorithmic_gflop_per_step": round(alg / 1e9, 1), "tflops": round(alg / (ms * 1e-3) / 1e12, 2),
+            "frac": round(alg / (ms * 1e-3) / 1e12 / X6_EQUIV_PEAK_TFLOPS, 4),
+            "frac_of_f32_mfma_peak": round(alg / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +175,8 @@ def main() -> None:
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-workloads", action="store_true",
+                    help="default C3 run only: skip the C2 / C1 / C5 sub-results (`workloads` in the JSON line)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="debug: a handle option (mt2_set_option), e.g. ar_groups=1, splitk=0, win_conv=0, t_ks4=512")
@@ -165,7 +218,7 @@ def main() -> None:
     from megatts2_amd.dist import gather_mels, shard_imbalance, utterance_cost
 
     g, p, a, h = C.production_g(), C.production_plm(), C.production_adm(), C.production_hifigan()
-    full = args.workload in ("C3", "C5")
+    full = args.workload in ("C1", "C3", "C5")     # C1 = infer.py's single utterance: the whole path incl. PLM + vocoder
     if dry:
         class _StandIn:                                                  # shapes only; never used for a measurement
             def synthesize_batch(self, phone, pl, mel_in, ml, forced_dur=None, tm_cap=None, **_):
@@ -203,7 +256,8 @@ def main() -> None:
     pl = np.full(B, Np, np.int32)
     ml = np.full(B, Tp, np.int32)
     frames_per_step = int(dur.sum())
-    stages = [s for s in (STAGES_FULL if full else ["mrte", "adm", "decoder"]) if not (args.skip_adm and s == "adm")]
+    stages = [s for s in (STAGES_FULL if full else ["mrte", "adm", "decoder"]) if not (args.skip_adm and s == "adm")
+              and not (args.workload == "C1" and s == "vqpe")]
     if not dry and full:            # pre-size the activation arena: no hipMalloc inside the timed region
         model.workspace_reserve(model.workspace_query(B, Np, Tp, shape.Tm, run_plm=True, vocoder=True, prompt_vqpe=True))
 
@@ -213,8 +267,8 @@ def main() -> None:
         # configs[2] "full VQ-PE -> ...": VQProsodyEncoder.forward (conv stacks + codebook L2-argmin) on the 431-frame
         # prompt mel - the prosody codes a prompt-conditioned PLM / stage-2 extraction consume.  Same work either way:
         # "overlap" runs it inside the synthesis call on an internal stream beside the ADM, "separate" in front.
-        side = full and args.vqpe == "overlap"
-        if full and not side:
+        side = full and args.vqpe == "overlap" and args.workload != "C1"     # infer.py (C1) has no prompt VQ-PE
+        if full and not side and args.workload != "C1":
             if time_vqpe:
                 ev[0].record()
             model.vqpe_forward(mel_in, ml)
@@ -287,7 +341,7 @@ def main() -> None:
         step(time_vqpe=True, exchange=False)
         torch.cuda.synchronize()
         stage_ms = {k: v for k, v in model.last_stage_ms().items()}
-        if full and args.vqpe == "separate":
+        if full and args.vqpe == "separate" and args.workload != "C1":
             stage_ms["vqpe"] = ev[0].elapsed_time(ev[1])
         elif "vqpe_side" in stage_ms:          # its duration on the internal stream (overlapped with the ADM stage)
             stage_ms["vqpe"] = stage_ms.pop("vqpe_side")
@@ -310,7 +364,9 @@ def main() -> None:
         # engine throughput against the time of the TIMED steps (the engine is busy for at most the whole step)
         achieved = alg_gemm / (ms_per_step * 1e-3) / 1e12
         pm = None
-        pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload.lower()}_latest.json")
+        pmc_path = os.path.join(ROOT, "profiles", f"r03_pmc_{args.workload.lower()}_latest.json")
+        if not os.path.exists(pmc_path):
+            pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload.lower()}_latest.json")
         if os.path.exists(pmc_path):
             pm = json.load(open(pmc_path))
         per_stage = {}
@@ -333,7 +389,8 @@ def main() -> None:
         if pm and "gemm_engine" in pm:
             ge = pm["gemm_engine"]
             traffic = round((ge["read_gb_corrected"] + ge["write_gb"]) * 1e9 / max(ge["launches"], 1))
-            traffic_detail = {"unit": "bytes per launch (fabric reads, FETCH_SIZE x 2, + WRITE_SIZE; KiB units)",
+            traffic_detail = {"kind": "static: read from the committed rocprofv3 --pmc summary named in `source`, not measured in this run",
+                              "unit": "bytes per launch (fabric reads, FETCH_SIZE x 2, + WRITE_SIZE; KiB units)",
                               "read_gb_per_step": ge["read_gb_corrected"], "write_gb_per_step": ge["write_gb"],
                               "launches_per_step": ge["launches"], "source": os.path.relpath(pmc_path, ROOT)}
         result["roofline"] = {
@@ -365,6 +422,37 @@ def main() -> None:
                             "tflops": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2)} for r in tr],
         }
 
+    if rank == 0 and world == 1 and not dry and not args.no_roofline and "roofline" in result:
+        # sustained shader clock under the dominant kernel, measured live: one wave of gemm_x6_ldr_kernel reads s_memtime
+        # (shader cycles) and s_memrealtime (constant rate) around its K loop; the bf16 pipe's ceiling scales with it
+        from megatts2_amd import runtime as rt
+        probes = []
+        for nm, M_, N_, K_, taps_, cfg_ in (("big 4096^3", 4096, 4096, 4096, 1, 51), ("conv stack 14064x512x1536", 14064, 512, 1536, 3, 51),
+                                          ("plm_ff0 864x4096x1024", 864, 4096, 1024, 1, 55), ("adm_qkv 1120x2304x768", 1120, 2304, 768, 1, 55)):
+            try:
+                ms_, cn_, ghz_ = rt.bench_gemm(M_, N_, K_, taps=taps_, force_cfg=cfg_, iters=6, w_copies=2, flags=4 | 8)
+                probes.append({"shape": nm, "config": cn_, "us": round(ms_ * 1e3, 1), "tflops": round(2.0 * M_ * N_ * K_ / ms_ / 1e9, 1),
+                               "sustained_ghz": round(ghz_, 3)})
+            except Exception as e:      # measurement extra: never fail the line
+                probes.append({"shape": nm, "error": str(e)[:120]})
+        ghz = [q["sustained_ghz"] for q in probes if q.get("sustained_ghz")]
+        if ghz:
+            full_chip = [q["sustained_ghz"] for q in probes[:2] if q.get("sustained_ghz")] or ghz
+            clk = sum(full_chip) / len(full_chip)
+            rf = result["roofline"]
+            rf["clock_probe"] = {"method": "s_memtime / s_memrealtime over the K loop of one wave of gemm_x6_ldr_kernel, live in this run",
+                                 "launches": probes, "sustained_ghz_full_chip_x6": round(clk, 3), "max_ghz": 2.4}
+            rf["peak_at_sustained_clock"] = round(X6_EQUIV_PEAK_TFLOPS * clk / 2.4, 1)
+            rf["frac_of_peak_at_sustained_clock"] = round(rf["achieved"] / (X6_EQUIV_PEAK_TFLOPS * clk / 2.4), 4)
+    if (rank == 0 and world == 1 and not dry and args.workload == "C3" and not args.no_sub_workloads and not args.batch
+            and not args.skip_adm and not args.opt):
+        subs = {}
+        for nm, k_, w_ in (("C2", 3, 1), ("C1", 5, 2), ("C5", 2, 1)):
+            try:
+                subs[nm] = sub_workload(model, (g, p, a, h), nm, k_, w_, dev)
+            except Exception as e:
+                subs[nm] = {"error": str(e)[:200]}
+        result["workloads"] = subs
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         # the oracle (a port of the reference path; dense primitives on ATen = the kernels the reference itself
         # dispatches to) on the utterances of the same workload for up to ~25 s, in its own process with a hard limit.
@@ -373,7 +461,7 @@ def main() -> None:
         import subprocess
         threads = min(os.cpu_count() or 1, 16)
         cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", args.workload,
-               "--threads", str(threads), "--budget", "25", "--max-utts", "32"]
+               "--threads", str(threads), "--budget", "20", "--max-utts", "32", "--min-utts", "3"]
         base = None
         for backend, limit in (("aten", 150), ("numpy", 240)):
             try:

@@ -1765,8 +1765,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     constexpr int A_IT = (PA + NL - 1) / NL, B_IT = (PB + NL - 1) / NL;   // per loader wave
     constexpr int L = A_IT + B_IT;
     constexpr int STAGE_A = BM * BK * 4, STAGE_B = PB * 1024, STAGE = STAGE_A + STAGE_B;   // bytes
-    static_assert(PA % NL == 0 && PB % NL == 0 && WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64 &&
-                  TM * TN > 1, "config");
+    static_assert(PA % NL == 0 && PB % NL == 0 && WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64, "config");
     // XP (cross-chunk prefetch, 3-deep ring): the loaders run one chunk further ahead (chunks <= c+1 are in LDS at the
     // barrier in front of chunk c, chunk c+2 in flight), so a compute wave fetches and splits the FIRST fragments of chunk
     // c+1 beside the last MFMAs of chunk c - the fetch latency (~400 cycles) and the first split (~270) leave the serial
@@ -2486,6 +2485,12 @@ static const TileCfg kCfgs[] = {
     MT2_WX6L(2, 256, 64, 8, 1, 3, 2),   // 61: 8 + 2
     // v2e: loader waves + de-phased compute groups
     MT2_GX6LD(128, 128, 4, 2, 4),       // 62
+    // v2d, small tiles for launches that cannot fill the chip with 128x128 tiles (the AR steps' mid-size GEMMs): one
+    // 32x32 tile per compute wave, 3-deep ring
+    MT2_GX6L(64, 128, 2, 4, 4, 3),      // 63: 8 + 4 waves, 96 KiB
+    MT2_GX6L(128, 64, 4, 2, 4, 3),      // 64: 8 + 4 waves, 84 KiB (less operand ingest per FLOP than 63: the A panel is the cheap one)
+    MT2_GX6L(64, 128, 2, 4, 2, 3),      // 65: 8 + 2 waves
+    MT2_GX6L(128, 64, 4, 2, 2, 3),      // 66: 8 + 2 waves
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -2628,6 +2633,12 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
         // loader-wave variants (profiles/r02_gemm_sweep_x6_v5_ldr.txt: +10..12 % over 37, +16..20 % over 39)
         if (t256 >= o.t_x6_256) bi = o.x6_loaders ? 51 : 37;
         else if (t128 >= o.t_x6_128) bi = t128 <= o.t_x6_64 ? 49 : (o.x6_loaders ? 55 : 39);
+        // small x6 tiles (x6_small_cfg = 63..66) for launches whose 128x128 tiles would leave most of the chip idle
+        if (o.x6_small_cfg >= 63 && o.x6_small_cfg <= 66 && t256 < o.t_x6_256 && t128 <= o.t_x6_small_max) {
+            const TileCfg& sc = kCfgs[o.x6_small_cfg];
+            const long long ts = (long long)((p.M + sc.bm - 1) / sc.bm) * ((p.N + sc.bn - 1) / sc.bn) * p.groups;
+            if (ts >= o.t_x6_small_min) bi = o.x6_small_cfg;
+        }
     }
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;
     *idx_out = bi;

@@ -239,7 +239,7 @@ def test_window_conv_x6_is_f32_equivalent(rt, k, dil, C, cfg, pro):
     assert rel(x6, f32) < 2e-6
 
 
-@pytest.mark.parametrize("cfg", [37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 62])
+@pytest.mark.parametrize("cfg", [37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 62, 63, 64, 65, 66])
 @pytest.mark.parametrize("M,N,taps,cin,dil", [(300, 512, 1, 256, 1), (77, 96, 1, 104, 1), (1000, 384, 5, 384, 1),
                                                (700, 64, 3, 80, 1), (515, 256, 7, 256, 3), (2240, 4096, 1, 1024, 1)])
 def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):

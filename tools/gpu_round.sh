@@ -87,6 +87,9 @@ prof)
 sweep)
   timeout 900 python tools/gemm_sweep.py > gpurun_out/gemm_sweep.txt 2>&1
   echo "sweep rc=$?"; cat gpurun_out/gemm_sweep.txt ;;
+sweep_x6s)
+  timeout 600 python tools/gemm_sweep.py x6s > gpurun_out/gemm_sweep_x6s.txt 2>&1
+  echo "sweep_x6s rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x6s.txt ;;
 sweep_x6)
   timeout 600 python tools/gemm_sweep.py x6 > gpurun_out/gemm_sweep_x6.txt 2>&1
   echo "sweep_x6 rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x6.txt
@@ -134,11 +137,12 @@ ablate)
   : > gpurun_out/x6_ablate.txt
   timeout 300 python tools/x6_ablate.py prod 2>&1 | grep -v amdgpu.ids >> gpurun_out/x6_ablate.txt
   for v in abl1 abl2 abl3 abl4; do
-    [ -d variants/$v ] && (cd variants/$v && timeout 300 python tools/x6_ablate.py $v 2>&1 | grep -v amdgpu.ids) >> gpurun_out/x6_ablate.txt
+    [ -d variants/$v ] && cp tools/*.py variants/$v/tools/ && (cd variants/$v && timeout 300 python tools/x6_ablate.py $v 2>&1 | grep -v amdgpu.ids) >> gpurun_out/x6_ablate.txt
   done
   echo "ablate rc=$?"; cat gpurun_out/x6_ablate.txt ;;
 clock)
   # phase timer + clock probe (s_memtime vs s_memrealtime) in the MT2_PHASE_TIMING variant
+  cp tools/*.py variants/phase/tools/
   (cd variants/phase && timeout 300 python tools/x6_phase_timing.py ldr && timeout 300 python tools/x6_phase_timing.py f32) > gpurun_out/clock_probe.txt 2>&1
   echo "clock rc=$?"; grep -v amdgpu.ids gpurun_out/clock_probe.txt ;;
 phase)

@@ -10,7 +10,10 @@ rt.device_check()
 LABEL = sys.argv[1] if len(sys.argv) > 1 else "prod"
 CASES = [("big", 4096, 4096, 4096, 1, 51), ("big", 4096, 4096, 4096, 1, 55), ("mrte_stack", 14064, 512, 1536, 3, 51),
          ("plm_ff0", 864, 4096, 1024, 1, 55), ("plm_qkv", 448, 3072, 1024, 1, 55), ("adm_qkv", 1120, 2304, 768, 1, 55),
-         ("adm_out", 2240, 768, 768, 1, 55)]
+         ("adm_out", 2240, 768, 768, 1, 55),
+         # the same tiles with 2 loader waves / a 2-deep ring: does the ingest rate follow the number of issuing waves?
+         ("big", 4096, 4096, 4096, 1, 52), ("big", 4096, 4096, 4096, 1, 54), ("big", 4096, 4096, 4096, 1, 53),
+         ("plm_qkv", 448, 3072, 1024, 1, 54)]
 for name, M, N, K, taps, cfg in CASES:
     ms, cn = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=10, w_copies=2)
     chunks = (K + 31) // 32

@@ -437,11 +437,14 @@ def main() -> None:
                 probes.append({"shape": nm, "error": str(e)[:120]})
         ghz = [q["sustained_ghz"] for q in probes if q.get("sustained_ghz")]
         if ghz:
-            full_chip = [q["sustained_ghz"] for q in probes[:2] if q.get("sustained_ghz")] or ghz
-            clk = sum(full_chip) / len(full_chip)
+            # the power manager needs ~1 ms of continuous load to settle: only the 4096^3 launches (6 x 0.8 ms back to
+            # back) show the steady state a long x6 stage (vocoder, conv stacks) runs at; short launches keep ~1.9-2.0 GHz
+            clk = probes[0].get("sustained_ghz") or min(ghz)
             rf = result["roofline"]
             rf["clock_probe"] = {"method": "s_memtime / s_memrealtime over the K loop of one wave of gemm_x6_ldr_kernel, live in this run",
-                                 "launches": probes, "sustained_ghz_full_chip_x6": round(clk, 3), "max_ghz": 2.4}
+                                 "launches": probes, "sustained_ghz_steady_state_x6": round(clk, 3), "max_ghz": 2.4,
+                                 "note": "steady state = the 4096^3 launches (several ms of continuous x6 load); launches "
+                                         "shorter than the power manager's reaction time stay near 1.9-2.0 GHz"}
             rf["peak_at_sustained_clock"] = round(X6_EQUIV_PEAK_TFLOPS * clk / 2.4, 1)
             rf["frac_of_peak_at_sustained_clock"] = round(rf["achieved"] / (X6_EQUIV_PEAK_TFLOPS * clk / 2.4), 4)
     if (rank == 0 and world == 1 and not dry and args.workload == "C3" and not args.no_sub_workloads and not args.batch

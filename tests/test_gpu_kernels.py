@@ -307,7 +307,7 @@ def test_gemm_x6_corner_cases(rt, cfg):
     ref = Xc.astype(np.float64) @ Wc.T.astype(np.float64)
     big = np.abs(Xc[:, :K // 2].astype(np.float64)) @ np.abs(Wc[:, :K // 2].T.astype(np.float64))     # size of what cancels
     m6, m32 = (np.abs(x6 - ref) / big).max(), (np.abs(f32 - ref) / big).max()
-    assert m6 < 4e-7 and m6 <= 2.0 * m32 + 2e-8, (m6, m32)
+    assert m6 < 1e-6 and m6 <= 2.0 * m32 + 2e-8, (m6, m32)
     # denormal planes: every A element below 2^-118 (second and third plane bf16-denormal)
     for scale in (2.0 ** -112, 2.0 ** -120):
         X = (base * np.float32(scale)).astype(np.float32)

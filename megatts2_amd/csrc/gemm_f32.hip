@@ -1755,7 +1755,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_areg_kernel(GemmP p) {
 // chunk have landed (counted vmcnt), a compute wave once it has finished the previous chunk - then the loaders refill
 // the stage that barrier freed while the compute waves fetch, split and multiply.  Arithmetic, LDS layout and fragment
 // pipeline are gemm_x6_dma_kernel's.
-template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO, bool XP = false>
+// MP (mid-chunk barrier, round 3): profiles/r03_x6_ablate.txt shows a chunk of this kernel costing the SUM of its matrix
+// time and of its serial head (barrier, first fragment fetch at LDS latency, first split): 1 622 ns = 902 (everything but
+// the MFMAs) + 720 (the MFMAs) at 864x4096x1024, with the operand ingest (973 ns alone) hidden.  The head is exposed
+// because every wave meets the barrier with an empty pipeline.  With MP the chunk's ONE barrier sits in the MIDDLE of the
+// chunk - right after the last LDS read of the chunk has been waited for (so the stage is free for the loaders exactly
+// as before) - and the products of every fragment are issued in two halves: the first half covers the LDS latency of the
+// NEXT fragment's fetch (which may be the first fragment of the next chunk: it has landed, the barrier just said so), the
+// second half is interleaved with that fragment's split.  No wave ever waits with the matrix pipe idle except at the
+// barrier itself, where its own MFMAs of the previous half are still draining.  Loader side, ring depth and chunks in
+// flight are unchanged (XP needed the next chunk one barrier earlier and lost a chunk in flight); same arithmetic order.
+template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO, bool XP = false, bool MP = false>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(GemmP p) {
     constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -1771,6 +1781,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     // c+1 beside the last MFMAs of chunk c - the fetch latency (~400 cycles) and the first split (~270) leave the serial
     // phase at the top of every chunk; only the barrier remains there.
     static_assert(!XP || NST == 3, "cross-chunk prefetch needs the 3-deep ring");
+    static_assert(!(XP && MP), "one pipeline form at a time");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ring = reinterpret_cast<char*>(smem);
@@ -1886,7 +1897,9 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     // ---------------------------------------------------------------------- compute wave
     const int wave = wave_all;
     const int wm = wave / WGN, wn = wave % WGN;
-    constexpr bool PRET = TM * TN <= 2;
+    // epilogue operands in flight during the K loop (49 registers) - not in the MP form, whose two fragment sets in
+    // flight need them (its launches - the AR steps' QKV / feed-forward GEMMs, split-K slabs - have no residual operand)
+    constexpr bool PRET = TM * TN <= 2 && !MP;
     EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
     if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 
@@ -2001,6 +2014,86 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
         split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (MP) {
+        constexpr int VPH = (44 + NMF / 2 - 1) / (NMF / 2);        // VALU per MFMA when a split rides on HALF a fragment's products
+        auto half_pattern = [&]() {
+#pragma unroll
+            for (int k = 0; k < NMF / 2; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPH, 0);
+            }
+        };
+        // one chunk; MORE = another chunk follows.  No branch inside: a conditional barrier / prefetch splits the body into
+        // scheduling regions (the split then sinks out of its MFMA group) and makes the register allocator copy the
+        // accumulators between blocks - the last chunk is a second, straight-line instance instead.
+        auto chunk = [&](auto more_tag, unsigned sa, unsigned sb, unsigned san, unsigned sbn) {
+            constexpr bool MORE = decltype(more_tag)::value;
+            fetch(1, sa, sb);                                      // block 1's registers: every reader was issued last chunk
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < F; ++s) {
+                const int b = s / TM, i = s % TM;
+                const int b2 = ((s + 1) / TM) & 1, i2 = (s + 1) % TM;
+                u32x4* nxt = pln[(s + 1) & 1];
+                if (i + 1 < TM) {
+                    // the next fragment belongs to the same k-block: already in registers
+                    tie(b2, i2);
+                    split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, nxt[0], nxt[1], nxt[2]);
+                    products(b, i, pln[s & 1], 0, 6);
+                    pattern(NMF);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (b == 0) {
+                    // last fragment of k-block 0: first half of its products over the LDS latency of block 1, the split of
+                    // block 1's first fragment beside the second half; THEN the chunk's barrier (every LDS read of this
+                    // chunk has been waited for: the stage is free; the next chunk has landed) and the request for the next
+                    // chunk's block 0 into registers whose readers have all been issued
+                    products(b, i, pln[s & 1], 0, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wait_block(1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    split3_bf16<PRO>(ra[1][0][0], ra[1][0][1], pro_slope, nxt[0], nxt[1], nxt[2]);
+                    products(b, i, pln[s & 1], 3, 6);
+                    half_pattern();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (MORE) {
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        fetch(0, san, sbn);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if constexpr (MORE) {
+                    // last fragment of the chunk: the same two halves around the next chunk's first fragment
+                    products(b, i, pln[s & 1], 0, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wait_block(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, nxt[0], nxt[1], nxt[2]);
+                    products(b, i, pln[s & 1], 3, 6);
+                    half_pattern();
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    products(b, i, pln[s & 1], 0, 6);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        // prologue: chunk 0 has landed (barrier #0); its first fragment is the only one fetched and split in the open
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        fetch(0, a_lane, b_lane);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_block(0);
+        __builtin_amdgcn_sched_barrier(0);
+        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c + 1 < nk; ++c) {
+            const int stn = st + 1 == NST ? 0 : st + 1;
+            chunk(std::true_type{}, a_lane + (unsigned)st * STAGE, b_lane + (unsigned)st * STAGE,
+                  a_lane + (unsigned)stn * STAGE, b_lane + (unsigned)stn * STAGE);
+            st = stn;
+        }
+        chunk(std::false_type{}, a_lane + (unsigned)st * STAGE, b_lane + (unsigned)st * STAGE, 0u, 0u);
+    } else
     for (int c = 0; c < nk; ++c) {
         const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
         const int stn = st + 1 == NST ? 0 : st + 1;
@@ -2399,6 +2492,12 @@ struct TileCfg {
       "x6ldrx" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s3",                                                      \
       { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_NONE, true>, gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_RELU, true>, \
         gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_LRELU, true>, nullptr, nullptr }, 0, true }
+#define MT2_GX6LM(BM_, BN_, WM_, WN_, NL_, NST_)                                                               \
+    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),       \
+      "x6ldm" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
+      { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, false, true>,                                   \
+        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, false, true>,                                   \
+        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, false, true>, nullptr, nullptr }, 0, true }
 #define MT2_GX6LD(BM_, BN_, WM_, WN_, NL_)                                                                     \
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)3 * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),          \
       "x6ldrd" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s3",                                                      \
@@ -2491,6 +2590,12 @@ static const TileCfg kCfgs[] = {
     MT2_GX6L(128, 64, 4, 2, 4, 3),      // 64: 8 + 4 waves, 84 KiB (less operand ingest per FLOP than 63: the A panel is the cheap one)
     MT2_GX6L(64, 128, 2, 4, 2, 3),      // 65: 8 + 2 waves
     MT2_GX6L(128, 64, 4, 2, 2, 3),      // 66: 8 + 2 waves
+    // v2f: loader waves + mid-chunk barrier (MP): fragment fetch and split never wait with an empty matrix pipe
+    MT2_GX6LM(128, 128, 4, 2, 4, 3),    // 67: the 55 tile
+    MT2_GX6LM(256, 128, 4, 2, 4, 2),    // 68: the 51 tile
+    MT2_GX6LM(128, 64, 4, 2, 4, 3),     // 69: the 64 tile
+    MT2_GX6LM(64, 128, 2, 4, 4, 3),     // 70: the 63 tile
+    MT2_GX6LM(128, 128, 4, 2, 4, 2),    // 71: 128x128 with a 2-deep ring (80 KiB)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -2639,6 +2744,8 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
             const long long ts = (long long)((p.M + sc.bm - 1) / sc.bm) * ((p.N + sc.bn - 1) / sc.bn) * p.groups;
             if (ts >= o.t_x6_small_min) bi = o.x6_small_cfg;
         }
+        // MP form of the loader-wave tiles (mid-chunk barrier, fragment fetch / split behind the previous products)
+        if (o.x6_mp) bi = bi == 55 ? 67 : (bi == 51 && o.x6_mp >= 2 ? 68 : (bi == 64 ? 69 : (bi == 63 ? 70 : bi)));
     }
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;
     *idx_out = bi;

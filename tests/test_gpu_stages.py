@@ -43,6 +43,11 @@ def model(kind):
         (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models(kind)
         tts = M.Megatts(models=(M.MegaG(g, sd_g), M.MegaPLM(p, sd_p), M.MegaADM(a, sd_a)),
                         hifi_gan=M.HIFIGAN(h, sd_h))
+        # MT2_TEST_OPTS="x6_mp=1,x6_small_cfg=64": run the whole parity suite under non-default engine options (A/B of a
+        # candidate default before it is made one - every discrete output must stay bit-exact under it)
+        for kv in filter(None, os.environ.get("MT2_TEST_OPTS", "").split(",")):
+            k, v = kv.split("=")
+            tts.native.set_option(k, int(v))
         _MODELS[kind] = tts
     return _MODELS[kind]
 

@@ -19,6 +19,13 @@ tests)
   echo "kernels rc=$?"; tail -3 gpurun_out/kernels.log
   timeout 1500 python -m pytest tests/test_gpu_stages.py -m gpu -q --no-header -p no:cacheprovider --maxfail=40 -rf > gpurun_out/stages.log 2>&1
   echo "stages rc=$?"; tail -6 gpurun_out/stages.log ;;
+tests_opts)
+  # the stage parity suite under candidate engine options: TEST_OPTS="x6_mp=1,x6_small_cfg=64"
+  MT2_TEST_OPTS="$TEST_OPTS" timeout 1500 python -m pytest tests/test_gpu_stages.py -m gpu -q --no-header -p no:cacheprovider --maxfail=40 -rf -k "${TEST_K:-prod or tiny_end_to_end or ragged}" > gpurun_out/stages_opts.log 2>&1
+  echo "stages under $TEST_OPTS rc=$?"; tail -6 gpurun_out/stages_opts.log ;;
+ktests)
+  timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -q --no-header -p no:cacheprovider --maxfail=40 -rf -k "${TEST_K:-x6}" > gpurun_out/kernels.log 2>&1
+  echo "kernels rc=$?"; tail -4 gpurun_out/kernels.log ;;
 smoke)
   timeout 600 python -c "import __graft_entry__ as g; g.build(); g.smoke()" > gpurun_out/smoke.log 2>&1
   echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log ;;

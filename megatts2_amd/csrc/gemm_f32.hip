@@ -2028,8 +2028,10 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
         // accumulators between blocks - the last chunk is a second, straight-line instance instead.
         auto chunk = [&](auto more_tag, unsigned sa, unsigned sb, unsigned san, unsigned sbn) {
             constexpr bool MORE = decltype(more_tag)::value;
+            MT2_T(5);                                              // (loop overhead)
             fetch(1, sa, sb);                                      // block 1's registers: every reader was issued last chunk
             __builtin_amdgcn_sched_barrier(0);
+            MT2_T(2);                                              // fetch issue
 #pragma unroll
             for (int s = 0; s < F; ++s) {
                 const int b = s / TM, i = s % TM;
@@ -2049,28 +2051,36 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
                     // chunk's block 0 into registers whose readers have all been issued
                     products(b, i, pln[s & 1], 0, 3);
                     __builtin_amdgcn_sched_barrier(0);
+                    MT2_T(3);                                      // first half of the products (MFMA issue)
                     wait_block(1);
                     __builtin_amdgcn_sched_barrier(0);
+                    MT2_T(0);                                      // LDS wait left over behind them
                     split3_bf16<PRO>(ra[1][0][0], ra[1][0][1], pro_slope, nxt[0], nxt[1], nxt[2]);
                     products(b, i, pln[s & 1], 3, 6);
                     half_pattern();
                     __builtin_amdgcn_sched_barrier(0);
+                    MT2_T(4);                                      // split beside the second half
                     if constexpr (MORE) {
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
+                        MT2_T(1);                                  // barrier
                         fetch(0, san, sbn);
                         __builtin_amdgcn_sched_barrier(0);
+                        MT2_T(2);
                     }
                 } else if constexpr (MORE) {
                     // last fragment of the chunk: the same two halves around the next chunk's first fragment
                     products(b, i, pln[s & 1], 0, 3);
                     __builtin_amdgcn_sched_barrier(0);
+                    MT2_T(3);
                     wait_block(0);
                     __builtin_amdgcn_sched_barrier(0);
+                    MT2_T(0);
                     split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, nxt[0], nxt[1], nxt[2]);
                     products(b, i, pln[s & 1], 3, 6);
                     half_pattern();
                     __builtin_amdgcn_sched_barrier(0);
+                    MT2_T(4);
                 } else {
                     products(b, i, pln[s & 1], 0, 6);
                     __builtin_amdgcn_sched_barrier(0);

@@ -143,14 +143,14 @@ ablate)
   # measurement builds made in the build container (tools/build_variant.sh): which resource bounds a chunk of the x6 tile
   : > gpurun_out/x6_ablate.txt
   timeout 300 python tools/x6_ablate.py prod 2>&1 | grep -v amdgpu.ids >> gpurun_out/x6_ablate.txt
-  for v in abl1 abl2 abl3 abl4; do
+  for v in ${ABL_LIST:-abl1 abl2 abl3 abl4}; do
     [ -d variants/$v ] && cp tools/*.py variants/$v/tools/ && (cd variants/$v && timeout 300 python tools/x6_ablate.py $v 2>&1 | grep -v amdgpu.ids) >> gpurun_out/x6_ablate.txt
   done
   echo "ablate rc=$?"; cat gpurun_out/x6_ablate.txt ;;
 clock)
   # phase timer + clock probe (s_memtime vs s_memrealtime) in the MT2_PHASE_TIMING variant
   cp tools/*.py variants/phase/tools/
-  (cd variants/phase && timeout 300 python tools/x6_phase_timing.py ldr && timeout 300 python tools/x6_phase_timing.py f32) > gpurun_out/clock_probe.txt 2>&1
+  (cd variants/phase && for m in ${CLOCK_MODES:-ldr f32}; do timeout 300 python tools/x6_phase_timing.py $m; done) > gpurun_out/clock_probe.txt 2>&1
   echo "clock rc=$?"; grep -v amdgpu.ids gpurun_out/clock_probe.txt ;;
 phase)
   # instrumented build in a scratch copy of the package (the in-tree library stays the production one)

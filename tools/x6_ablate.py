@@ -13,9 +13,12 @@ CASES = [("big", 4096, 4096, 4096, 1, 51), ("big", 4096, 4096, 4096, 1, 55), ("m
          ("adm_out", 2240, 768, 768, 1, 55),
          # the same tiles with 2 loader waves / a 2-deep ring: does the ingest rate follow the number of issuing waves?
          ("big", 4096, 4096, 4096, 1, 52), ("big", 4096, 4096, 4096, 1, 54), ("big", 4096, 4096, 4096, 1, 53),
-         ("plm_qkv", 448, 3072, 1024, 1, 54)]
+         ("plm_qkv", 448, 3072, 1024, 1, 54),
+         # MP form
+         ("big", 4096, 4096, 4096, 1, 67), ("big", 4096, 4096, 4096, 1, 68), ("plm_ff0", 864, 4096, 1024, 1, 67),
+         ("plm_qkv", 448, 3072, 1024, 1, 67), ("plm_qkv", 448, 3072, 1024, 1, 69)]
 for name, M, N, K, taps, cfg in CASES:
-    ms, cn = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=10, w_copies=2)
+    ms, cn, ghz = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=10, w_copies=2, flags=4 | 8)
     chunks = (K + 31) // 32
     print(f"{LABEL:6s} {name:10s} {M}x{N}x{K} {cn}: {ms * 1e3:8.1f} us {2.0 * M * N * K / ms / 1e9:7.1f} TF/s "
-          f"({ms * 1e3 / chunks * 1e3:6.0f} ns per chunk)", flush=True)
+          f"({ms * 1e3 / chunks * 1e3:6.0f} ns per chunk, {ghz:.2f} GHz -> {ms * 1e3 / chunks * ghz * 1e3:6.0f} cycles)", flush=True)

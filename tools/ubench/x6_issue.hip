@@ -27,7 +27,7 @@ __device__ __forceinline__ void split3(const f32x4& lo, const f32x4& hi, u32x4& 
 
 // per 12 MFMAs (two accumulators, as one wave of the 128x128 tile has): NS splits (44 VALU each, interleaved with the
 // MFMAs by the same sched_group_barrier pattern the GEMM uses) and NLDS ds_read_b128 (waited for once per 12 MFMAs)
-template <int NS, int NLDS>
+template <int NS, int NLDS, int PH = 0>
 __global__ void k(float* out, int iters, long long* cyc, long long* real) {
     __shared__ __attribute__((aligned(16))) float lds[16384];
     f32x16 acc0, acc1;
@@ -61,10 +61,15 @@ __global__ void k(float* out, int iters, long long* cyc, long long* real) {
             if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
             else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
         }
+        if (PH == 0) {
 #pragma unroll
-        for (int m = 0; m < 12; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (VPM) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+            for (int m = 0; m < 12; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (VPM) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+            }
+        } else {        // serial phases, as the non-MP GEMM loop: all the VALU first, then the MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x002, 44 * NS + 16, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (NLDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -76,7 +81,12 @@ __global__ void k(float* out, int iters, long long* cyc, long long* real) {
     for (int q = 0; q < 3; ++q) s += lo[q][0] + hi[q][1];
     for (int e = 0; e < 8; ++e) s += r[e][0];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if (threadIdx.x == 0 && blockIdx.x == 0) { *cyc = t1 - t0; *real = w1 - w0; }
+    // the LAST wave to finish counts (issue arbitration favours the oldest wave: it finishes early, the others late)
+    if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) {
+        atomicMax((unsigned long long*)cyc, (unsigned long long)(t1 - t0));
+        atomicMax((unsigned long long*)real, (unsigned long long)(w1 - w0));
+        atomicMin((unsigned long long*)(cyc + 1), (unsigned long long)(t1 - t0));
+    }
 }
 
 // LDS throughput as the x6 tile uses it: NC "compute" waves each issue 8 ds_read_b128 (1 KiB per wave-instruction) and wait,
@@ -132,14 +142,19 @@ template <int NC, int NL, int PIECES> void run_lds(int iters) {
 template <class F> void run(const char* name, F kern, int waves_per_simd, int iters) {
     const int blocks = 256, threads = 256 * waves_per_simd;
     float* out; long long *cyc, *real;
-    hipMalloc(&out, sizeof(float) * blocks * threads); hipMalloc(&cyc, 8); hipMalloc(&real, 8);
-    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out, iters, cyc, real);
-    hipDeviceSynchronize();
-    long long c = 0, r = 0;
-    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(&r, real, 8, hipMemcpyDeviceToHost);
+    hipMalloc(&out, sizeof(float) * blocks * threads); hipMalloc(&cyc, 16); hipMalloc(&real, 8);
+    long long c2[2] = {0, 0}, r = 0;
+    for (int w = 0; w < 2; ++w) {
+        const long long init[2] = {0, 0x7fffffffffffffffll};
+        hipMemcpy(cyc, init, 16, hipMemcpyHostToDevice); hipMemset(real, 0, 8);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out, iters, cyc, real);
+        hipDeviceSynchronize();
+    }
+    hipMemcpy(c2, cyc, 16, hipMemcpyDeviceToHost); hipMemcpy(&r, real, 8, hipMemcpyDeviceToHost);
+    const long long c = c2[0];
     const double mf = 12.0 * iters * waves_per_simd;        // MFMAs issued on one SIMD
-    printf("%-22s waves/SIMD %d: %7.1f cycles per MFMA per SIMD (pipe pace 32), clock %.2f GHz\n", name, waves_per_simd,
-           (double)c / mf, (double)c / ((double)r / 100e6) / 1e9);
+    printf("%-22s waves/SIMD %d: %7.1f cycles per MFMA per SIMD (pipe pace 32; first wave done at %.0f %% of the last), clock %.2f GHz\n",
+           name, waves_per_simd, (double)c / mf, 100.0 * c2[1] / c, (double)c / ((double)r / 100e6) / 1e9);
     hipFree(out); hipFree(cyc); hipFree(real);
 }
 
@@ -153,6 +168,9 @@ int main() {
         run("0 splits + 8 LDS", k<0, 8>, w, iters);
         run("1 split + 8 LDS", k<1, 8>, w, iters);
         run("2 splits + 8 LDS", k<2, 8>, w, iters);
+        run("1 split, serial phases", k<1, 0, 1>, w, iters);
+        run("1 split+8 LDS, serial", k<1, 8, 1>, w, iters);
+        run("2 splits+8 LDS, serial", k<2, 8, 1>, w, iters);
     }
     run_lds<8, 0, 1>(4000);
     run_lds<4, 0, 1>(4000);

@@ -2032,6 +2032,43 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
             fetch(1, sa, sb);                                      // block 1's registers: every reader was issued last chunk
             __builtin_amdgcn_sched_barrier(0);
             MT2_T(2);                                              // fetch issue
+            if constexpr (TM >= 2) {
+                // two or more fragments per k-block: a fetch is always requested a whole fragment (>= 12 MFMAs, ~400 cycles)
+                // before its first use, so the wait costs nothing and EVERY fragment's products carry exactly one split
+                // (1 MFMA : 44 / NMF VALU throughout - profiles/r03_ubench_x6_issue_v2.txt: 35.7 cycles per MFMA for a
+                // lone wave at that mix, 44 at twice the VALU density)
+#pragma unroll
+                for (int s = 0; s < F; ++s) {
+                    const int b = s / TM, i = s % TM;
+                    const int b2 = ((s + 1) / TM) & 1, i2 = (s + 1) % TM;
+                    u32x4* nxt = pln[(s + 1) & 1];
+                    const bool last = s + 1 == F;
+                    if (!last || MORE) {
+                        if (i2 == 0) {                             // the next fragment opens a k-block: its fetch has landed by now
+                            wait_block(b2);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else {
+                            tie(b2, i2);
+                        }
+                        split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, nxt[0], nxt[1], nxt[2]);
+                        products(b, i, pln[s & 1], 0, 6);
+                        pattern(NMF);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        products(b, i, pln[s & 1], 0, 6);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (MORE && s == TM - 1) {
+                        // k-block 0 is done and block 1 has been waited for: every LDS read of this chunk is complete - the
+                        // chunk's barrier (stage free, next chunk landed), then the request for the next chunk's block 0
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        fetch(0, san, sbn);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < F; ++s) {
                 const int b = s / TM, i = s % TM;
@@ -2606,6 +2643,13 @@ static const TileCfg kCfgs[] = {
     MT2_GX6LM(128, 64, 4, 2, 4, 3),     // 69: the 64 tile
     MT2_GX6LM(64, 128, 2, 4, 4, 3),     // 70: the 63 tile
     MT2_GX6LM(128, 128, 4, 2, 4, 2),    // 71: 128x128 with a 2-deep ring (80 KiB)
+    // ONE compute wave per SIMD (64x64 per wave) + 4 loader waves: two barrier-synchronised waves on a SIMD run one after
+    // the other (the matrix pipe's arbiter serves the older wave first, profiles/r03_ubench_x6_issue_v2.txt), each at a
+    // lone wave's efficiency and each with its own exposed head; one wave with twice the tile has the same MFMA count per
+    // SIMD, 37 % less LDS traffic, half the splits per MFMA, and 256 registers for the MP pipeline
+    MT2_GX6LM(128, 128, 2, 2, 4, 3),    // 72: 4 + 4 waves, 120 KiB
+    MT2_GX6LM(128, 128, 2, 2, 2, 3),    // 73: 4 + 2 waves
+    MT2_GX6L(128, 128, 2, 2, 4, 3),     // 74: the same tile without the MP pipeline (A/B)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -2755,7 +2799,8 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
             if (ts >= o.t_x6_small_min) bi = o.x6_small_cfg;
         }
         // MP form of the loader-wave tiles (mid-chunk barrier, fragment fetch / split behind the previous products)
-        if (o.x6_mp) bi = bi == 55 ? 67 : (bi == 51 && o.x6_mp >= 2 ? 68 : (bi == 64 ? 69 : (bi == 63 ? 70 : bi)));
+        if (o.x6_mp == 3) bi = bi == 55 ? 72 : bi;       // one compute wave per SIMD, MP pipeline
+        else if (o.x6_mp) bi = bi == 55 ? 67 : (bi == 51 && o.x6_mp >= 2 ? 68 : (bi == 64 ? 69 : (bi == 63 ? 70 : bi)));
     }
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;
     *idx_out = bi;

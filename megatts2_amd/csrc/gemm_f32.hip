@@ -1765,7 +1765,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_areg_kernel(GemmP p) {
 // second half is interleaved with that fragment's split.  No wave ever waits with the matrix pipe idle except at the
 // barrier itself, where its own MFMAs of the previous half are still draining.  Loader side, ring depth and chunks in
 // flight are unchanged (XP needed the next chunk one barrier earlier and lost a chunk in flight); same arithmetic order.
-template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO, bool XP = false, bool MP = false>
+// FR (free-running compute waves, round 3).  tools/ubench/x6_issue.hip (profiles/r03_ubench_x6_issue_v3_barriers.txt): two
+// waves on a SIMD, each with this loop's instruction mix (12 MFMAs : 1 split : 8 ds_read_b128), keep the matrix pipe at
+// 32.0-35.1 cycles per MFMA when they run FREE - and at 42.9 when they meet at a barrier every 24 MFMAs (= every chunk): the
+// pipe's arbiter serves the older wave first, so after every barrier the two waves run one after the other instead of
+// filling each other's fetch / split phases.  A compute wave never needs its SIMD partner: it needs "chunk c has landed"
+// from the loaders and the loaders need "stage free" from the compute waves.  With FR those two facts travel through LDS
+// counters instead of s_barrier: a loader adds 1 to ready[stage] once its pieces of the chunk have landed (counted vmcnt,
+// then ds_add), a compute wave adds 1 to done[stage] once its last LDS read of the chunk has returned; a compute wave
+// starts chunk c at ready[c % NST] >= NL * (c / NST + 1), a loader refills a stage for chunk cn at done >= NW * (cn / NST).
+// The counters are monotonic (zeroed once per launch), every wait is a bounded spin, the K loop has no s_barrier at all,
+// and the waves drift into the complementary phases the ubench shows.  Arithmetic and its order are unchanged.
+template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO, bool XP = false, bool MP = false, bool FR = false>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(GemmP p) {
     constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -1781,7 +1792,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     // c+1 beside the last MFMAs of chunk c - the fetch latency (~400 cycles) and the first split (~270) leave the serial
     // phase at the top of every chunk; only the barrier remains there.
     static_assert(!XP || NST == 3, "cross-chunk prefetch needs the 3-deep ring");
-    static_assert(!(XP && MP), "one pipeline form at a time");
+    static_assert(!(XP && MP) && !(FR && (XP || MP)), "one pipeline form at a time");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ring = reinterpret_cast<char*>(smem);
@@ -1797,6 +1808,28 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
     const int Kt = p.K;
     const int nk = (Kt + BK - 1) / BK;
+    // FR: ready[NST] | done[NST] behind the ring (LDS byte addresses), zeroed before anything is in flight
+    const unsigned fr_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring + NST * STAGE;
+    if constexpr (FR) {
+        if (tid < 16) reinterpret_cast<unsigned*>(ring + NST * STAGE)[tid] = 0u;
+        __syncthreads();
+    }
+    // counter += 1 from ONE lane, branch-free (a divergent `if (lane == 0)` would cut the K loop into scheduling regions and
+    // the split would leave its MFMA group): exec is narrowed to lane 0 around the ds_add inside one asm statement
+    auto fr_signal = [&](unsigned addr) {
+        unsigned long long keep;
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
+                     : "=&s"(keep) : "v"(addr), "v"(1u) : "memory");
+    };
+    auto fr_wait = [&](unsigned addr, unsigned need, int nap) {      // bounded spin until counter >= need
+#pragma nounroll
+        for (int spin = 0; spin < (1 << 16); ++spin) {      // >= 6 ms before giving up (a real wait is microseconds)
+            unsigned v;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= need) break;
+            if (nap) __builtin_amdgcn_s_sleep(2);
+        }
+    };
 
     if (wave_all >= NW) {
         // ------------------------------------------------------------------ loader wave lw: pieces lw, lw + NL, ...
@@ -1883,6 +1916,17 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
         for (int c = 0; c < nk; ++c) {
             if (!XP && c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();   // this wave's pieces of chunk c have landed
             else wait_vmcnt<0>();                                        // XP: of chunk c+1 as well
+            if constexpr (FR) {
+                fr_signal(fr_base + (unsigned)st * 4u);              // this wave's pieces of chunk c are in LDS
+                const int cn = c + NST - 1, sp = st == 0 ? NST - 1 : st - 1;
+                if (cn < nk) {
+                    // stage sp held chunk c-1 (and cn / NST chunks in all): refill once every compute wave has read it
+                    if (c >= 1) fr_wait(fr_base + (unsigned)(NST + sp) * 4u, (unsigned)(NW * (cn / NST)), 1);
+                    issue(cn, sp);
+                }
+                st = st + 1 == NST ? 0 : st + 1;
+                continue;
+            }
             __builtin_amdgcn_s_barrier();                            // chunk c complete; chunk c-1's stage is free
 #if defined(MT2_ABLATE) && MT2_ABLATE == 2                           // ablation: no operand ingest inside the K loop
             if (c + NST - 1 < nk && c < 1) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
@@ -2014,7 +2058,48 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
         split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
         __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (MP) {
+    if constexpr (FR) {
+        bool landed = false;                           // "the chunk about to start is known to have landed"
+        for (int c = 0; c < nk; ++c) {
+            const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
+            const int stn = st + 1 == NST ? 0 : st + 1;
+            if (!landed) fr_wait(fr_base + (unsigned)st * 4u, (unsigned)(NL * (c / NST + 1)), 0);
+            fetch(0, sa, sb);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_block(0);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch(1, sa, sb);
+            unsigned nflag = 0u;                       // the next chunk's ready counter rides on the same LDS wait
+            asm volatile("ds_read_b32 %0, %1" : "=v"(nflag) : "v"(fr_base + (unsigned)stn * 4u) : "memory");
+            split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < F; ++s) {
+                const int b = s / TM, i = s % TM;
+                if (s + 1 < F) {
+                    const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
+                    if (b2 != b) {
+                        wait_block(b2);                // the last LDS read of this chunk has returned:
+                        asm volatile("" : "+v"(nflag));
+                        __builtin_amdgcn_sched_barrier(0);
+                        fr_signal(fr_base + (unsigned)(NST + st) * 4u);        // the stage may be refilled
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        tie(b2, i2);
+                    }
+                    split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
+                    products(b, i, pln[s & 1], 0, 6);
+                    pattern(NMF);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    products(b, i, pln[s & 1], 0, 6);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            landed = (unsigned)__builtin_amdgcn_readfirstlane((int)nflag) >= (unsigned)(NL * ((c + 1) / NST + 1));
+            st = stn;
+        }
+    } else if constexpr (MP) {
         constexpr int VPH = (44 + NMF / 2 - 1) / (NMF / 2);        // VALU per MFMA when a split rides on HALF a fragment's products
         auto half_pattern = [&]() {
 #pragma unroll
@@ -2545,6 +2630,12 @@ struct TileCfg {
       { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, false, true>,                                   \
         gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, false, true>,                                   \
         gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, false, true>, nullptr, nullptr }, 0, true }
+#define MT2_GX6LF(BM_, BN_, WM_, WN_, NL_, NST_)                                                               \
+    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024) + 64,  \
+      "x6ldf" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
+      { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, false, false, true>,                            \
+        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, false, false, true>,                            \
+        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, false, false, true>, nullptr, nullptr }, 0, true }
 #define MT2_GX6LD(BM_, BN_, WM_, WN_, NL_)                                                                     \
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)3 * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),          \
       "x6ldrd" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s3",                                                      \
@@ -2650,6 +2741,11 @@ static const TileCfg kCfgs[] = {
     MT2_GX6LM(128, 128, 2, 2, 4, 3),    // 72: 4 + 4 waves, 120 KiB
     MT2_GX6LM(128, 128, 2, 2, 2, 3),    // 73: 4 + 2 waves
     MT2_GX6L(128, 128, 2, 2, 4, 3),     // 74: the same tile without the MP pipeline (A/B)
+    // v2g: loader waves + FREE-RUNNING compute waves (LDS counters instead of s_barrier in the K loop)
+    MT2_GX6LF(128, 128, 4, 2, 4, 3),    // 75: the 55 tile
+    MT2_GX6LF(256, 128, 4, 2, 4, 2),    // 76: the 51 tile
+    MT2_GX6LF(128, 64, 4, 2, 4, 3),     // 77: the 64 tile
+    MT2_GX6LF(128, 128, 4, 2, 2, 3),    // 78: 55 with 2 loader waves
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -2799,7 +2895,9 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
             if (ts >= o.t_x6_small_min) bi = o.x6_small_cfg;
         }
         // MP form of the loader-wave tiles (mid-chunk barrier, fragment fetch / split behind the previous products)
-        if (o.x6_mp == 3) bi = bi == 55 ? 72 : bi;       // one compute wave per SIMD, MP pipeline
+        if (o.x6_mp == 4) bi = bi == 55 ? 75 : (bi == 64 ? 77 : bi);                       // free-running compute waves
+        else if (o.x6_mp == 5) bi = bi == 55 ? 75 : (bi == 51 ? 76 : (bi == 64 ? 77 : bi));
+        else if (o.x6_mp == 3) bi = bi == 55 ? 72 : bi;       // one compute wave per SIMD, MP pipeline
         else if (o.x6_mp) bi = bi == 55 ? 67 : (bi == 51 && o.x6_mp >= 2 ? 68 : (bi == 64 ? 69 : (bi == 63 ? 70 : bi)));
     }
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;

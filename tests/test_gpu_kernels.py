@@ -239,7 +239,7 @@ def test_window_conv_x6_is_f32_equivalent(rt, k, dil, C, cfg, pro):
     assert rel(x6, f32) < 2e-6
 
 
-@pytest.mark.parametrize("cfg", [37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74])
+@pytest.mark.parametrize("cfg", [37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78])
 @pytest.mark.parametrize("M,N,taps,cin,dil", [(300, 512, 1, 256, 1), (77, 96, 1, 104, 1), (1000, 384, 5, 384, 1),
                                                (700, 64, 3, 80, 1), (515, 256, 7, 256, 3), (2240, 4096, 1, 1024, 1)])
 def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
@@ -269,7 +269,7 @@ def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
     assert not x6[valid == 0].any()
 
 
-@pytest.mark.parametrize("cfg", [51, 55, 39, 67, 69, 72])
+@pytest.mark.parametrize("cfg", [51, 55, 39, 67, 69, 72, 75])
 def test_gemm_x6_corner_cases(rt, cfg):
     """Documented corner behaviour of the 3-plane split (DESIGN 4.2 "Corner cases"), against the f32-MFMA kernel and float64:
       * magnitudes 1e+30 / 1e-30 (all three planes normal bf16 numbers): f32-equivalent like any other input, and the

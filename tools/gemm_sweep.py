@@ -24,7 +24,7 @@ if mode == "vocx":     # the vocoder's real launches: dilation, leaky-ReLU prolo
             print(f"{name} dil={dil} prologue={flags & 1} epilogue={flags >> 1}: {cn} {ms * 1e3:.1f} us {2.0 * M * N * K / ms / 1e9:.1f} TF/s", flush=True)
     sys.exit(0)
 if mode == "x6":       # the bf16-pipe (f32-equivalent) configurations against their f32 counterparts
-    cfgs = [16, 51, 68, 55, 67, 72, 74]
+    cfgs = [16, 51, 68, 76, 55, 75, 72]
     shapes = [("mrte_stack", 14064, 512, 1536, 3), ("decoder", 13858, 512, 2560, 5), ("vqpe", 13858, 384, 1920, 5),
               ("hifi_s1", 111000, 256, 1792, 7), ("hifi_s1k11", 111000, 256, 2816, 11),
               ("plm_ff0", 1728, 4096, 1024, 1), ("plm_ff0", 864, 4096, 1024, 1), ("plm_ff0", 432, 4096, 1024, 1),
@@ -33,7 +33,7 @@ if mode == "x6":       # the bf16-pipe (f32-equivalent) configurations against t
               ("adm_qkv", 1120, 2304, 768, 1), ("adm_ff0", 2240, 1024, 768, 1), ("adm_out", 2240, 768, 768, 1),
               ("big", 4096, 4096, 4096, 1)]
 elif mode == "x6s":    # under-filled AR launches: the 128x128 loader tile against the small loader tiles and the f32 K-split tiles
-    cfgs = [55, 67, 72, 73, 74, 64, 69, 20, 22]
+    cfgs = [55, 75, 78, 72, 64, 77, 20, 22]
     shapes = [("plm_qkv", 224, 3072, 1024, 1), ("plm_qkv", 448, 3072, 1024, 1), ("plm_qkv", 864, 3072, 1024, 1),
               ("plm_ff0", 224, 4096, 1024, 1), ("plm_ff0", 448, 4096, 1024, 1), ("plm_ff0", 864, 4096, 1024, 1),
               ("plm_ff1", 448, 1024, 4096, 1), ("plm_out", 448, 1024, 1024, 1), ("plm_out", 864, 1024, 1024, 1),

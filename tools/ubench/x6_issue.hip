@@ -27,7 +27,7 @@ __device__ __forceinline__ void split3(const f32x4& lo, const f32x4& hi, u32x4& 
 
 // per 12 MFMAs (two accumulators, as one wave of the 128x128 tile has): NS splits (44 VALU each, interleaved with the
 // MFMAs by the same sched_group_barrier pattern the GEMM uses) and NLDS ds_read_b128 (waited for once per 12 MFMAs)
-template <int NS, int NLDS, int PH = 0>
+template <int NS, int NLDS, int PH = 0, int BAR = 0>     // BAR: s_barrier every BAR iterations (0: the waves run free)
 __global__ void k(float* out, int iters, long long* cyc, long long* real) {
     __shared__ __attribute__((aligned(16))) float lds[16384];
     f32x16 acc0, acc1;
@@ -74,6 +74,7 @@ __global__ void k(float* out, int iters, long long* cyc, long long* real) {
         __builtin_amdgcn_sched_barrier(0);
         if (NLDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        if (BAR && (it % BAR) == BAR - 1) __builtin_amdgcn_s_barrier();
     }
     const long long t1 = __builtin_readcyclecounter(), w1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
@@ -168,6 +169,11 @@ int main() {
         run("0 splits + 8 LDS", k<0, 8>, w, iters);
         run("1 split + 8 LDS", k<1, 8>, w, iters);
         run("2 splits + 8 LDS", k<2, 8>, w, iters);
+        run("1sp+8LDS, barrier/24", k<1, 8, 0, 2>, w, iters);
+        run("1sp+8LDS ser, bar/24", k<1, 8, 1, 2>, w, iters);
+        run("1sp+8LDS, barrier/12", k<1, 8, 0, 1>, w, iters);
+        run("1sp+8LDS ser, bar/12", k<1, 8, 1, 1>, w, iters);
+        run("1sp+8LDS, barrier/96", k<1, 8, 0, 8>, w, iters);
         run("1 split, serial phases", k<1, 0, 1>, w, iters);
         run("1 split+8 LDS, serial", k<1, 8, 1>, w, iters);
         run("2 splits+8 LDS, serial", k<2, 8, 1>, w, iters);

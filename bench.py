@@ -174,6 +174,12 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="C3", choices=["C1", "C2", "C3", "C5"])
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default: the workload's)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --batch utterances per GPU; strong: BASELINE configs[3] - ONE fixed set of 256 "
+                         "utterances (C4) LPT-sharded over the N ranks (megatts2_amd/dist.py), total work fixed as N grows")
+    ap.add_argument("--jitter", type=float, default=None,
+                    help="utterance lengths scaled by U(1 - jitter, 1): ragged batches (default 0 for weak, 0.3 for strong, "
+                         "where it is what makes the shard balance `slowest_over_mean` mean something)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-workloads", action="store_true",
                     help="default C3 run only: skip the C2 / C1 / C5 sub-results (`workloads` in the JSON line)")
@@ -246,15 +252,39 @@ def main() -> None:
             model.set_option("stage_markers", 1)
 
     shape = synth.SHAPES[args.workload]
-    B = args.batch or shape.B
-    utts = synth.make_batch(shape, seed=1000 + int(args.workload[1]) + 17 * rank, batch=B)
-    Np, Tp = shape.Np, shape.Tp
-    phone = torch.from_numpy(np.stack([u.phone for u in utts])).to(dev)
-    mel_in = torch.from_numpy(np.stack([u.prompt_mel for u in utts])).to(dev)
-    dur = np.stack([u.durations for u in utts]).astype(np.int32)
-    codes = None if full else torch.from_numpy(np.stack([u.p_codes for u in utts])).to(dev)
-    pl = np.full(B, Np, np.int32)
-    ml = np.full(B, Tp, np.int32)
+    strong = args.scaling == "strong"
+    jitter = args.jitter if args.jitter is not None else (0.3 if strong else 0.0)
+    shard_info = None
+    if strong:
+        # BASELINE configs[3]: the SAME 256 utterances whatever N is (seeded identically on every rank), sharded by the LPT
+        # bin packing of dist.shard_utterances on the per-utterance cost model; this rank synthesizes its shard only
+        shape4 = synth.SHAPES["C4"]
+        everything = synth.make_batch(shape4, seed=1004, jitter=jitter, batch=args.batch or shape4.B)
+        from megatts2_amd.dist import shard_utterances
+        costs_all = [utterance_cost(u.phone.size, u.prompt_mel.shape[0], int(u.durations.sum())) for u in everything]
+        shards = shard_utterances(costs_all, world)
+        utts = [everything[i] for i in shards[rank]]
+        shard_info = {"utterances_total": len(everything), "shard_sizes": [len(x) for x in shards],
+                      "lpt_cost_imbalance": round(shard_imbalance(costs_all, shards), 4)}
+        b_cap = max(len(x) for x in shards)
+    else:
+        utts = synth.make_batch(shape, seed=1000 + int(args.workload[1]) + 17 * rank, jitter=jitter, batch=args.batch or shape.B)
+        b_cap = len(utts)
+    B = len(utts)
+
+    def pad_stack(arrs, dtype):
+        n = max(a.shape[0] for a in arrs)
+        out_ = np.zeros((len(arrs), n) + arrs[0].shape[1:], dtype)
+        for i_, a_ in enumerate(arrs):
+            out_[i_, :a_.shape[0]] = a_
+        return out_
+    Np, Tp = max(u.phone.size for u in utts), max(u.prompt_mel.shape[0] for u in utts)
+    phone = torch.from_numpy(pad_stack([u.phone for u in utts], np.int64)).to(dev)
+    mel_in = torch.from_numpy(pad_stack([u.prompt_mel for u in utts], np.float32)).to(dev)
+    dur = pad_stack([u.durations for u in utts], np.int32)
+    codes = None if full else torch.from_numpy(pad_stack([u.p_codes for u in utts], np.int64)).to(dev)
+    pl = np.asarray([u.phone.size for u in utts], np.int32)
+    ml = np.asarray([u.prompt_mel.shape[0] for u in utts], np.int32)
     frames_per_step = int(dur.sum())
     stages = [s for s in (STAGES_FULL if full else ["mrte", "adm", "decoder"]) if not (args.skip_adm and s == "adm")
               and not (args.workload == "C1" and s == "vqpe")]
@@ -278,7 +308,7 @@ def main() -> None:
                                      vocoder=full, tm_cap=shape.Tm, skip_adm=args.skip_adm, prompt_vqpe=side)
         mel, lens = out[0], out[1]
         if world > 1 and exchange:   # the path's only exchange: ONE fixed-capacity RCCL all-gather over xGMI, lengths stay on the device
-            mel, lens = gather_mels(mel, lens, b_cap=B, t_cap=shape.Tm, host_lens=False)
+            mel, lens = gather_mels(mel, lens, b_cap=b_cap, t_cap=shape.Tm, host_lens=False)
         return mel, lens
 
     for _ in range(args.warmup):
@@ -316,16 +346,22 @@ def main() -> None:
     result = {
         "metric": "mel-frames/sec (whole node)", "value": round(value, 1), "unit": "mel-frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
         "dtype_detail": "f32 storage and accumulation; products on v_mfma_f32_32x32x2_f32 or, f32-equivalent, as six bf16 MFMAs of exactly split operands",
         "data": "synthetic",
-        "config": {"workload": f"{args.workload}: B={B}/GPU x {world} GPU, Np={Np}, Tp={Tp}, Tm={shape.Tm}; stages "
+        "config": {"workload": (f"C4 strong scaling: {shard_info['utterances_total']} utterances LPT-sharded over {world} GPU, "
+                                 f"lengths U({1 - jitter:.2f}, 1) x (Np={shape.Np}, Tp={shape.Tp}, Tm={shape.Tm}); stages "
+                                 if strong else
+                                 f"{args.workload}: B={B}/GPU x {world} GPU, Np={Np}, Tp={Tp}, Tm={shape.Tm}"
+                                 + (f", lengths U({1 - jitter:.2f}, 1)" if jitter else "") + "; stages ")
                                + "+".join(stages) + "; forced durations" + ("" if full else " and prosody codes"),
                    "frames_per_step": int(total_frames), "weights": "synthetic (name-seeded)", "parallelism":
                    f"dp{world} (utterance shards, one RCCL all-gather of mels per step)"},
         "rtf": {"sr16000": round(elapsed / args.steps / (total_frames * 256 / 16000), 6),
                 "sr22050": round(elapsed / args.steps / (total_frames * 256 / 22050), 6)},
     }
+    if shard_info:
+        result["strong_scaling"] = shard_info
     if world > 1:
         costs = [utterance_cost(u.phone.size, u.prompt_mel.shape[0], int(u.durations.sum())) for u in utts]
         result["multi_gpu"] = {"per_rank_ms_per_step": rank_ms, "slowest_over_mean": round(max(rank_ms) / (sum(rank_ms) / world), 4),

@@ -2895,6 +2895,7 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
             if (ts >= o.t_x6_small_min) bi = o.x6_small_cfg;
         }
         // MP form of the loader-wave tiles (mid-chunk barrier, fragment fetch / split behind the previous products)
+        if (o.x6_mp256 && bi == 51) bi = 68;             // MP form of the 256x128 tile only (+2..7 % on the conv-stack shapes)
         if (o.x6_mp == 4) bi = bi == 55 ? 75 : (bi == 64 ? 77 : bi);                       // free-running compute waves
         else if (o.x6_mp == 5) bi = bi == 55 ? 75 : (bi == 51 ? 76 : (bi == 64 ? 77 : bi));
         else if (o.x6_mp == 3) bi = bi == 55 ? 72 : bi;       // one compute wave per SIMD, MP pipeline

@@ -307,9 +307,63 @@ def make_prod_c5_utterance() -> None:
           "adm float nearest to .5:", np.abs((out["adm_float"] + 0.5) % 1.0).min())
 
 
+# ------------------------------------------------------------------------------------------------
+# prompt-conditioned synthesis (row f1, `python oracle/make_golden.py --extra-prompted`): the training layout of
+# modules/datamodule.py:161-177,196-212 run at inference through the LIVE reference modules - prompt tc_latents
+# (length-regulated by the prompt's durations, max-pooled) and prompt VQ-PE codes in front, greedy decoding from there.
+
+def make_prompted(kind: str, seed: int, n_ph: int, n_pp: int, n_pr: int, n_fr: int) -> None:
+    ref = ref_shim.load()
+    from modules.mrte import LengthRegulator
+    G, plm, adm, sd_g, sd_p, sd_a = build_reference(kind)
+    g = cfgs(kind)[0]
+    install_codebook(G, sd_g, np.load(os.path.join(GOLDEN, f"codebook_{kind}.npy")))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    utt = synth.make_utterance(rng, n_ph, n_pr, n_fr, g.mrte.phone_vocab_size, g.mrte.mel_bins, g.vqpe.vq_bins)
+    pphone = rng.integers(0, g.mrte.phone_vocab_size, n_pp, dtype=np.int64)
+    pdur = synth.forced_durations(n_pp, n_pr)
+    out = {"phone": utt.phone, "prompt_mel": utt.prompt_mel, "forced_dur": utt.durations, "prompt_phone": pphone,
+           "prompt_dur": pdur}
+    lr = LengthRegulator(256, 16000, 16.0)
+    with torch.no_grad():
+        mel = torch.from_numpy(utt.prompt_mel)[None]
+        tc_p = G.mrte.tc_latent(torch.from_numpy(pphone)[None], mel)
+        cond_p = F.max_pool1d(lr(tc_p, torch.from_numpy(pdur)[None]).transpose(1, 2), 8, ceil_mode=True).transpose(1, 2)
+        _, _, _, codes_p = G.vqpe(mel)                                              # models/megatts2.py:82
+        codes_p = codes_p[0, 0]
+        assert cond_p.shape[1] == codes_p.shape[0]
+        tc = G.mrte.tc_latent(torch.from_numpy(utt.phone)[None], mel)
+        dt = adm.infer(tc)[..., 0]
+        tc_expand = lr(tc, torch.from_numpy(utt.durations)[None])
+        cond_t = F.max_pool1d(tc_expand.transpose(1, 2), 8, ceil_mode=True).transpose(1, 2)
+        cond = torch.cat([cond_p, cond_t], dim=1)
+        P, TQ = cond_p.shape[1], cond_t.shape[1]
+        p_code = torch.cat([torch.tensor([1024]), codes_p])[None]                   # BOS, then the prompt's codes (:208-209)
+        for t in range(P, P + TQ):                                                  # models/megatts2.py:172-179
+            pc_emb = plm.pc_embedding(p_code)
+            x_pos = plm.pos(torch.cat([cond[:, 0:t + 1, :], pc_emb], dim=-1))
+            logits = plm.predict_layer(plm.plm(x_pos))[:, -1:, :]
+            p_code = torch.cat([p_code, logits.argmax(dim=-1)], dim=1)
+        codes = p_code[:, 1 + P:]
+        zq = G.vqpe.vq.decode(codes.unsqueeze(0)).transpose(1, 2).unsqueeze(2).contiguous().expand(-1, -1, 8, -1)
+        zq = zq.reshape(zq.shape[0], -1, zq.shape[-1])
+        x = torch.cat([tc_expand, zq[:, :tc_expand.shape[1], :]], dim=-1)
+        out["mel"] = G.decoder(x.transpose(1, 2))[0].transpose(0, 1).numpy()
+    out["adm_dur"] = dt[0].numpy().astype(np.int32)
+    out["prompt_codes"] = codes_p.numpy()
+    out["prompt_cond"] = cond_p[0].numpy()
+    out["p_codes"] = codes[0].numpy()
+    np.savez_compressed(os.path.join(GOLDEN, f"{kind}_prompted.npz"), **out)
+    print(kind, "prompted", {k: v.shape for k, v in out.items()}, "codes", out["p_codes"][:10], "prompt codes", out["prompt_codes"][:8])
+
+
 def main() -> None:
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
+    if "--extra-prompted" in sys.argv:
+        make_prompted("tiny", 7007, 9, 7, 56, 45)
+        make_prompted("prod", 7008, 42, 30, 256, 200)
+        return
     if "--extra-long" in sys.argv:
         make_prod_c5_utterance()
         return

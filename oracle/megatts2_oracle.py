@@ -534,6 +534,39 @@ def mel_spectrogram(wav: np.ndarray, sample_rate: int = 16000, n_fft: int = 1024
     return np.log(np.maximum(mag @ fb, clip)).astype(F32)
 
 
+def synthesize_prompt_conditioned(sd_g: SD, sd_plm: SD, sd_adm: SD, g_cfg, plm_cfg, adm_cfg, phone: np.ndarray,
+                                  prompt_mel: np.ndarray, prompt_phone: np.ndarray, prompt_durations: Sequence[int],
+                                  forced_durations: Optional[Sequence[int]] = None) -> Dict[str, np.ndarray]:
+    """Synthesis with the PLM conditioned on the PROMPT's prosody: the layout the PLM is trained on
+    (modules/datamodule.py:161-177,196-212) applied at inference.  The prompt utterance contributes
+      * its time-content latents: mrte.tc_latent(prompt_phone, prompt_mel) length-regulated by the prompt's own durations
+        (sum = prompt frames) and max-pooled by 8 (read_latent, :161-177) - P = ceil(Tp / 8) rows in FRONT of the target's;
+      * its prosody codes: VQProsodyEncoder codes of the prompt mel (prepare_ds stage 2: MegaG.s2_latent,
+        models/megatts2.py:75-84) behind the BOS (:208-209).
+    Decoding then continues from position P (models/megatts2.py:165-181 with that history); everything else is
+    Megatts.forward (:353-368)."""
+    out: Dict[str, np.ndarray] = {}
+    tc_p = mrte_tc_latent(sd_g, g_cfg, np.asarray(prompt_phone), prompt_mel)
+    pd = np.asarray(prompt_durations, np.int32)
+    assert int(pd.sum()) == prompt_mel.shape[0], "prompt durations must cover the prompt mel"
+    cond_p = max_pool1d_ceil(length_regulate(tc_p, pd), g_cfg.vqpe.stride)
+    codes_p = vqpe_forward(sd_g, g_cfg, prompt_mel)[1]
+    assert cond_p.shape[0] == codes_p.shape[0]                         # datamodule.py:198,207 asserts
+    out["prompt_cond"], out["prompt_codes"] = cond_p, codes_p
+    tc = mrte_tc_latent(sd_g, g_cfg, phone, prompt_mel)
+    dur, flt = adm_infer(sd_adm, adm_cfg, tc, return_float=True)
+    out["adm_dur"], out["adm_float"] = dur, flt
+    if forced_durations is not None:
+        dur = np.asarray(forced_durations, np.int32)
+    tc_expand = length_regulate(tc, dur)
+    cond_t = max_pool1d_ceil(tc_expand, g_cfg.vqpe.stride)
+    codes, logits = plm_infer(sd_plm, plm_cfg, np.concatenate([cond_p, cond_t], axis=0).astype(F32), return_logits=True,
+                              prefix_codes=codes_p)
+    out["p_codes"], out["plm_logits"] = codes, logits
+    out["mel"] = mel_decoder(sd_g, g_cfg, decoder_input(sd_g, g_cfg, tc_expand, codes))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # optional ATen backend for the dense primitives (timing leg of bench.py's cpu_baseline)
 

@@ -290,3 +290,41 @@ pretrainer: !new:speechbrain.utils.parameter_transfer.Pretrainer
         assert got[k].shape == sd[k].shape and np.abs(got[k] - sd[k]).max() < 1e-6, k
     with pytest.raises(FileNotFoundError):
         weights.load_speechbrain_hifigan(str(tmp_path / "nowhere"))
+
+
+def test_symbol_table_and_phone2token_match_the_reference(tmp_path):
+    """Host glue of Megatts.__init__ / forward (reference utils/symbol_table.py:77-125,280-287, modules/datamodule.py:30-35,
+    65-69): the k2 symbol-table reader and TokensCollector.phone2token - token id = RANK of the symbol among the symbols
+    sorted as strings (<eps> added when the file does not list id 0), whatever ids the file carries.  Against the
+    mapping the reference's own SymbolTable produced for the committed table, and against the live class when present."""
+    import json
+    import sys
+    import torch
+    from megatts2_amd.tokens import SymbolTable, TokensCollector
+    path = os.path.join(ROOT, "tests", "golden", "symbols_small.k2symbols")
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "symbols_small.json"), encoding="utf-8"))
+    st = SymbolTable.from_file(path)
+    assert st.symbols == want["symbols"] and st.eps == want["eps"] and st[0] == "<eps>" and st["zh"] == 3
+    tc = TokensCollector(path)
+    assert tc.token2idx == want["token2idx"]
+    got = tc.phone2token(["sil", "zh", "ang4", "_", "AA0", "sil"])
+    assert got.dtype == torch.int64 and got.tolist() == [7, 8, 5, 3, 1, 7]
+    with pytest.raises(KeyError):
+        tc.phone2token(["sil", "not-a-phone"])
+    for bad in ("a 1\nb\n", "a 1\na 2\n", "a 1\nb 1\n", "a 1 2\n"):          # field count, duplicated symbol / id
+        with pytest.raises(AssertionError):
+            SymbolTable.from_str(bad)
+    named0 = SymbolTable.from_str("<blk> 0\nx 5\n")                              # a file that names id 0 itself
+    assert named0.eps == "<blk>" and named0.symbols == ["<blk>", "x"]
+    if os.path.isdir("/root/reference/utils"):
+        sys.path.insert(0, "/root/reference")
+        try:
+            from utils.symbol_table import SymbolTable as Ref
+            rng = np.random.default_rng(5)
+            syms = sorted({"".join(chr(int(c)) for c in rng.integers(48, 123, rng.integers(1, 5))) for _ in range(200)})
+            ids = rng.permutation(np.arange(1, len(syms) + 1))
+            f = tmp_path / "t.k2symbols"
+            f.write_text("".join(f"{s} {i}\n" for s, i in zip(syms, ids)), encoding="utf-8")
+            assert SymbolTable.from_file(str(f)).symbols == Ref.from_file(str(f)).symbols
+        finally:
+            sys.path.remove("/root/reference")

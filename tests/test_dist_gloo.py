@@ -91,3 +91,31 @@ def test_bench_launch_contract_world2_gloo():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["frames_per_step"] == 2 * 4 * 431     # whole-job frames: both ranks' shards
     assert d["unit"] == "mel-frames/s" and d["higher_is_better"] is True and "DRY RUN" in d["data"]
+
+
+def test_bench_strong_scaling_contract_world2_gloo():
+    """`bench.py --scaling strong` (BASELINE configs[3]): ONE seeded ragged set of utterances LPT-sharded over the ranks -
+    the job's frame total does not depend on N, every utterance is synthesized exactly once, shard sizes differ by <= 1."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    totals = {}
+    for n in (1, 2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        tail = [os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--dry-run-cpu",
+                "--batch", "9", "--scaling", "strong"]
+        cmd = ([sys.executable] + tail) if n == 1 else \
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+             "127.0.0.1", "--master-port", str(port)] + tail
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["scaling"] == "strong" and d["n_gpus"] == n
+        ss = d["strong_scaling"]
+        assert ss["utterances_total"] == 9 and sum(ss["shard_sizes"]) == 9 and max(ss["shard_sizes"]) - min(ss["shard_sizes"]) <= 1
+        assert ss["lpt_cost_imbalance"] >= 1.0
+        totals[n] = d["config"]["frames_per_step"]
+    assert totals[1] == totals[2] and 9 * 431 * 0.7 <= totals[1] <= 9 * 431       # ragged: U(0.7, 1) x 431 frames each

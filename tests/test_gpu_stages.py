@@ -952,3 +952,29 @@ def test_prompt_vqpe_inside_the_synthesis_call(tiny_batch):
     for i, z in enumerate(tiny_batch):
         want = O.vqpe_forward(synth_models("tiny")[1][0], synth_models("tiny")[0][0], z["prompt_mel"])[1]
         assert np.array_equal(auxb["prompt_codes"][i, :want.size].cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("kind", ["tiny", "prod"])
+def test_prompt_conditioned_synthesis_as_one_call(kind):
+    """Row f1 end to end through the mirror: `Megatts.synthesize_prompt_conditioned` (prompt tc_latents length-regulated by
+    the prompt's own durations and max-pooled in front of the target's, the prompt's VQ-PE codes behind the BOS) against
+    the fixture made by the LIVE reference modules - prompt codes, durations and target codes bit-exact, mel 1e-3; and the
+    same utterance twice in one batch."""
+    tts = model(kind)
+    z = load_golden(f"{kind}_prompted.npz")
+    args = (dev(z["phone"][None]), dev(z["prompt_mel"][None]), dev(z["prompt_phone"][None]), z["prompt_dur"][None])
+    mel, lens, aux = tts.synthesize_prompt_conditioned(*args, forced_durations=z["forced_dur"][None], return_aux=True)
+    n = z["mel"].shape[0]
+    assert int(lens[0]) == n
+    assert np.array_equal(aux["prompt_codes"][0].cpu().numpy(), z["prompt_codes"])
+    assert np.array_equal(aux["dur"][0].cpu().numpy(), z["adm_dur"])
+    assert np.array_equal(aux["codes"][0, :z["p_codes"].size].cpu().numpy(), z["p_codes"])
+    assert O.rel_l2(mel[0, :n].cpu().numpy(), z["mel"]) < NORTH_STAR
+    two = [torch.cat([a, a]) if hasattr(a, "shape") and not isinstance(a, np.ndarray) else np.concatenate([a, a]) for a in args]
+    mel2, lens2, aux2 = tts.synthesize_prompt_conditioned(*two, forced_durations=np.concatenate([z["forced_dur"][None]] * 2),
+                                                          return_aux=True)
+    for b in range(2):
+        assert np.array_equal(aux2["codes"][b, :z["p_codes"].size].cpu().numpy(), z["p_codes"])
+        assert O.rel_l2(mel2[b, :n].cpu().numpy(), z["mel"]) < NORTH_STAR
+    with pytest.raises(ValueError, match="sum to the prompt"):
+        tts.synthesize_prompt_conditioned(args[0], args[1], args[2], z["prompt_dur"][None] + 1)

@@ -216,3 +216,24 @@ def test_mel_filterbank_pinned_against_transformers():
                                  max_frequency=fmax, sampling_rate=sr, norm="slaney", mel_scale="slaney")
         got = O.melscale_fbanks(n_freq, fmin, fmax, n_mels, sr)
         assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("kind", ["tiny", "prod"])
+def test_prompt_conditioned_synthesis(kind, tiny, prod):
+    """Row f1: synthesis with the PLM conditioned on the prompt's prosody codes (training layout of the reference,
+    modules/datamodule.py:161-177,196-212, at inference) against the fixture made by the LIVE reference modules
+    (oracle/make_golden.py --extra-prompted): prompt conditioning rows and prompt codes, target codes bit-exact, mel."""
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = tiny if kind == "tiny" else prod
+    z = load_golden(f"{kind}_prompted.npz")
+    if kind == "prod":
+        O.enable_torch_kernels()
+    try:
+        out = O.synthesize_prompt_conditioned(sd_g, sd_p, sd_a, g, p, a, z["phone"], z["prompt_mel"], z["prompt_phone"],
+                                              z["prompt_dur"], forced_durations=z["forced_dur"])
+    finally:
+        O.disable_torch_kernels()
+    assert O.rel_l2(out["prompt_cond"], z["prompt_cond"]) < TOL
+    assert np.array_equal(out["prompt_codes"], z["prompt_codes"])
+    assert np.array_equal(out["adm_dur"], z["adm_dur"])
+    assert np.array_equal(out["p_codes"], z["p_codes"])
+    assert O.rel_l2(out["mel"], z["mel"]) < 1e-3

@@ -56,6 +56,11 @@ typedef struct mt2_config {
     /* speechbrain HifiganGenerator.inference(): the mel is replicate-padded by this many frames on both sides
      * before the generator (hub model: 5), so decode_batch returns (T + 2*pad)*hop samples; 0 = plain forward */
     int32_t hg_inference_padding;
+    /* edge mode of the generator's "same" convolutions (conv_pre, every ResBlock conv, conv_post): 0 = zero padding
+     * (torch nn.Conv1d / transformers.SpeechT5HifiGan), 1 = per-utterance REFLECT padding - speechbrain's
+     * nnet.CNN.Conv1d(padding="same") default padding_mode, what the hub model of the reference
+     * (models/megatts2.py:321-323) is trained and run with.  The transposed convolutions are unaffected. */
+    int32_t hg_reflect_pad;
 } mt2_config;
 
 const char* mt2_last_error(void);

@@ -137,6 +137,9 @@ class HifiGanConfig:
     # sides before forward() (hub model: 5) - decode_batch then returns (T + 2*pad) * hop samples.  0 = plain
     # forward (what transformers.SpeechT5HifiGan, the stand-in oracle, computes).
     inference_padding: int = 0
+    # edge mode of the "same" convolutions: "zeros" (torch / transformers.SpeechT5HifiGan) or "reflect" - the default
+    # padding_mode of speechbrain.nnet.CNN.Conv1d, i.e. what every conv of the speechbrain generator uses
+    pad_mode: str = "zeros"
 
     @property
     def hop(self) -> int:

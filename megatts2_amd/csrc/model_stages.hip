@@ -1042,7 +1042,20 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
     const float slope = cfg.hg_slope;
     long long R = M0.R;
     int ch = cfg.hg_init_channels;
+    // reflect edge mode (speechbrain): the halo rows of every utterance are mirrored into the gap in front of each
+    // "same" convolution; `scale` = output rows per mel frame at the current stage
+    const bool reflect = cfg.hg_reflect_pad != 0;
+    long long scale = 1;
+    auto halo = [&](const Ctx& cc, float* buf, int width, int G) {
+        if (!reflect || G <= 0) return;
+        MT2_REQUIRE(2ll * G <= (long long)M0.G * scale, "reflect padding needs a gap of two halos between utterances");
+        MT2_HIP(launch_fill_reflect(buf, width, width, M0.d_start, M0.d_len, M0.B, scale, G, cc.s));
+    };
     float* x = c.ws.get<float>((size_t)R * ch);
+    if (reflect) {      // conv_pre reads its input in place: mirror the mel rows first (the rows are ours: a packed copy)
+        MT2_REQUIRE((cfg.hg_in_dim & 3) == 0, "reflect padding needs a mel width that is a multiple of 4");
+        halo(c, const_cast<float*>(xmel), cfg.hg_in_dim, (m.hg_pre.k - 1) / 2);
+    }
     conv_same(c, xmel, cfg.hg_in_dim, (int)R, m.hg_pre, x, ch, M0.d_valid);
     const int* valid = M0.d_valid;
     for (int i = 0; i < cfg.hg_n_up; ++i) {
@@ -1063,6 +1076,7 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
         MT2_HIP(launch_expand_mask(valid, s, v2, R * s, c.s));
         valid = v2;
         R *= s;
+        scale *= s;
         ch = co;
         // multi-receptive-field fusion: mean of the resblocks (ResBlock1: x += conv2(lrelu(conv1(lrelu(x)))) x3)
         // The three resblocks of a stage only share their input: each runs on its own stream (the caller's + two
@@ -1072,6 +1086,11 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
         MT2_REQUIRE(cfg.hg_n_res == 3, "HiFi-GAN V1 uses three resblocks per stage");
         const int nside = m.opts.voc_streams > 1 ? 2 : 0;
         ensure_aux(m, nside);
+        if (reflect) {     // the three chains share `up`: one halo wide enough for the widest first convolution, before the fork
+            int g0 = 0;
+            for (int j = 0; j < 3; ++j) g0 = std::max(g0, (m.hg_res[i * 3 + j].k - 1) / 2 * m.hg_res[i * 3 + j].dil[0]);
+            halo(c, up, ch, g0);
+        }
         if (nside) {
             MT2_HIP(hipEventRecord(m.ev_fork, c.s));
             m.aux_forked = true;
@@ -1089,7 +1108,9 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
                 float* out = n == 2 ? rb[j] : (n == 0 ? ha : hb);
                 // x + conv2(lrelu(conv1(lrelu(x)))): the inner leaky ReLU has ONE consumer, so it is applied once in
                 // conv1's epilogue instead of on every operand fragment of conv2 (same values, no VALU in that loop)
+                if (n > 0) halo(cj, const_cast<float*>(h), ch, (r.k - 1) / 2 * r.dil[n]);
                 conv_same(cj, h, ch, (int)R, r.c1[n], t1, ch, valid, ACT_LRELU, slope, ACT_LRELU, nullptr, 0, r.dil[n]);
+                halo(cj, t1, ch, (r.k - 1) / 2);
                 conv_same(cj, t1, ch, (int)R, r.c2[n], out, ch, valid, ACT_NONE, slope, ACT_NONE, h, ch, 1);
                 h = out;
             }
@@ -1098,7 +1119,7 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
             MT2_HIP(hipEventRecord(m.ev_join[j], m.aux_streams[j]));
             MT2_HIP(hipStreamWaitEvent(c.s, m.ev_join[j], 0));
         }
-        if (i + 1 == cfg.hg_n_up && m.hg_post.cout == 1 && (ch & 3) == 0 && ch <= 128 && m.hg_post.k <= 15) {
+        if (!reflect && i + 1 == cfg.hg_n_up && m.hg_post.cout == 1 && (ch & 3) == 0 && ch <= 128 && m.hg_post.k <= 15) {
             // last stage: the mean goes straight into the output layer (one pass over the three resblock outputs)
             // F.leaky_relu default slope 0.01, conv_post k7, tanh
             float* wav = c.ws.get<float>((size_t)R);
@@ -1111,6 +1132,7 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
         MT2_HIP(launch_avg3(rb[0], rb[1], rb[2], 1.0f / 3.0f, x, (long long)per, c.s));
     }
     float* wav = c.ws.get<float>((size_t)R);
+    halo(c, x, ch, (m.hg_post.k - 1) / 2);
     conv_same(c, x, ch, (int)R, m.hg_post, wav, 1, valid, ACT_LRELU, 0.01f, ACT_TANH);
     return wav;
 }

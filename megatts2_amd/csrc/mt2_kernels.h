@@ -210,6 +210,9 @@ hipError_t launch_reflect_pad_blocks(const float* wav, long long wstride, const 
                                      const int* len, int hop, int pad, float* out, int R, hipStream_t s);
 hipError_t launch_magnitude(const float* spec, int lds_, int F, float* out, int ldo, int M, hipStream_t s);
 hipError_t launch_tanh_col(const float* x, int ldx, float* out, long long n, hipStream_t s);
+// reflect halo rows of every utterance (rows start[b]*scale .. +len[b]*scale) in front of a "same" convolution
+hipError_t launch_fill_reflect(float* x, int ld, int C, const int* start, const int* len, int B, long long scale, int G,
+                               hipStream_t s);
 // no-op kernel named mt2::stage_marker_kernel<ID> (ID 0..15): stage boundary in a kernel trace
 hipError_t launch_stage_marker(int id, hipStream_t s);
 

@@ -374,6 +374,32 @@ hipError_t launch_conv_post(const float* x0, const float* x1, const float* x2, f
     return hipGetLastError();
 }
 
+// Reflect halo of every utterance (torch F.pad(mode="reflect"), what speechbrain's Conv1d(padding="same") applies):
+//   x[off - j] = x[off + j],  x[off + L - 1 + j] = x[off + L - 1 - j],  j = 1..G   (rows; off = start * scale, L = len * scale)
+// written into the gap rows in front of / behind the utterance (the gap is >= 2 G, checked by the caller).  A conv kernel
+// that follows reads them as its padding; its own epilogue zeroes the gap rows of its output again (row mask).
+__global__ void fill_reflect_kernel(float* x, int ld, int C, const int* start, const int* len, int B, long long scale, int G) {
+    const int c4n = C >> 2;
+    const long long total = (long long)B * 2 * G * c4n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const long long r = i / c4n;
+        const int j = (int)(r % G) + 1, side = (int)((r / G) & 1), b = (int)(r / (2 * G));
+        const long long off = (long long)start[b] * scale, L = (long long)len[b] * scale;
+        if (j >= L) continue;                                         // torch requires pad < length; nothing to mirror
+        const long long dst = side == 0 ? off - j : off + L - 1 + j, src = side == 0 ? off + j : off + L - 1 - j;
+        *reinterpret_cast<float4*>(x + dst * ld + c) = *reinterpret_cast<const float4*>(x + src * ld + c);
+    }
+}
+hipError_t launch_fill_reflect(float* x, int ld, int C, const int* start, const int* len, int B, long long scale, int G,
+                               hipStream_t s) {
+    if (B <= 0 || G <= 0) return hipSuccess;
+    if (C & 3) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fill_reflect_kernel, row_grid((long long)B * 2 * G * (C >> 2)), dim3(256), 0, s, x, ld, C, start, len,
+                       B, scale, G);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // boundary layout conversion: reference tensors are padded batch-first [B, Tmax, C] (or [B, C, Tmax]
 // for the mel decoder / vocoder, "B D T"); internal rows are packed with gap rows.

@@ -47,6 +47,7 @@ class MT2Config(C.Structure):
         ("hg_slope", C.c_float),
         ("max_positions", C.c_int32),
         ("hg_inference_padding", C.c_int32),
+        ("hg_reflect_pad", C.c_int32),
     ]
 
 
@@ -122,6 +123,7 @@ def make_config(g: Optional[cfgmod.GConfig], plm: Optional[cfgmod.PLMConfig], ad
     c.hg_slope = hg.leaky_relu_slope
     c.max_positions = max_positions
     c.hg_inference_padding = int(getattr(hg, "inference_padding", 0))
+    c.hg_reflect_pad = 1 if getattr(hg, "pad_mode", "zeros") == "reflect" else 0
     return c
 
 

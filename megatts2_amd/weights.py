@@ -315,7 +315,10 @@ def hifigan_config_from_speechbrain(hparams_path: str) -> HifiGanConfig:
         resblock_dilation_sizes=[[int(d) for d in row] for row in
                                  get("resblock_dilation_sizes", [[1, 3, 5], [1, 3, 5], [1, 3, 5]])],
         leaky_relu_slope=0.1,                                  # LRELU_SLOPE constant of speechbrain's HifiGAN.py
-        inference_padding=int(get("inference_padding", 5)))
+        inference_padding=int(get("inference_padding", 5)),
+        # speechbrain.nnet.CNN.Conv1d pads "same" convolutions with padding_mode="reflect" unless told otherwise, and
+        # HifiganGenerator does not override it (hyperparams may carry an explicit padding_mode)
+        pad_mode="zeros" if str(get("padding_mode", "reflect")) in ("zeros", "constant") else "reflect")
 
 
 def fold_weight_norm(g: np.ndarray, v: np.ndarray) -> np.ndarray:

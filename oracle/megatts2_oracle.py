@@ -410,12 +410,28 @@ def mel_decoder(sd: SD, cfg, x: np.ndarray) -> np.ndarray:
 # HiFi-GAN V1 generator (NOT in the reference tree; parity unpinned - see module docstring)
 
 
+def conv1d_same(x: np.ndarray, w: np.ndarray, b, dilation: int = 1, reflect: bool = False) -> np.ndarray:
+    """'same' Conv1d on x[T, Cin] (odd kernel): zero padding (torch nn.Conv1d), or - `reflect` - the input mirrored at
+    both ends first (F.pad(mode="reflect"): x[-j] = x[j], x[T-1+j] = x[T-1-j]), which is what speechbrain's
+    nnet.CNN.Conv1d(padding="same") does with its default padding_mode="reflect"."""
+    g = (w.shape[2] - 1) // 2 * dilation
+    if not reflect or g == 0:
+        return conv1d(x, w, b, padding=g, dilation=dilation)
+    assert g < x.shape[0], "reflect padding must be smaller than the input"
+    xp = np.concatenate([x[g:0:-1], x, x[-2:-g - 2:-1]], axis=0)
+    return conv1d(xp, w, b, padding=0, dilation=dilation)
+
+
 def hifigan(sd: SD, cfg, mel: np.ndarray) -> np.ndarray:
     """mel[T, 80] -> waveform[T * hop].  conv_pre k7; per stage: leaky_relu(0.1) ->
     ConvTranspose1d(k, stride, pad (k-stride)//2) -> mean of ResBlock1(k in {3,7,11}, dil {1,3,5});
     then leaky_relu(0.01 default slope) -> conv_post k7 -> tanh.  Call site in the reference:
-    models/megatts2.py:370 `hifi_gan.decode_batch(x)`."""
+    models/megatts2.py:370 `hifi_gan.decode_batch(x)`.  cfg.pad_mode "reflect": every 'same' convolution mirrors its
+    input at the utterance ends (speechbrain's Conv1d default) instead of zero padding; the transposed convolutions
+    are the same in both modes."""
     slope = cfg.leaky_relu_slope
+    if getattr(cfg, "pad_mode", "zeros") == "reflect":
+        return _hifigan_reflect(sd, cfg, mel)
     x = conv1d(mel.astype(F32), sd["conv_pre.weight"], sd["conv_pre.bias"], padding=3)
     nk = len(cfg.resblock_kernel_sizes)
     for i, (r, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
@@ -436,6 +452,27 @@ def hifigan(sd: SD, cfg, mel: np.ndarray) -> np.ndarray:
         x = (acc / F32(nk)).astype(F32)
     x = leaky_relu(x, 0.01)
     x = conv1d(x, sd["conv_post.weight"], sd["conv_post.bias"], padding=3)
+    return np.tanh(x[:, 0]).astype(F32)
+
+
+def _hifigan_reflect(sd: SD, cfg, mel: np.ndarray) -> np.ndarray:
+    slope = cfg.leaky_relu_slope
+    x = conv1d_same(mel.astype(F32), sd["conv_pre.weight"], sd["conv_pre.bias"], reflect=True)
+    nk = len(cfg.resblock_kernel_sizes)
+    for i, (r, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+        x = leaky_relu(x, slope)
+        x = conv_transpose1d(x, sd[f"upsampler.{i}.weight"], sd[f"upsampler.{i}.bias"], r, (k - r) // 2)
+        acc = None
+        for j, (rk, dils) in enumerate(zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes)):
+            p = f"resblocks.{i * nk + j}"
+            h = x
+            for n, d in enumerate(dils):
+                y = conv1d_same(leaky_relu(h, slope), sd[f"{p}.convs1.{n}.weight"], sd[f"{p}.convs1.{n}.bias"], d, True)
+                y = conv1d_same(leaky_relu(y, slope), sd[f"{p}.convs2.{n}.weight"], sd[f"{p}.convs2.{n}.bias"], 1, True)
+                h = (y + h).astype(F32)
+            acc = h if acc is None else (acc + h).astype(F32)
+        x = (acc / F32(nk)).astype(F32)
+    x = conv1d_same(leaky_relu(x, 0.01), sd["conv_post.weight"], sd["conv_post.bias"], reflect=True)
     return np.tanh(x[:, 0]).astype(F32)
 
 
@@ -618,6 +655,8 @@ def enable_torch_kernels(threads: Optional[int] = None) -> None:
             return Fn.linear(o, t(sd[f"{p}.out_proj.0.weight"]), t(sd[f"{p}.out_proj.0.bias"])).numpy()
 
     def hifigan_t(sd, cfg, mel):
+        if getattr(cfg, "pad_mode", "zeros") == "reflect":
+            return _hifigan_reflect(sd, cfg, mel)
         """The vocoder leg on ATen, channels-first from end to end (what a PyTorch HiFi-GAN module - speechbrain's, or
         transformers.SpeechT5HifiGan, the stand-in of BASELINE.md section 3 - dispatches to): F.conv1d,
         F.conv_transpose1d, F.leaky_relu.  Same structure and arithmetic as `hifigan` above."""

@@ -80,7 +80,7 @@ def test_config_struct_matches_header():
                 n *= int(d)
             words += n
     assert fields == [f[0] for f in MT2Config._fields_]
-    assert ctypes.sizeof(MT2Config) == 4 * words == 292
+    assert ctypes.sizeof(MT2Config) == 4 * words == 296
 
 
 def test_production_yaml_equals_builtin_configs():
@@ -286,6 +286,7 @@ pretrainer: !new:speechbrain.utils.parameter_transfer.Pretrainer
     cfg, got = weights.load_speechbrain_hifigan(str(d))
     assert cfg.upsample_initial_channel == 64 and cfg.upsample_rates == [8, 8, 2, 2] and cfg.inference_padding == 5
     assert cfg.hop == 256 and list(got) == list(sd)
+    assert cfg.pad_mode == "reflect"          # speechbrain.nnet.CNN.Conv1d(padding="same") mirrors unless told otherwise
     for k in sd:
         assert got[k].shape == sd[k].shape and np.abs(got[k] - sd[k]).max() < 1e-6, k
     with pytest.raises(FileNotFoundError):

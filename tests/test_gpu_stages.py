@@ -891,17 +891,24 @@ def test_megatts_seven_argument_constructor_writes_wav(tmp_path, monkeypatch):
     wdir = tmp_path / "prompts"
     wdir.mkdir()
     A.write_wav(str(wdir / "p0.wav"), y, 16000, "PCM_S16")
-    tts = M.Megatts(ck["g"], ypath["g"], ck["plm"], ypath["plm"], ck["adm"], ypath["adm"], None)
+    # symbol table (k2 format, ids deliberately NOT in sorted-symbol order): token id = rank among the sorted symbols
+    syms = ["sil", "a1", "zh", "b", "ang4", "AA0", "_", "n", "i3"]
+    stab = tmp_path / "unique_text_tokens.k2symbols"
+    stab.write_text("".join(f"{s_} {i + 1}\n" for i, s_ in enumerate(syms)), encoding="utf-8")
+    tts = M.Megatts(ck["g"], ypath["g"], ck["plm"], ypath["plm"], ck["adm"], ypath["adm"], str(stab))
     tts.eval()
-    assert tts.hifi_gan is not None and tts.hifi_gan.cfg.inference_padding == 5
-    phone = rng.integers(0, g.mrte.phone_vocab_size, 5)
+    assert tts.hifi_gan is not None and tts.hifi_gan.cfg.inference_padding == 5 and tts.hifi_gan.cfg.pad_mode == "reflect"
+    phones = ["n", "i3", "sil", "zh", "ang4"]
+    rank = {s_: i for i, s_ in enumerate(sorted(syms + ["<eps>"]))}
+    phone = np.asarray([rank[s_] for s_ in phones])
+    assert tts.ttc.phone2token(phones).tolist() == phone.tolist()
     out_wav = str(tmp_path / "test.wav")
-    mel, lens, aux = tts(str(wdir), None, phone_tokens=phone, out_path=out_wav)
+    mel, lens, aux = tts(str(wdir), None, phones=phones, out_path=out_wav)
     prompt = O.mel_spectrogram(A.load_audio(str(wdir / "p0.wav")))
     ref = O.synthesize(sd_g, sd_p, sd_a, g, p, a, phone.astype(np.int64), prompt)
     assert lens[0] == ref["mel"].shape[0] and O.rel_l2(mel[0, :lens[0]].cpu().numpy(), ref["mel"]) < NORTH_STAR
     audio, sr = A.read_wav(out_wav)
-    want_gen = O.hifigan(sd_h, h, np.pad(ref["mel"], ((5, 5), (0, 0)), mode="edge"))
+    want_gen = O.hifigan(sd_h, tts.hifi_gan.cfg, np.pad(ref["mel"], ((5, 5), (0, 0)), mode="edge"))   # reflect edge mode
     assert sr == 16000 and audio.size == (prompt.shape[0] + 10 + int(lens[0]) + 10) * h.hop
     assert O.rel_l2(audio[-want_gen.size:], want_gen) < 5e-3       # mel round-off amplified by the (random-weight) vocoder
 
@@ -978,3 +985,40 @@ def test_prompt_conditioned_synthesis_as_one_call(kind):
         assert O.rel_l2(mel2[b, :n].cpu().numpy(), z["mel"]) < NORTH_STAR
     with pytest.raises(ValueError, match="sum to the prompt"):
         tts.synthesize_prompt_conditioned(args[0], args[1], args[2], z["prompt_dur"][None] + 1)
+
+
+def test_hifigan_reflect_edge_mode():
+    """The speechbrain generator's edge mode (`HifiGanConfig.pad_mode = "reflect"`: every 'same' convolution mirrors its
+    input at the utterance ends - speechbrain.nnet.CNN.Conv1d's default - instead of zero padding), per utterance inside
+    ragged batches, with and without `inference_padding`, against the oracle's reflect form (itself checked against
+    torch's F.pad(mode="reflect") in the CPU suite): tiny model on short utterances (edge-dominated) and the production
+    generator at 187 + 64 frames.  The two modes differ by > 1e-2 on a short utterance."""
+    from megatts2_amd import megatts2 as M, synth
+    import dataclasses
+    rng = np.random.Generator(np.random.PCG64(79))
+    (gt, pt, at, ht), (_, _, _, sd_ht) = synth_models("tiny")
+    for pad in (0, 5):
+        hr = dataclasses.replace(ht, pad_mode="reflect", inference_padding=pad)
+        voc = M.HIFIGAN(hr, sd_ht)
+        small = [synth.make_utterance(rng, 1, T, T).prompt_mel for T in (23, 9, 40, 7)]
+        mel, ln = pad_stack(small)
+        wav = voc.decode_batch(dev(mel).transpose(1, 2).contiguous(), mel_lens=ln).cpu().numpy()
+        for i, m in enumerate(small):
+            want = O.hifigan(sd_ht, hr, np.pad(m, ((pad, pad), (0, 0)), mode="edge"))
+            assert O.rel_l2(wav[i, 0, :want.size], want) < NORTH_STAR, (pad, i)
+            assert not wav[i, 0, want.size:].any()
+        zero = O.hifigan(sd_ht, ht, np.pad(small[1], ((pad, pad), (0, 0)), mode="edge"))
+        assert O.rel_l2(wav[1, 0, :zero.size], zero) > 1e-2
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("prod")
+    hr = dataclasses.replace(h, pad_mode="reflect", inference_padding=5)
+    voc = M.HIFIGAN(hr, sd_h)
+    mels = [synth.make_utterance(rng, 2, T, T).prompt_mel for T in (187, 64)]
+    mel, ln = pad_stack(mels)
+    wav = voc.decode_batch(dev(mel).transpose(1, 2).contiguous(), mel_lens=ln).cpu().numpy()
+    O.enable_torch_kernels()
+    try:
+        for i, m in enumerate(mels):
+            want = O.hifigan(sd_h, hr, np.pad(m, ((5, 5), (0, 0)), mode="edge"))
+            assert O.rel_l2(wav[i, 0, :want.size], want) < NORTH_STAR
+    finally:
+        O.disable_torch_kernels()

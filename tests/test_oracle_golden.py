@@ -237,3 +237,40 @@ def test_prompt_conditioned_synthesis(kind, tiny, prod):
     assert np.array_equal(out["adm_dur"], z["adm_dur"])
     assert np.array_equal(out["p_codes"], z["p_codes"])
     assert O.rel_l2(out["mel"], z["mel"]) < 1e-3
+
+
+def test_hifigan_reflect_edge_mode_against_torch(tiny):
+    """speechbrain's Conv1d(padding="same") mirrors its input (padding_mode="reflect") where torch / SpeechT5HifiGan pad
+    zeros: the oracle's reflect form of the vocoder against F.pad(mode="reflect") + F.conv1d on the same weights - and
+    the two edge modes differ by far more than any tolerance on a short utterance (so the mode is not a detail)."""
+    import dataclasses
+    import torch
+    import torch.nn.functional as Fn
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = tiny
+    hr = dataclasses.replace(h, pad_mode="reflect")
+    mel = np.random.default_rng(0).standard_normal((23, h.in_dim)).astype(np.float32)
+
+    def t(x):
+        return torch.from_numpy(np.ascontiguousarray(x))
+
+    def cs(x, w, b, d=1):
+        gp = (w.shape[2] - 1) // 2 * d
+        return Fn.conv1d(Fn.pad(x, (gp, gp), mode="reflect"), t(w), t(b), dilation=d)
+    with torch.no_grad():
+        x = cs(t(mel).T[None], sd_h["conv_pre.weight"], sd_h["conv_pre.bias"])
+        nk = len(h.resblock_kernel_sizes)
+        for i, (r, k) in enumerate(zip(h.upsample_rates, h.upsample_kernel_sizes)):
+            x = Fn.conv_transpose1d(Fn.leaky_relu(x, h.leaky_relu_slope), t(sd_h[f"upsampler.{i}.weight"]),
+                                    t(sd_h[f"upsampler.{i}.bias"]), stride=r, padding=(k - r) // 2)
+            acc = None
+            for j, (rk, dils) in enumerate(zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes)):
+                q, hh = f"resblocks.{i * nk + j}", x
+                for n, d in enumerate(dils):
+                    y = cs(Fn.leaky_relu(hh, h.leaky_relu_slope), sd_h[f"{q}.convs1.{n}.weight"], sd_h[f"{q}.convs1.{n}.bias"], d)
+                    y = cs(Fn.leaky_relu(y, h.leaky_relu_slope), sd_h[f"{q}.convs2.{n}.weight"], sd_h[f"{q}.convs2.{n}.bias"])
+                    hh = y + hh
+                acc = hh if acc is None else acc + hh
+            x = acc / nk
+        ref = torch.tanh(cs(Fn.leaky_relu(x, 0.01), sd_h["conv_post.weight"], sd_h["conv_post.bias"])[0, 0]).numpy()
+    assert O.rel_l2(O.hifigan(sd_h, hr, mel), ref) < TOL
+    assert O.rel_l2(O.hifigan(sd_h, h, mel), ref) > 1e-2

@@ -34,6 +34,7 @@
 namespace mt2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v, float slope) {
@@ -203,6 +204,63 @@ __device__ __forceinline__ void epilogue_pre_t(const GemmP& p, f32x16 (&acc)[TM]
     }
 }
 
+// Epilogue with 16-byte stores.  The 32x32 MFMA leaves a lane with ONE column and 16 scattered rows, i.e. 16 dword stores per
+// tile - the store tail of a wave that owns four tiles (64x64: the 256x128 tile, the one-wave-per-SIMD 128x128 tile) measured
+// 11.6-17.3 us per tile (tools/x6_overheads.py: store ISSUE, not bandwidth).  Every group of four accumulator registers
+// (rows R0..R0+3 of the lane's column) is a 4x4 block across the four lanes of a quad (columns 4k..4k+3): a two-stage DPP
+// butterfly (lane xor 1 on register pairs (0,1) (2,3), lane xor 2 on (0,2) (1,3); 8 v_mov_dpp + 8 v_cndmask per block)
+// transposes it, after which lane r of the quad holds row R0+r, columns 4k..4k+3 contiguously: one dwordx4 store (and one
+// float4 load of bias / residual) instead of four dword stores.  Needs N, ldc, ldr multiples of 4 and 16-byte aligned
+// bases (the caller checks, wave-uniformly, and falls back to `epilogue`).
+__device__ __forceinline__ float dpp_quad(float v, const int ctrl) {
+    return __builtin_bit_cast(float, ctrl == 0xB1 ? __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)
+                                                  : __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+}
+__device__ __forceinline__ bool epilogue_t4_ok(const GemmP& p) {
+    return ((p.N | p.ldc | (p.R ? p.ldr : 0)) & 3) == 0 && (((unsigned long long)p.C | (unsigned long long)p.R | (unsigned long long)p.bias) & 15) == 0 &&
+           ((p.strideC | p.strideR | p.strideB) & 3) == 0;
+}
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_t4(const GemmP& p, f32x16 (&acc)[TM][TN], int g, int mw, int nw, int lane) {
+    const float* __restrict__ bias = p.bias ? p.bias + (long long)g * p.strideB : nullptr;
+    const float* __restrict__ R = p.R ? p.R + (long long)g * p.strideR : nullptr;
+    float* __restrict__ C = p.C + (long long)g * p.strideC;
+    const int epi_act = p.epi_act;
+    const float epi_par = p.pro_slope, out_scale = p.out_scale;
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const int rr = (lane & 3) + 4 * (lane >> 5), c4 = ((lane & 31) >> 2) * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 32 + c4;
+        const bool nok = n < p.N;                       // N is a multiple of 4: the four columns are in or out together
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias && nok) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x0 = acc[i][j][4 * q], x1 = acc[i][j][4 * q + 1], x2 = acc[i][j][4 * q + 2], x3 = acc[i][j][4 * q + 3];
+                const float p0 = dpp_quad(x0, 0xB1), p1 = dpp_quad(x1, 0xB1), p2 = dpp_quad(x2, 0xB1), p3 = dpp_quad(x3, 0xB1);
+                const float y0 = b0 ? p1 : x0, y1 = b0 ? x1 : p0, y2 = b0 ? p3 : x2, y3 = b0 ? x3 : p2;
+                const float q0 = dpp_quad(y0, 0x4E), q1 = dpp_quad(y1, 0x4E), q2 = dpp_quad(y2, 0x4E), q3 = dpp_quad(y3, 0x4E);
+                f32x4 v = {b1 ? q2 : y0, b1 ? q3 : y1, b1 ? y2 : q0, b1 ? y3 : q1};
+                const int m = mw + i * 32 + 8 * q + rr;
+                if (nok && m < p.M) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_rt(epi_act, v[e] + bv[e], epi_par) * out_scale;
+                    if (R) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(R + (long long)m * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                    }
+                    if (p.valid && p.valid[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(C + (long long)m * p.ldc + n) = v;
+                }
+            }
+        }
+    }
+}
+
 constexpr int BK = 32;   // K chunk (floats)
 constexpr int PRO_LN = 3;   // prologue kind: LayerNorm of the A rows (value of GemmP::pro_act)
 constexpr int PRO_LNA = 4;  // LayerNorm of the A rows, ALGEBRAIC form: statistics in the prologue, correction in the epilogue
@@ -347,7 +405,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f32_kernel(GemmP p) {
 //     to the fragment registers after the ds_read;
 //   * one raw s_barrier per chunk, preceded by a COUNTED s_waitcnt vmcnt((NST-2)*L) so younger chunks stay
 //     in flight across the barrier (hipcc's __syncthreads would drain them with vmcnt(0)).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 lds_read_b128(unsigned byte_addr) {
     f32x4 v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr) : "memory");
@@ -1799,6 +1856,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.z;
+    const unsigned long long t_entry = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;      // clock probe only
 
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
     const int bid = blockIdx.x;
@@ -2046,6 +2104,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     if (probe) {
         treal0 = __builtin_amdgcn_s_memrealtime();
         tcyc0 = __builtin_readcyclecounter();
+        if (lane == 0) p.dbg[9] = treal0 - t_entry;        // ticks from kernel entry to the start of the K loop
     }
 #endif
     if constexpr (XP) {       // first fragments of chunk 0 (the only exposed fetch + split)
@@ -2307,15 +2366,27 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
         p.dbg[8] = __builtin_readcyclecounter() - tcyc0;
     }
 #else
-    if (probe && lane == 0) {
-        p.dbg[6] = (unsigned long long)nk;
-        p.dbg[7] = __builtin_amdgcn_s_memrealtime() - treal0;
-        p.dbg[8] = __builtin_readcyclecounter() - tcyc0;
+    unsigned long long t_loop_end = 0;
+    if (probe) {
+        t_loop_end = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            p.dbg[6] = (unsigned long long)nk;
+            p.dbg[7] = t_loop_end - treal0;
+            p.dbg[8] = __builtin_readcyclecounter() - tcyc0;
+        }
     }
 #endif
 #undef MT2_T
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    else if (epilogue_t4_ok(p)) epilogue_t4<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+#ifndef MT2_PHASE_TIMING
+    if (probe) {                                  // ticks spent in the epilogue (stores issued, not necessarily retired)
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) p.dbg[10] = t_end - t_loop_end;
+    }
+#endif
 }
 
 // ===================================================================================================

@@ -16,7 +16,11 @@ CASES = [("big", 4096, 4096, 4096, 1, 51), ("big", 4096, 4096, 4096, 1, 55), ("m
          ("plm_qkv", 448, 3072, 1024, 1, 54),
          # MP form
          ("big", 4096, 4096, 4096, 1, 67), ("big", 4096, 4096, 4096, 1, 68), ("plm_ff0", 864, 4096, 1024, 1, 67),
-         ("plm_qkv", 448, 3072, 1024, 1, 67), ("plm_qkv", 448, 3072, 1024, 1, 69)]
+         ("plm_qkv", 448, 3072, 1024, 1, 67), ("plm_qkv", 448, 3072, 1024, 1, 69),
+         # one compute wave per SIMD (MP), the same tile without MP, free-running waves
+         ("plm_ff0", 864, 4096, 1024, 1, 72), ("plm_qkv", 448, 3072, 1024, 1, 72), ("big", 4096, 4096, 4096, 1, 72),
+         ("plm_ff0", 864, 4096, 1024, 1, 74), ("plm_ff0", 864, 4096, 1024, 1, 75), ("plm_qkv", 448, 3072, 1024, 1, 75),
+         ("plm_ff0", 864, 4096, 1024, 1, 73)]
 for name, M, N, K, taps, cfg in CASES:
     ms, cn, ghz = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=10, w_copies=2, flags=4 | 8)
     chunks = (K + 31) // 32

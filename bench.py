@@ -186,6 +186,10 @@ def main() -> None:
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="debug: a handle option (mt2_set_option), e.g. ar_groups=1, splitk=0, win_conv=0, t_ks4=512")
+    ap.add_argument("--ab", default=None, metavar="NAME=VALUE[,NAME=VALUE...]",
+                    help="measurement: A/B of handle options INSIDE one process - steps alternate between the defaults (A) and "
+                         "these options (B), so that clock / temperature drift hits both arms alike; prints one JSON line "
+                         "{a_ms, b_ms, ...} and exits")
     ap.add_argument("--vqpe", default="overlap", choices=["overlap", "separate"],
                     help="C3/C5: the VQ-PE stage inside the synthesis call on an internal stream beside the ADM (default) "
                          "or as its own call in front of it")
@@ -311,6 +315,28 @@ def main() -> None:
             mel, lens = gather_mels(mel, lens, b_cap=b_cap, t_cap=shape.Tm, host_lens=False)
         return mel, lens
 
+    if args.ab and not dry and world == 1:
+        b_opts = [kv.split("=") for kv in args.ab.split(",")]
+        a_opts = [(k_, model.get_option(k_)) for k_, _ in b_opts]
+        t_arm = {"a": [], "b": []}
+        for it in range(args.warmup + args.steps):
+            for arm, opts_ in (("a", a_opts), ("b", b_opts)) if it % 2 == 0 else (("b", b_opts), ("a", a_opts)):
+                for k_, v_ in opts_:
+                    model.set_option(k_, int(v_))
+                sync()
+                t0_ = time.perf_counter()
+                step()
+                sync()
+                if it >= args.warmup:
+                    t_arm[arm].append((time.perf_counter() - t0_) * 1e3)
+        for k_, v_ in a_opts:
+            model.set_option(k_, int(v_))
+        med = lambda x_: float(np.median(x_))                                # noqa: E731
+        print(json.dumps({"ab": args.ab, "workload": args.workload, "steps_per_arm": args.steps,
+                          "a_ms_median": round(med(t_arm["a"]), 3), "b_ms_median": round(med(t_arm["b"]), 3),
+                          "a_ms_min": round(min(t_arm["a"]), 3), "b_ms_min": round(min(t_arm["b"]), 3),
+                          "b_over_a": round(med(t_arm["b"]) / med(t_arm["a"]), 4)}), flush=True)
+        return
     for _ in range(args.warmup):
         step()
     sync()

@@ -2390,6 +2390,188 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
 }
 
 // ===================================================================================================
+// v2h: x6 arithmetic for the K-SPLIT tiles of the autoregressive steps.  The mid-size AR launches
+// (M = 16 t rows per stream group, t < ~30: 3 900 launches, 86 ms of traced kernel time per C3 step) run on
+// gemm_f32_dma_kernel's K-split tiles because one tile's serial K chain is their latency - and those tiles do their
+// products on the f32 MFMA (16 x 64 cycles per wave and 32-deep chunk: 65-74 % of a round, profiles/r02_x6_phase_timing.txt).
+// Here the same decomposition - KS groups of WGM x WGN waves, one 32x32 tile per wave, group kg walking chunks kg, kg+KS, ...
+// through its OWN ring, one barrier per round, partial tiles summed through LDS in a fixed order, each group finishing
+// 16 / KS accumulator elements in the fused epilogue - carries the x6 arithmetic (12 bf16 MFMAs of 32 cycles instead of 16
+// f32 MFMAs of 64) with the weights arriving as three bf16 planes, and NL loader waves own the whole refill (a K-split tile
+// issues KS times the LDS-DMA instructions of a plain one: 770 cycles of a 3 150-cycle round when the compute waves do it).
+// Linear layers only (taps = 1, K a multiple of 32 KS); same arithmetic order per output element as the other x6 kernels
+// within a K group, groups summed kg = 0..KS-1.
+template <int BM, int BN, int WGM, int WGN, int KS, int NL, int NST, int PRO>
+__global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x6_ks_kernel(GemmP p) {
+    constexpr int NW = WGM * WGN;                         // waves of one K group
+    constexpr int NWC = NW * KS;                          // compute waves
+    constexpr int PA = BM / 8, PB = 3 * BN / 16;          // 1-KiB pieces of one group's chunk: f32 A rows, bf16 plane rows
+    constexpr int PG = PA + PB, PT = PG * KS;             // pieces per round (all groups)
+    constexpr int LW = PT / NL;                           // pieces per loader wave and round
+    constexpr int STAGE_A = BM * BK * 4, STAGE_B = PB * 1024, STAGE = STAGE_A + STAGE_B;   // bytes, one group's stage
+    constexpr int EPG = 16 / KS;
+    static_assert(BM == 32 * WGM && BN == 32 * WGN, "one 32x32 tile per wave");
+    static_assert(PT % NL == 0 && 16 % KS == 0 && NST >= 2 && (NST - 2) * LW < 64 && NWC + NL <= 16, "config");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* ring = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.z;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const bool nmajor = p.M < p.N;
+    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
+    const int nr = p.K / (BK * KS);                       // rounds (launch_gemm guarantees K % (32 KS) == 0)
+
+    if (wave_all >= NWC) {
+        // ------------------------------------------------------------------ loader wave lw: pieces lw, lw + NL, ... of a round
+        const int lw = wave_all - NWC;
+        const char* __restrict__ Xb = reinterpret_cast<const char*>(p.X + (long long)g * p.strideX);
+        const char* __restrict__ Wb = reinterpret_cast<const char*>(reinterpret_cast<const unsigned short*>(p.W3) + (long long)g * p.strideW);
+        const char* zero = reinterpret_cast<const char*>(g_zero16);
+        const char* base[LW];            // operand base of the piece (X or W3), nullptr-free
+        long long rowb[LW];              // byte offset of the lane's row + its k slot inside a chunk, < 0: zero row
+        int kmul[LW], ldsoff[LW];        // bytes per k element (4: A, 2: B); LDS byte offset of the piece inside its group's stage
+        int grp[LW];
+#pragma unroll
+        for (int j = 0; j < LW; ++j) {
+            const int pi = j * NL + lw, kg = pi / PG, w = pi - kg * PG;
+            grp[j] = kg;
+            if (w < PA) {                                  // A piece: rows w*8 .. +7, 8 lanes per 128-byte row
+                const int m = m0 + w * 8 + (lane >> 3);
+                int src = kInvalidRow;
+                if (m < p.M) src = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
+                const int kl = ((lane & 7) ^ ((w * 4 + (lane >> 4)) & 7)) * 4;
+                base[j] = Xb; kmul[j] = 4; ldsoff[j] = w * 1024;
+                rowb[j] = (unsigned)src < (unsigned)p.Rx ? ((long long)src * p.ldx + kl) * 4 : -1;
+            } else {                                       // B piece: plane pl, rows rb*16 .. +15, 4 lanes per 64-byte row
+                const int bp = w - PA, pl = bp / (BN / 16), rb = bp - pl * (BN / 16);
+                const int nl = rb * 16 + (lane >> 2), n = n0 + nl;
+                const int kl = ((lane & 3) ^ ((nl >> 2) & 3)) * 8;
+                base[j] = Wb; kmul[j] = 2; ldsoff[j] = STAGE_A + bp * 1024;
+                rowb[j] = n < p.N ? (pl * p.w3_plane + (long long)n * p.ldw + kl) * 2 : -1;
+            }
+        }
+        wait_vmcnt<0>();                                   // the rowbase loads
+        auto issue = [&](int rd, int st) {
+#pragma unroll
+            for (int j = 0; j < LW; ++j) {
+                const long long kb = (long long)(rd * KS + grp[j]) * BK * kmul[j];
+                const char* src = rowb[j] >= 0 ? base[j] + rowb[j] + kb : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(ring + (grp[j] * NST + st) * STAGE + ldsoff[j]),
+                                                 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nr) issue(st, st);
+        int st = 0;
+        for (int rd = 0; rd < nr; ++rd) {
+            if (rd + NST - 2 < nr) wait_vmcnt<(NST - 2) * LW>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                  // round rd complete in LDS; round rd-1's stages are free
+            if (rd + NST - 1 < nr) issue(rd + NST - 1, st == 0 ? NST - 1 : st - 1);
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute wave: K group kg, tile (wm, wn)
+    const int kg = wave_all / NW, wave = wave_all % NW;
+    const int wm = wave / WGN, wn = wave % WGN;
+    EpiPre<EPG> pre;
+    epi_prefetch<EPG>(p, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    const float pro_slope = p.pro_slope;
+    const int half = lane >> 5;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring + (unsigned)(kg * NST) * STAGE;
+    const int swza = (lane >> 1) & 7;
+    const unsigned a_lane = lds0 + ((wm * 32 + (lane & 31)) * BK) * 4;
+    const int nrow = wn * 32 + (lane & 31);
+    const int swzb = (nrow >> 2) & 3;
+    const unsigned b_lane = lds0 + STAGE_A + nrow * 64;
+    unsigned koffa[2][2], koffb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        koffa[b][0] = (unsigned)(((b * 4 + half * 2) ^ swza) * 16);
+        koffa[b][1] = (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
+        koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+    }
+    f32x4 ra[2][2];
+    u32x4 rb[2][3], pln[3];
+    auto fetch = [&](int b, unsigned sa, unsigned sb) {
+        ra[b][0] = lds_read_b128(sa + koffa[b][0]);
+        ra[b][1] = lds_read_b128(sa + koffa[b][1]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) rb[b][pl] = __builtin_bit_cast(u32x4, lds_read_b128(sb + koffb[b] + (unsigned)(pl * BN * 64)));
+    };
+    auto wait_block = [&](int b) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(ra[b][0]), "+v"(ra[b][1]), "+v"(rb[b][0]), "+v"(rb[b][1]), "+v"(rb[b][2]));
+    };
+    auto products = [&](int b) {
+        const bf16x8 A1 = __builtin_bit_cast(bf16x8, pln[0]), A2 = __builtin_bit_cast(bf16x8, pln[1]), A3 = __builtin_bit_cast(bf16x8, pln[2]);
+        constexpr int PA_[6] = {3, 1, 2, 2, 1, 1}, PB_[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const bf16x8 At = PA_[t] == 1 ? A1 : (PA_[t] == 2 ? A2 : A3);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, __builtin_bit_cast(bf16x8, rb[b][PB_[t]]), acc, 0, 0, 0);
+        }
+    };
+    int st = 0;
+    for (int rd = 0; rd < nr; ++rd) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
+        fetch(0, sa, sb);
+        fetch(1, sa, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        // one tile per wave: 44 VALU per 6 MFMAs do not fit in the MFMA shadow - split and multiply in turn, the other
+        // waves of the SIMD (another K group) fill the gaps
+        wait_block(0);
+        wait_block(1);
+        __builtin_amdgcn_sched_barrier(0);
+        split3_bf16<PRO>(ra[0][0], ra[0][1], pro_slope, pln[0], pln[1], pln[2]);
+        products(0);
+        __builtin_amdgcn_sched_barrier(0);
+        split3_bf16<PRO>(ra[1][0], ra[1][1], pro_slope, pln[0], pln[1], pln[2]);
+        products(1);
+        __builtin_amdgcn_sched_barrier(0);
+        st = st + 1 == NST ? 0 : st + 1;
+    }
+    // ---- sum the KS partial tiles through LDS (every DMA has been waited for; the barrier orders the last operand reads),
+    // fixed order kg = 0..KS-1; group kg finishes elements e = kg*EPG .. kg*EPG+EPG-1
+    if constexpr (KS > 1) {
+        __syncthreads();                                  // (the loader waves have left: the barrier counts live waves only)
+        float* red = smem + ((kg * NW + wave) * 16) * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[e * 64] = acc[e];
+        __syncthreads();
+        float out[EPG];
+#pragma unroll
+        for (int i = 0; i < EPG; ++i) {
+            const int e = kg * EPG + i;
+            float v = 0.0f;
+#pragma unroll
+            for (int g2 = 0; g2 < KS; ++g2) v += smem[(((g2 * NW + wave) * 16) + e) * 64 + lane];
+            out[i] = v;
+        }
+        epilogue_pre<EPG>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
+    } else {
+        float out[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[e] = acc[e];
+        epilogue_pre<16>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, 0);
+    }
+}
+
+// ===================================================================================================
 // v2e: the loader-wave x6 kernel with the two halves of the compute waves DE-PHASED (128x128 tile, 3-deep ring).
 template <int BM, int BN, int WGM, int WGN, int NL, int PRO>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldrd_kernel(GemmP p) {
@@ -2637,6 +2819,7 @@ struct TileCfg {
     void (*fn[5])(GemmP);     // indexed by the prologue: none / relu / leaky relu / LayerNorm / algebraic LayerNorm (nullptr: no variant)
     int win_qs = 0;           // > 0: window convolution for Cin = Cout = 32 * win_qs
     bool x6 = false;          // window convolution on the bf16 pipe (3-way split, 6 products): needs GemmP::W3
+    int x6_ks = 0;            // > 0: x6 K-split tile (gemm_x6_ks_kernel): linear layers with K a multiple of 32 * x6_ks
 };
 
 #define MT2_CFG(BM_, BN_, WM_, WN_)                                                                    \
@@ -2707,6 +2890,11 @@ struct TileCfg {
       { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, false, false, true>,                            \
         gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, false, false, true>,                            \
         gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, false, false, true>, nullptr, nullptr }, 0, true }
+#define MT2_GX6K(BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                           \
+    { BM_, BN_, (WM_* WN_ * KS_ + NL_) * 64, (size_t)KS_ * NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024), \
+      "x6ks" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "+" #NL_ "_s" #NST_,                                         \
+      { gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_NONE>, gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_RELU>, \
+        gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true, KS_ }
 #define MT2_GX6LD(BM_, BN_, WM_, WN_, NL_)                                                                     \
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)3 * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),          \
       "x6ldrd" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s3",                                                      \
@@ -2817,6 +3005,12 @@ static const TileCfg kCfgs[] = {
     MT2_GX6LF(256, 128, 4, 2, 4, 2),    // 76: the 51 tile
     MT2_GX6LF(128, 64, 4, 2, 4, 3),     // 77: the 64 tile
     MT2_GX6LF(128, 128, 4, 2, 2, 3),    // 78: 55 with 2 loader waves
+    // v2h: x6 arithmetic on the K-split tiles of the AR steps, loader waves own the refill
+    MT2_GX6K(32, 64, 1, 2, 4, 4, 2),    // 79: 8 compute (4 K groups of 1x2) + 4 loader waves, 128 KiB: the 22 tile
+    MT2_GX6K(64, 64, 2, 2, 2, 4, 3),    // 80: 8 compute (2 K groups of 2x2) + 4 loader waves, 120 KiB: the 18 / 20 tile
+    MT2_GX6K(32, 64, 1, 2, 4, 2, 2),    // 81: 79 with 2 loader waves
+    MT2_GX6K(32, 32, 1, 1, 8, 4, 2),    // 82: 8 K groups of one wave + 4 loader waves, 112 KiB: the 28 tile
+    MT2_GX6K(64, 64, 2, 2, 2, 4, 2),    // 83: 80 with a 2-deep ring (80 KiB)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -2966,6 +3160,12 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
             if (ts >= o.t_x6_small_min) bi = o.x6_small_cfg;
         }
         // MP form of the loader-wave tiles (mid-chunk barrier, fragment fetch / split behind the previous products)
+        // K-split tiles on the bf16 pipe (x6_ks: 1 = the 32x64 k4 and 64x64 k4/k2 tiles, 2 = the 32x32 k8 tile too)
+        if (o.x6_ks && p.taps == 1 && p.groups >= 1) {
+            if ((bi == 22 || bi == 21) && p.K % (BK * 4) == 0) bi = 79;
+            else if ((bi == 20 || bi == 18 || bi == 19) && p.K % (BK * 2) == 0) bi = 80;
+            else if (o.x6_ks >= 2 && bi == 28 && p.K % (BK * 8) == 0) bi = 82;
+        }
         if (o.x6_mp256 && bi == 51) bi = 68;             // MP form of the 256x128 tile only (+2..7 % on the conv-stack shapes)
         if (o.x6_mp == 4) bi = bi == 55 ? 75 : (bi == 64 ? 77 : bi);                       // free-running compute waves
         else if (o.x6_mp == 5) bi = bi == 55 ? 75 : (bi == 51 ? 76 : (bi == 64 ? 77 : bi));
@@ -3008,6 +3208,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     }
     if (p.pro_act == PRO_LNA) lds = c->lds + (size_t)c->bm * 2 * sizeof(float);     // + row statistics [BM][2]
     if (c->x6 && (!p.W3 || (p.K & 7) || (p.ldw & 7) || p.pro_act >= PRO_LN)) return hipErrorInvalidValue;
+    if (c->x6_ks && (p.taps != 1 || p.K % (BK * c->x6_ks) != 0)) return hipErrorInvalidValue;
     if (c->x6 && p.w3_plane == 0) p.w3_plane = (long long)p.N * p.ldw;
     if (c->win_qs) {
         if (!win_eligible(p) || p.Cin != 32 * c->win_qs) return hipErrorInvalidValue;

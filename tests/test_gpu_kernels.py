@@ -269,6 +269,28 @@ def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
     assert not x6[valid == 0].any()
 
 
+@pytest.mark.parametrize("cfg", [79, 80, 81, 82, 83])
+@pytest.mark.parametrize("M,N,K", [(300, 512, 256), (77, 96, 512), (448, 3072, 1024), (33, 200, 768), (224, 1024, 4096),
+                                   (16, 1024, 1024)])
+def test_gemm_x6_ks_is_f32_equivalent(rt, cfg, M, N, K):
+    """gemm_x6_ks_kernel: the K-split tiles of the AR steps on the bf16 pipe (x6), loader waves owning the refill - linear
+    layers with M / N tails, every epilogue operand (bias, residual, row mask) and the ReLU prologue: as accurate against
+    float64 as the f32-MFMA K-split kernel on wide-dynamic-range data; masked rows exactly zero."""
+    rng = np.random.default_rng(M + N + K + cfg)
+    X = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-3, 3, (M, K)))).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / math.sqrt(K) * np.exp(rng.uniform(-2, 2, (N, K)))).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    valid = (rng.random(M) > 0.1).astype(np.int32)
+    kw = dict(valid=dev(valid), shift0=0, taps=1, dil=1, Cin=K, pro_act=rt.ACT_RELU, epi_act=rt.ACT_NONE)
+    x6 = rt.op_conv_x6(dev(X), dev(W), dev(b), dev(R), force_cfg=cfg, **kw).cpu().numpy()
+    f32 = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=22, **kw).cpu().numpy()
+    ref = (np.maximum(X, 0).astype(np.float64) @ W.T.astype(np.float64) + b + R) * valid[:, None]
+    e6, e32 = rel(x6, ref), rel(f32, ref)
+    assert e6 < 1e-6 and e6 <= 2.0 * e32 + 1e-7, (e6, e32)
+    assert not x6[valid == 0].any()
+
+
 @pytest.mark.parametrize("cfg", [51, 55, 39, 67, 69, 72, 75])
 def test_gemm_x6_corner_cases(rt, cfg):
     """Documented corner behaviour of the 3-plane split (DESIGN 4.2 "Corner cases"), against the f32-MFMA kernel and float64:

@@ -125,6 +125,42 @@ __global__ __launch_bounds__((NC + NL) * 64) void lds_bw(const float* src, float
     if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
     if (threadIdx.x == NC * 64 && blockIdx.x == 0) cyc[1] = t1 - t0;
 }
+// LDS-DMA ingest of one CU with DEPTH rounds in flight per loader wave (counted vmcnt, as the GEMM's loader waves do):
+// NL waves x PIECES KiB per round from a per-workgroup region of FOOT KiB (L2-resident when small)
+template <int NL, int PIECES, int DEPTH, int FOOT>
+__global__ __launch_bounds__(NL * 64) void dma_bw(const float* src, float* out, int iters, long long* cyc) {
+    __shared__ __attribute__((aligned(16))) float lds[NL * PIECES * 256 * DEPTH];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const float* g = src + (size_t)blockIdx.x * (FOOT * 256) + lane * 4;
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        float* dst = lds + ((it % DEPTH) * NL + wave) * PIECES * 256;
+        const int off = ((it * NL + wave) * PIECES * 256) % (FOOT * 256);
+#pragma unroll
+        for (int pc = 0; pc < PIECES; ++pc)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + (off + pc * 256) % (FOOT * 256)),
+                                             (__attribute__((address_space(3))) void*)(dst + pc * 256), 16, 0, 0);
+        constexpr int LEFT = (DEPTH - 1) * PIECES;
+        __builtin_amdgcn_s_waitcnt((LEFT & 0xF) | ((LEFT >> 4) << 14) | (7 << 4) | (15 << 8));
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070 | (15 << 8));
+    const long long t1 = __builtin_readcyclecounter();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = lds[threadIdx.x];
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+template <int NL, int PIECES, int DEPTH, int FOOT> void run_dma(int iters, int blocks) {
+    float *src, *out; long long* cyc;
+    hipMalloc(&src, (size_t)256 * FOOT * 1024 + 1048576); hipMemset(src, 0, (size_t)256 * FOOT * 1024 + 1048576);
+    hipMalloc(&out, 4 * 256 * 1024); hipMalloc(&cyc, 16); hipMemset(cyc, 0, 16);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((dma_bw<NL, PIECES, DEPTH, FOOT>), dim3(blocks), dim3(NL * 64), 0, 0, src, out, iters, cyc);
+    hipDeviceSynchronize();
+    long long c = 0;
+    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    printf("LDS-DMA ingest: %d workgroups, %d loader waves x %d KiB per round, %d rounds in flight, %d KiB per workgroup region: "
+           "%.1f B/clk/CU (%.0f cycles per round)\n", blocks, NL, PIECES, DEPTH, FOOT, (double)NL * PIECES * 1024.0 * iters / c, (double)c / iters);
+    hipFree(src); hipFree(out); hipFree(cyc);
+}
+
 template <int NC, int NL, int PIECES> void run_lds(int iters) {
     float *src, *out; long long* cyc;
     hipMalloc(&src, 256ull * 65536 * 4 + 1048576); hipMemset(src, 0, 256ull * 65536 * 4 + 1048576);
@@ -178,6 +214,10 @@ int main() {
         run("1 split+8 LDS, serial", k<1, 8, 1>, w, iters);
         run("2 splits+8 LDS, serial", k<2, 8, 1>, w, iters);
     }
+    run_dma<4, 10, 1, 64>(4000, 256);  run_dma<4, 10, 2, 64>(4000, 256);  run_dma<4, 10, 3, 64>(4000, 256);
+    run_dma<4, 16, 2, 64>(4000, 256);  run_dma<4, 8, 4, 64>(4000, 256);   run_dma<8, 8, 2, 64>(4000, 256);
+    run_dma<4, 10, 2, 4096>(4000, 256); run_dma<4, 10, 3, 4096>(4000, 256); run_dma<4, 16, 2, 4096>(4000, 256);
+    run_dma<4, 10, 3, 64>(4000, 96);   run_dma<4, 10, 3, 4096>(4000, 96);
     run_lds<8, 0, 1>(4000);
     run_lds<4, 0, 1>(4000);
     run_lds<8, 4, 10>(4000);

@@ -3011,6 +3011,9 @@ static const TileCfg kCfgs[] = {
     MT2_GX6K(32, 64, 1, 2, 4, 2, 2),    // 81: 79 with 2 loader waves
     MT2_GX6K(32, 32, 1, 1, 8, 4, 2),    // 82: 8 K groups of one wave + 4 loader waves, 112 KiB: the 28 tile
     MT2_GX6K(64, 64, 2, 2, 2, 4, 2),    // 83: 80 with a 2-deep ring (80 KiB)
+    MT2_GX6K(32, 64, 1, 2, 4, 8, 2),    // 84: 79 with EIGHT loader waves (16 waves: a round's 64 pieces are 8 per loader)
+    MT2_GX6K(64, 64, 2, 2, 2, 8, 3),    // 85: 80 with eight loader waves (5 pieces per loader and round)
+    MT2_GX6K(32, 32, 1, 1, 8, 8, 2),    // 86: 82 with eight loader waves
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -3162,9 +3165,10 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
         // MP form of the loader-wave tiles (mid-chunk barrier, fragment fetch / split behind the previous products)
         // K-split tiles on the bf16 pipe (x6_ks: 1 = the 32x64 k4 and 64x64 k4/k2 tiles, 2 = the 32x32 k8 tile too)
         if (o.x6_ks && p.taps == 1 && p.groups >= 1) {
-            if ((bi == 22 || bi == 21) && p.K % (BK * 4) == 0) bi = 79;
-            else if ((bi == 20 || bi == 18 || bi == 19) && p.K % (BK * 2) == 0) bi = 80;
-            else if (o.x6_ks >= 2 && bi == 28 && p.K % (BK * 8) == 0) bi = 82;
+            const bool l8 = o.x6_ks >= 3;                 // 3, 4: the eight-loader forms
+            if ((bi == 22 || bi == 21) && p.K % (BK * 4) == 0 && o.x6_ks != 5) bi = l8 ? 84 : 79;
+            else if ((bi == 20 || bi == 18 || bi == 19) && p.K % (BK * 2) == 0) bi = l8 ? 85 : 80;
+            else if ((o.x6_ks == 2 || o.x6_ks == 4) && bi == 28 && p.K % (BK * 8) == 0) bi = l8 ? 86 : 82;
         }
         if (o.x6_mp256 && bi == 51) bi = 68;             // MP form of the 256x128 tile only (+2..7 % on the conv-stack shapes)
         if (o.x6_mp == 4) bi = bi == 55 ? 75 : (bi == 64 ? 77 : bi);                       // free-running compute waves

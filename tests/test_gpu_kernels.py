@@ -269,7 +269,7 @@ def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
     assert not x6[valid == 0].any()
 
 
-@pytest.mark.parametrize("cfg", [79, 80, 81, 82, 83])
+@pytest.mark.parametrize("cfg", [79, 80, 81, 82, 83, 84, 85, 86])
 @pytest.mark.parametrize("M,N,K", [(300, 512, 256), (77, 96, 512), (448, 3072, 1024), (33, 200, 768), (224, 1024, 4096),
                                    (16, 1024, 1024)])
 def test_gemm_x6_ks_is_f32_equivalent(rt, cfg, M, N, K):

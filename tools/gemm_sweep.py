@@ -33,7 +33,7 @@ if mode == "x6":       # the bf16-pipe (f32-equivalent) configurations against t
               ("adm_qkv", 1120, 2304, 768, 1), ("adm_ff0", 2240, 1024, 768, 1), ("adm_out", 2240, 768, 768, 1),
               ("big", 4096, 4096, 4096, 1)]
 elif mode == "x6k":    # the AR steps' K-split launches: f32-MFMA tiles (22, 20, 18, 28) against their x6 forms (79-83) and the loader tile
-    cfgs = [22, 79, 81, 20, 18, 80, 83, 28, 82, 55]
+    cfgs = [22, 79, 84, 20, 80, 85, 28, 82, 86, 55]
     shapes = [("plm_qkv", 32, 3072, 1024, 1), ("plm_qkv", 96, 3072, 1024, 1), ("plm_qkv", 224, 3072, 1024, 1),
               ("plm_qkv", 448, 3072, 1024, 1), ("plm_ff0", 224, 4096, 1024, 1), ("plm_ff0", 448, 4096, 1024, 1),
               ("plm_ff1", 224, 1024, 4096, 1), ("plm_ff1", 448, 1024, 4096, 1), ("plm_ff1", 864, 1024, 4096, 1),

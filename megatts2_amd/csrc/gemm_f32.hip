@@ -3166,6 +3166,9 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
         // K-split tiles on the bf16 pipe (x6_ks: 1 = the 32x64 k4 and 64x64 k4/k2 tiles, 2 = the 32x32 k8 tile too)
         if (o.x6_ks && p.taps == 1 && p.groups >= 1) {
             const bool l8 = o.x6_ks >= 3;                 // 3, 4: the eight-loader forms
+            // the 64x64 K-split x6 tile also beats the 128x128 loader tile while the launch has few 64x64 tiles
+            // (profiles/r03_gemm_sweep_x6k.txt: 448x3072x1024 82 vs 64 TF/s, 448x4096x1024 106 vs 82)
+            if (bi == 55 && t64 <= o.t_x6_ks_over128 && p.K % (BK * 2) == 0) bi = 20;
             if ((bi == 22 || bi == 21) && p.K % (BK * 4) == 0 && o.x6_ks != 5) bi = l8 ? 84 : 79;
             else if ((bi == 20 || bi == 18 || bi == 19) && p.K % (BK * 2) == 0) bi = l8 ? 85 : 80;
             else if ((o.x6_ks == 2 || o.x6_ks == 4) && bi == 28 && p.K % (BK * 8) == 0) bi = l8 ? 86 : 82;

@@ -72,6 +72,7 @@ struct EngineOpts {
     int t_x6_256 = 160, t_x6_128 = 72;   // ... from this many 256x128 / 128x128 tiles on (profiles/r02_gemm_sweep_x6.txt)
     int x6_ks = 0;               // x6 arithmetic + loader waves for the AR steps' K-split tiles (gemm_x6_ks_kernel): 0 off,
                                  // 1: the 32x64 k4 / 64x64 tiles, 2: the 32x32 k8 tile as well
+    int t_x6_ks_over128 = 0;     // with x6_ks: up to this many 64x64 tiles the K-split x6 tile replaces the 128x128 loader tile
     bool x6_mp256 = false;       // MP form (config 68) wherever the 256x128 loader tile (51) would run
     int x6_mp = 0;               // 1: MP form (gemm_x6_ldr_kernel<..., MP>) of the 128x128 and small loader tiles, 2: of 256x128 too
     int x6_small_cfg = 0;        // 63..66: small loader-wave x6 tile for launches with at most t_x6_small_max 128x128 tiles and

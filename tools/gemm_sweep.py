@@ -39,7 +39,10 @@ elif mode == "x6k":    # the AR steps' K-split launches: f32-MFMA tiles (22, 20,
               ("plm_ff1", 224, 1024, 4096, 1), ("plm_ff1", 448, 1024, 4096, 1), ("plm_ff1", 864, 1024, 4096, 1),
               ("plm_out", 224, 1024, 1024, 1), ("plm_out", 448, 1024, 1024, 1), ("plm_out", 864, 1024, 1024, 1),
               ("adm_qkv", 280, 2304, 768, 1), ("adm_qkv", 560, 2304, 768, 1), ("adm_ff0", 560, 1024, 768, 1),
-              ("adm_out", 560, 768, 768, 1), ("adm_out", 1120, 768, 768, 1), ("adm_ff1", 1120, 768, 1024, 1)]
+              ("adm_out", 560, 768, 768, 1), ("adm_out", 1120, 768, 768, 1), ("adm_ff1", 1120, 768, 1024, 1),
+              ("plm_qkv", 672, 3072, 1024, 1), ("plm_qkv", 864, 3072, 1024, 1), ("plm_ff0", 672, 4096, 1024, 1),
+              ("plm_ff0", 864, 4096, 1024, 1), ("adm_qkv", 840, 2304, 768, 1), ("adm_qkv", 1120, 2304, 768, 1),
+              ("adm_ff0", 1120, 1024, 768, 1)]
 elif mode == "x6s":    # under-filled AR launches: the 128x128 loader tile against the small loader tiles and the f32 K-split tiles
     cfgs = [55, 75, 78, 72, 64, 77, 20, 22]
     shapes = [("plm_qkv", 224, 3072, 1024, 1), ("plm_qkv", 448, 3072, 1024, 1), ("plm_qkv", 864, 3072, 1024, 1),

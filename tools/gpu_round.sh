@@ -19,12 +19,12 @@ tests)
   echo "kernels rc=$?"; tail -3 gpurun_out/kernels.log
   timeout 1500 python -m pytest tests/test_gpu_stages.py -m gpu -q --no-header -p no:cacheprovider --maxfail=40 -rf > gpurun_out/stages.log 2>&1
   echo "stages rc=$?"; tail -6 gpurun_out/stages.log ;;
-tests_ab)
+ab)
   # interleaved in-process A/B of handle options (robust against clock / temperature drift): AB="x6_mp256=1 x6_mp=3 ..."
   for o in ${AB}; do
     timeout 600 python bench.py --workload ${WL:-C3} --steps ${AB_STEPS:-6} --warmup 2 --no-cpu-baseline --no-roofline --ab $o 2>/dev/null | grep "^{" | tee -a gpurun_out/ab.txt
   done ;;
-opts)
+tests_opts)
   # the stage parity suite under candidate engine options: TEST_OPTS="x6_mp=1,x6_small_cfg=64"
   MT2_TEST_OPTS="$TEST_OPTS" timeout 1500 python -m pytest tests/test_gpu_stages.py -m gpu -q --no-header -p no:cacheprovider --maxfail=40 -rf -k "${TEST_K:-prod or tiny_end_to_end or ragged}" > gpurun_out/stages_opts.log 2>&1
   echo "stages under $TEST_OPTS rc=$?"; tail -6 gpurun_out/stages_opts.log ;;

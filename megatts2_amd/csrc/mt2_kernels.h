@@ -70,8 +70,10 @@ struct EngineOpts {
     int t_x6_64 = 0;             // up to this many 128x128 tiles an x6 launch uses 64x128 tiles (A through registers, 2 WG/CU):
                                  // +10 % on the isolated kernels, -1 % inside the model (profiles/r02_opts_ab.txt): off
     int t_x6_256 = 160, t_x6_128 = 72;   // ... from this many 256x128 / 128x128 tiles on (profiles/r02_gemm_sweep_x6.txt)
-    int x6_ks = 0;               // x6 arithmetic + loader waves for the AR steps' K-split tiles (gemm_x6_ks_kernel): 0 off,
-                                 // 1: the 32x64 k4 / 64x64 tiles, 2: the 32x32 k8 tile as well
+    int x6_ks = 4;               // x6 arithmetic + loader waves for the AR steps' K-split tiles (gemm_x6_ks_kernel): 0 off;
+                                 // 1 / 2: four loader waves (configs 79, 80 / + 82 for the 32x32 k8 tile); 3 / 4: EIGHT loader
+                                 // waves (84, 85 / + 86); 5: the 64x64 tile only.  Default 4: isolated launches +10..50 %
+                                 // (profiles/r03_gemm_sweep_x6k.txt), C3 step -1.6 % (profiles/r03_ab_interleaved_v1.txt)
     int t_x6_ks_over128 = 0;     // with x6_ks: up to this many 64x64 tiles the K-split x6 tile replaces the 128x128 loader tile
     bool x6_mp256 = false;       // MP form (config 68) wherever the 256x128 loader tile (51) would run
     int x6_mp = 0;               // 1: MP form (gemm_x6_ldr_kernel<..., MP>) of the 128x128 and small loader tiles, 2: of 256x128 too

@@ -2378,7 +2378,11 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
 #endif
 #undef MT2_T
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-    else if (epilogue_t4_ok(p)) epilogue_t4<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    // the 16-byte-store epilogue only where the variant has registers to spare (<= 8 waves: 256 VGPRs; MP: <= 127 in use):
+    // in the 12-wave 256x128 tile, which sits at its 168-VGPR cap, the extra code made the allocator spill an in-flight
+    // ds_read destination inside the K loop (tools/asm_audit.py; NaNs at production size) - that tile keeps `epilogue`
+    else if ((NW + NL <= 8 || (MP && TM * TN <= 2)) && p.epi_t4 && epilogue_t4_ok(p))
+        epilogue_t4<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 #ifndef MT2_PHASE_TIMING
     if (probe) {                                  // ticks spent in the epilogue (stores issued, not necessarily retired)
@@ -3234,6 +3238,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     }
     const int tiles = ((p.M + c->bm - 1) / c->bm) * ((p.N + c->bn - 1) / c->bn);
     p.w_nt = (o.nt_weights && (p.M + c->bm - 1) / c->bm <= o.nt_row_tiles) ? 1 : 0;
+    p.epi_t4 = o.epi_t4 ? 1 : 0;
     dim3 grid(tiles, 1, p.groups), block(c->threads);
     if (opts) opts->last_cfg = c->name;
     if (opts && opts->trace_on) {

@@ -291,6 +291,37 @@ def test_gemm_x6_ks_is_f32_equivalent(rt, cfg, M, N, K):
     assert not x6[valid == 0].any()
 
 
+@pytest.mark.parametrize("pro", ["none", "relu", "lrelu"])
+@pytest.mark.parametrize("cfg", [51, 52, 55, 39, 67, 72, 75, 84])
+def test_gemm_x6_every_prologue_at_production_size(rt, cfg, pro):
+    """Each prologue kind is its own kernel instantiation with its own register allocation (round 3: the <256,128> tiles
+    with PRO none / lrelu acquired an in-loop spill of an in-flight LDS read, NaNs at production size, while the ReLU
+    instantiation the other tests use stayed correct - tools/asm_audit.py is the build-time half of this check).  Production
+    shape (several tile rows per CU, K = 1024 and a 5-tap Cin 512 convolution), all three prologues, against float64."""
+    rng = np.random.default_rng(cfg * 7 + len(pro))
+    act, slope = {"none": (rt.ACT_NONE, 0.0), "relu": (rt.ACT_RELU, 0.0), "lrelu": (rt.ACT_LRELU, 0.1)}[pro]
+    for M, N, taps, cin in ((6000, 1024, 1, 1024), (3000, 512, 5, 512)):
+        if cfg == 84 and taps > 1:
+            continue                # the K-split tiles serve linear layers only
+        K, G = taps * cin, (taps - 1) // 2
+        X = rng.standard_normal((M, cin)).astype(np.float32)
+        W = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        kw = dict(shift0=-G, taps=taps, dil=1, Cin=cin, pro_act=act, pro_slope=slope, epi_act=rt.ACT_NONE)
+        x6 = rt.op_conv_x6(dev(X), dev(W), dev(b), None, force_cfg=cfg, **kw).cpu().numpy()
+        a = X.astype(np.float64)
+        a = np.where(a > 0, a, a * slope) if pro != "none" else a
+        ap = np.zeros((M + 2 * G, cin))
+        ap[G:G + M] = a
+        ref = np.zeros((M, N))
+        for t in range(taps):
+            ref += ap[t:t + M] @ W[:, t * cin:(t + 1) * cin].T.astype(np.float64)
+        ref += b
+        assert np.isfinite(x6).all(), (cfg, pro, M)
+        assert rel(x6, ref) < 1e-6, (cfg, pro, M, rel(x6, ref))
+        assert np.abs(x6 - ref).max() < 2e-5 * np.abs(ref).max(), (cfg, pro, M)
+
+
 @pytest.mark.parametrize("cfg", [51, 55, 39, 67, 69, 72, 75])
 def test_gemm_x6_corner_cases(rt, cfg):
     """Documented corner behaviour of the 3-plane split (DESIGN 4.2 "Corner cases"), against the f32-MFMA kernel and float64:

@@ -48,7 +48,7 @@ pmcstage)
     for half in a b; do
       if [ $half = a ]; then ARGS="--workload C2"; KEEP="mrte,adm"; else ARGS="--workload C3 --skip-adm"; KEEP="vqpe,regulate,plm,decoder,vocoder"; fi
       rm -rf gpurun_out/pmcs_${t}_$half
-      (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcs_${t}_$half -o pmc -- python $GRAFT_REPO_ROOT/bench.py $ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --stage-markers) > gpurun_out/pmcs_${t}_$half.log 2>&1
+      (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcs_${t}_$half -o pmc -- python $GRAFT_REPO_ROOT/bench.py $ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-sub-workloads --stage-markers) > gpurun_out/pmcs_${t}_$half.log 2>&1
       echo "pmcstage $t $half rc=$?"; tail -1 gpurun_out/pmcs_${t}_$half.log | cut -c1-160
       f=$(find gpurun_out/pmcs_${t}_$half -name "*counter_collection.csv" | head -1)
       [ -n "$f" ] && SPECS="$SPECS $f:$KEEP"
@@ -84,7 +84,7 @@ bench1)
   echo "bench1 rc=$?"; tail -1 gpurun_out/bench_c1.log | cut -c1-1200 ;;
 prof3)
   rm -rf gpurun_out/prof3
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof3 -o bench -- python $GRAFT_REPO_ROOT/bench.py --workload C3 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline) > gpurun_out/prof3.log 2>&1
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof3 -o bench -- python $GRAFT_REPO_ROOT/bench.py --workload C3 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-sub-workloads) > gpurun_out/prof3.log 2>&1
   echo "prof3 rc=$?"; f=$(find gpurun_out/prof3 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/prof3_kernel_stats.csv && head -24 "$f" | cut -c1-200
   find gpurun_out/prof3 -name "*kernel_trace.csv" -size +8M -delete ;;
 bench3)
@@ -92,7 +92,7 @@ bench3)
   echo "bench3 rc=$?"; tail -1 gpurun_out/bench_c3.log | cut -c1-1500 ;;
 prof)
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --stage-markers) > gpurun_out/prof.log 2>&1
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-sub-workloads --stage-markers) > gpurun_out/prof.log 2>&1
   echo "prof rc=$?"; tail -2 gpurun_out/prof.log | cut -c1-400
   f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/prof_kernel_stats.csv && head -30 "$f"
   find gpurun_out/prof -name "*kernel_trace.csv" -size +8M -delete ;;
@@ -116,7 +116,7 @@ sweep_ar)
 gaps)
   # plain kernel trace (no counters) of one C2 step + per-queue gap analysis of the ADM stage
   rm -rf gpurun_out/gaps
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/gaps -o t -- python $GRAFT_REPO_ROOT/bench.py --workload ${WL:-C2} --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --stage-markers) > gpurun_out/gaps.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/gaps -o t -- python $GRAFT_REPO_ROOT/bench.py --workload ${WL:-C2} --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-sub-workloads --stage-markers) > gpurun_out/gaps.log 2>&1
   echo "gaps rc=$?"; f=$(find gpurun_out/gaps -name "*kernel_trace.csv" | head -1)
   [ -n "$f" ] && python tools/gap_analysis.py $f ${M0:-1} ${M1:-2} | tee gpurun_out/gap_analysis.txt
   find gpurun_out/gaps -name "*.csv" -size +6M -delete ;;

@@ -184,6 +184,10 @@ def main() -> None:
     ap.add_argument("--no-sub-workloads", action="store_true",
                     help="default C3 run only: skip the C2 / C1 / C5 sub-results (`workloads` in the JSON line)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="batches in flight: step i runs on handle i %% N and HIP stream i %% N (N model handles, each with its "
+                         "own weights and workspace); a step is still one batch, the timed region still ends with a device-wide "
+                         "synchronisation.  1 = every step on one handle, one after the other")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="debug: a handle option (mt2_set_option), e.g. ar_groups=1, splitk=0, win_conv=0, t_ks4=512")
     ap.add_argument("--ab", default=None, metavar="NAME=VALUE[,NAME=VALUE...]",
@@ -248,12 +252,14 @@ def main() -> None:
         sd_a = weights.synth_state_dict(weights.inventory_adm(a), 0, "adm.")
         sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.") if full else None
         sd_h = weights.synth_state_dict(weights.inventory_hifigan(h), 0, "hifigan.") if full else None
-        model = NativeModel(g, p, a, h, sd_g, sd_p, sd_a, sd_h)
-        for kv in args.opt:
-            k, v = kv.split("=")
-            model.set_option(k, int(v))
-        if args.stage_markers:
-            model.set_option("stage_markers", 1)
+        models = [NativeModel(g, p, a, h, sd_g, sd_p, sd_a, sd_h) for _ in range(max(1, args.inflight))]
+        model = models[0]
+        for m_ in models:
+            for kv in args.opt:
+                k, v = kv.split("=")
+                m_.set_option(k, int(v))
+            if args.stage_markers:
+                m_.set_option("stage_markers", 1)
 
     shape = synth.SHAPES[args.workload]
     strong = args.scaling == "strong"
@@ -293,11 +299,20 @@ def main() -> None:
     stages = [s for s in (STAGES_FULL if full else ["mrte", "adm", "decoder"]) if not (args.skip_adm and s == "adm")
               and not (args.workload == "C1" and s == "vqpe")]
     if not dry and full:            # pre-size the activation arena: no hipMalloc inside the timed region
-        model.workspace_reserve(model.workspace_query(B, Np, Tp, shape.Tm, run_plm=True, vocoder=True, prompt_vqpe=True))
+        for m_ in models:
+            m_.workspace_reserve(m_.workspace_query(B, Np, Tp, shape.Tm, run_plm=True, vocoder=True, prompt_vqpe=True))
 
     ev = None if dry else [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
-    def step(time_vqpe=False, exchange=True):
+    lanes = None if dry or args.inflight <= 1 else [torch.cuda.Stream() for _ in models]
+
+    def step(time_vqpe=False, exchange=True, i=0):
+        if lanes is not None:         # batch i on handle / stream i % N; joined by the synchronisation that ends the timed region
+            with torch.cuda.stream(lanes[i % len(lanes)]):
+                return step_on(models[i % len(models)], time_vqpe, exchange)
+        return step_on(model, time_vqpe, exchange)
+
+    def step_on(model, time_vqpe=False, exchange=True):
         # configs[2] "full VQ-PE -> ...": VQProsodyEncoder.forward (conv stacks + codebook L2-argmin) on the 431-frame
         # prompt mel - the prosody codes a prompt-conditioned PLM / stage-2 extraction consume.  Same work either way:
         # "overlap" runs it inside the synthesis call on an internal stream beside the ADM, "separate" in front.
@@ -337,15 +352,15 @@ def main() -> None:
                           "a_ms_min": round(min(t_arm["a"]), 3), "b_ms_min": round(min(t_arm["b"]), 3),
                           "b_over_a": round(med(t_arm["b"]) / med(t_arm["a"]), 4)}), flush=True)
         return
-    for _ in range(args.warmup):
-        step()
+    for i_ in range(args.warmup):
+        step(i=i_)
     sync()
     if world > 1:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i_ in range(args.steps):
+        step(i=i_)
     sync()
     local_elapsed = time.perf_counter() - t0          # this rank's own step loop (before waiting for the others)
     if world > 1:
@@ -388,6 +403,8 @@ def main() -> None:
     }
     if shard_info:
         result["strong_scaling"] = shard_info
+    if args.inflight > 1:
+        result["config"]["batches_in_flight"] = args.inflight
     if world > 1:
         costs = [utterance_cost(u.phone.size, u.prompt_mel.shape[0], int(u.durations.sum())) for u in utts]
         result["multi_gpu"] = {"per_rank_ms_per_step": rank_ms, "slowest_over_mean": round(max(rank_ms) / (sum(rank_ms) / world), 4),

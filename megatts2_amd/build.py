@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmegatts2_hip.so")
-UNITS = ["gemm_f32.hip", "attention.hip", "rowops.hip", "model_load.hip", "model_stages.hip"]
+UNITS = ["gemm_f32.hip", "gemm_skinny.hip", "attention.hip", "rowops.hip", "model_load.hip", "model_stages.hip"]
 DEPS = ["mt2_kernels.h", "mt2_model.h", "capi.inc", os.path.join("..", "..", "include", "megatts2_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("MT2_EXTRA_HIPCC_FLAGS", "").split()      # e.g. -DMT2_PHASE_TIMING (tools/x6_phase_timing.py)

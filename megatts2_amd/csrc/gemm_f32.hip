@@ -3018,7 +3018,11 @@ static const TileCfg kCfgs[] = {
     MT2_GX6K(32, 64, 1, 2, 4, 8, 2),    // 84: 79 with EIGHT loader waves (16 waves: a round's 64 pieces are 8 per loader)
     MT2_GX6K(64, 64, 2, 2, 2, 8, 3),    // 85: 80 with eight loader waves (5 pieces per loader and round)
     MT2_GX6K(32, 32, 1, 1, 8, 8, 2),    // 86: 82 with eight loader waves
+    // names only: the weight-streaming kernel for M <= 64 rows lives in gemm_skinny.hip (launch_gemm routes to it)
+    { 32, 32, 512, 0, "skinny32_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },    // 87
+    { 64, 32, 512, 0, "skinny64_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },    // 88
 };
+constexpr int kSkinny32 = 87, kSkinny64 = 88;
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 int gemm_trace_shapes(EngineOpts& o, char* buf, int cap, int top) {
@@ -3194,9 +3198,30 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     GemmP p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.groups <= 0) return hipSuccess;
     if ((p.Cin & 3) || (p.ldx & 3) || (p.ldw & 3) || p.K != p.taps * p.Cin) return hipErrorInvalidValue;
+    if (p.pro_act < 0 || p.pro_act > PRO_LNA) return hipErrorInvalidValue;
+    // a handful of rows: the weight-streaming kernel (gemm_skinny.hip) instead of a tile configuration
+    const bool sk_forced = o.force_cfg == kSkinny32 || o.force_cfg == kSkinny64;
+    if (sk_forced || (o.skinny_rows > 0 && o.force_cfg < 0 && gemm_skinny_eligible(p, o.skinny_rows))) {
+        if (!gemm_skinny_eligible(p, 64)) return hipErrorInvalidValue;
+        p.w_nt = o.skinny_nt ? 1 : 0;
+        const int sidx = p.M <= 32 ? kSkinny32 : kSkinny64;
+        if (opts) opts->last_cfg = kCfgs[sidx].name;
+        if (opts && opts->trace_on) {
+            TraceRec r;
+            r.cfg = sidx;
+            r.flops = 2.0 * p.M * p.N * p.K * p.groups;
+            r.M = p.M; r.N = p.N; r.K = p.K; r.groups = p.groups;
+            if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return hipErrorUnknown;
+            (void)hipEventRecord(r.e0, s);
+            const hipError_t e = launch_gemm_skinny(p, s);
+            (void)hipEventRecord(r.e1, s);
+            opts->trace.push_back(r);
+            return e;
+        }
+        return launch_gemm_skinny(p, s);
+    }
     int idx = 0;
     const TileCfg* c = choose_cfg(p, o, &idx);
-    if (p.pro_act < 0 || p.pro_act > PRO_LNA) return hipErrorInvalidValue;
     if (p.pro_act == PRO_LNA) {     // algebraic LayerNorm: every LDS-DMA configuration has the variant
         if (p.taps != 1 || p.K > 1024 || !p.ln_g || p.groups != 1) return hipErrorInvalidValue;
         if (!c->fn[PRO_LNA]) return hipErrorNotSupported;

@@ -79,6 +79,8 @@ struct EngineOpts {
     bool epi_t4 = true;          // DPP-transposed 16-byte-store epilogue for wave tiles without epilogue prefetch
     bool x6_mp256 = false;       // MP form (config 68) wherever the 256x128 loader tile (51) would run
     int x6_mp = 0;               // 1: MP form (gemm_x6_ldr_kernel<..., MP>) of the 128x128 and small loader tiles, 2: of 256x128 too
+    int skinny_rows = 64;        // linear layers with at most this many rows (<= 64) run on the weight-streaming kernel of
+    int skinny_nt = 0;           // gemm_skinny.hip (0: off); skinny_nt: non-temporal weight loads (measured: C1 65.2 ms with, 56.8 without)
     int x6_small_cfg = 0;        // 63..66: small loader-wave x6 tile for launches with at most t_x6_small_max 128x128 tiles and
     int t_x6_small_max = 200, t_x6_small_min = 48;   // at least t_x6_small_min small tiles (0: off)
     bool markers = false;        // a named no-op kernel at every stage boundary: lets tools/pmc_stage_summary.py attribute
@@ -88,6 +90,9 @@ struct EngineOpts {
     const char* last_cfg = "";   // name of the tile configuration the last launch used
 };
 hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
+// gemm_skinny.hip: weight-streaming linear layer for M <= 64 rows (taps = 1, no rowbase, K a multiple of 32)
+bool gemm_skinny_eligible(const GemmP& p, int max_rows);
+hipError_t launch_gemm_skinny(const GemmP& p, hipStream_t s);
 int gemm_num_configs();
 const char* gemm_config_name(int idx);
 // per tile configuration: launches, executed FLOPs, summed ms; last entry "union" (see gemm_f32.hip); -1 on error

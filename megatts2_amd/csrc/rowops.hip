@@ -152,10 +152,62 @@ __global__ __launch_bounds__(256) void ln_reduce_kernel(LnReduceP p) {
         }
     }
 }
+// The same reduction with ONE ROW PER WORKGROUP (thread = one float4 of the row): every slab load of a thread is
+// independent of the others and they are issued eight at a time, so a row costs one or two memory round trips instead
+// of 4 * S serial ones (a wave per row: 16 us at S = 16 whatever M is - the AR steps' most expensive small launch,
+// profiles/r03_c1_kernel_stats.csv).  Same summation order per element: slabs ascending, then bias, then the residual.
+__global__ __launch_bounds__(256) void ln_reduce_row_kernel(LnReduceP p) {
+    __shared__ float red[2][4];
+    const int m = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int C = p.C, c = t * 4;
+    const bool ok = c < C;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), gv = a, bv = a;
+    if (ok) {
+        const float* __restrict__ base = p.parts + (long long)m * C + c;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), rq = bq;
+        if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + c);
+        if (p.R) rq = *reinterpret_cast<const float4*>(p.R + (long long)m * p.ldr + c);
+        gv = *reinterpret_cast<const float4*>(p.gamma + c);
+        bv = *reinterpret_cast<const float4*>(p.beta + c);
+        for (int g0 = 0; g0 < p.S; g0 += 8) {
+            float4 q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (g0 + j < p.S) q[j] = *reinterpret_cast<const float4*>(base + (long long)(g0 + j) * p.pstride);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (g0 + j < p.S) { a.x += q[j].x; a.y += q[j].y; a.z += q[j].z; a.w += q[j].w; }
+        }
+        if (p.bias) { a.x += bq.x; a.y += bq.y; a.z += bq.z; a.w += bq.w; }
+        if (p.R) { a.x += rq.x; a.y += rq.y; a.z += rq.z; a.w += rq.w; }
+        if (p.xout) *reinterpret_cast<float4*>(p.xout + (long long)m * p.ldx + c) = a;
+    }
+    const float inv_c = 1.0f / (float)C;
+    float s = wave_sum(ok ? (a.x + a.y) + (a.z + a.w) : 0.0f);
+    if (lane == 0) red[0][wave] = s;
+    __syncthreads();
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * inv_c;
+    a.x -= mean; a.y -= mean; a.z -= mean; a.w -= mean;
+    float q2 = wave_sum(ok ? (a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w) : 0.0f);
+    if (lane == 0) red[1][wave] = q2;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * inv_c + p.eps);
+    if (ok) {
+        float4 y;
+        y.x = a.x * rstd * gv.x + bv.x;
+        y.y = a.y * rstd * gv.y + bv.y;
+        y.z = a.z * rstd * gv.z + bv.z;
+        y.w = a.w * rstd * gv.w + bv.w;
+        *reinterpret_cast<float4*>(p.hout + (long long)m * p.ldh + c) = y;
+    }
+}
 hipError_t launch_ln_reduce(const LnReduceP& p, hipStream_t s) {
     if (p.M <= 0) return hipSuccess;
     if (p.C > 1024 || (p.C & 3) || (p.ldx & 3) || (p.ldh & 3) || (p.ldr & 3) || p.S < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3((p.M + 3) / 4), dim3(256), 0, s, p);
+    if (p.M <= 4096)      // every AR step: one row per workgroup
+        hipLaunchKernelGGL(ln_reduce_row_kernel, dim3(p.M), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(ln_reduce_kernel, dim3((p.M + 3) / 4), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -291,6 +291,35 @@ def test_gemm_x6_ks_is_f32_equivalent(rt, cfg, M, N, K):
     assert not x6[valid == 0].any()
 
 
+@pytest.mark.parametrize("M,N,K,a_mul,shift0", [(1, 1024, 1024, 1, 0), (16, 3072, 1024, 1, 0), (33, 1024, 4096, 1, 0),
+                                                 (64, 768, 768, 1, 0), (20, 100, 96, 1, 0), (7, 200, 160, 1, 0),
+                                                 (16, 1024, 1024, 5, 4), (40, 96, 64, 2, 1), (32, 64, 32, 1, 0)])
+@pytest.mark.parametrize("pro", ["none", "relu", "lrelu"])
+def test_gemm_skinny_streams_weights_for_a_handful_of_rows(rt, M, N, K, a_mul, shift0, pro):
+    """gemm_skinny_f32_kernel (M <= 64 rows: the reference's batch-1 AR steps and the last-row launches): both MFMA
+    operands straight from memory, K shares of a workgroup's waves summed in LDS in wave order.  Every wave count
+    (K = 32 ... 4096), N tails, strided row selection (a_mul / shift0: "last row of each sequence"), all epilogue
+    operands and the three prologues - against float64, and routed there by default (force_cfg = -1)."""
+    rng = np.random.default_rng(M * 131 + N + K + len(pro))
+    act, slope = {"none": (rt.ACT_NONE, 0.0), "relu": (rt.ACT_RELU, 0.0), "lrelu": (rt.ACT_LRELU, 0.1)}[pro]
+    Rx = (M - 1) * a_mul + shift0 + 1
+    X = (rng.standard_normal((Rx, K)) * np.exp(rng.uniform(-3, 3, (Rx, K)))).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    valid = (rng.random(M) > 0.2).astype(np.int32)
+    kw = dict(valid=dev(valid), a_mul=a_mul, shift0=shift0, M=M, pro_act=act, pro_slope=slope, epi_act=rt.ACT_RELU)
+    a = X[shift0::a_mul][:M].astype(np.float64)
+    a = np.where(a > 0, a, a * slope) if pro != "none" else a
+    ref = (np.maximum(a @ W.T.astype(np.float64) + b, 0) + R) * valid[:, None]
+    for cfg in (-1, 87 if M <= 32 else 88):
+        y = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=cfg, **kw).cpu().numpy()
+        assert rel(y, ref) < 1e-6, (cfg, rel(y, ref))
+        assert not y[valid == 0].any()
+    f32 = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=5, **kw).cpu().numpy()
+    assert rel(y, ref) <= 2.0 * rel(f32, ref) + 1e-7
+
+
 @pytest.mark.parametrize("pro", ["none", "relu", "lrelu"])
 @pytest.mark.parametrize("cfg", [51, 52, 55, 39, 67, 72, 75, 84])
 def test_gemm_x6_every_prologue_at_production_size(rt, cfg, pro):

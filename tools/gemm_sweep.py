@@ -51,6 +51,11 @@ elif mode == "x6s":    # under-filled AR launches: the 128x128 loader tile again
               ("adm_qkv", 280, 2304, 768, 1), ("adm_qkv", 560, 2304, 768, 1), ("adm_qkv", 1120, 2304, 768, 1),
               ("adm_ff0", 560, 1024, 768, 1), ("adm_ff0", 1120, 1024, 768, 1), ("adm_out", 560, 768, 768, 1),
               ("adm_out", 1120, 768, 768, 1), ("adm_ff1", 1120, 768, 1024, 1)]
+elif mode == "skinny":  # M <= 64: the weight-streaming kernel (87 / 88) against the K-split tiles it replaces; microseconds per launch
+    cfgs = [22, 84, 28, 86, 87, 88]
+    shapes = [(nm, M, N, K, 1) for M in (1, 16, 32, 33, 64)
+              for nm, N, K in (("plm_qkv", 3072, 1024), ("plm_out", 1024, 1024), ("plm_ff0", 4096, 1024), ("plm_ff1", 1024, 4096),
+                               ("plm_slab", 1024, 256), ("adm_qkv", 2304, 768), ("adm_out", 768, 768), ("adm_ff1", 768, 1024))]
 elif mode == "x6win":
     cfgs = [34, 35, 58, 61, 36, 59, 60]
     shapes = [("hifi_s4k3", 3552000, 32, 96, 3), ("hifi_s4k11", 3552000, 32, 352, 11), ("hifi_s3k3", 1776000, 64, 192, 3),
@@ -69,7 +74,7 @@ else:
                ("mrte_1/16", 928, 512, 1536, 3), ("hifi_s4", 200000, 32, 352, 11), ("hifi_s1", 111000, 256, 1792, 7)]
 print("%-12s %7s %5s %5s | " % ("shape", "M", "N", "K") + " ".join("%6s" % f"c{i}" for i in cfgs) + " | auto (us)")
 for name, M, N, K, taps in shapes:
-    copies = max(1, min(16, int(48e6 // (N * K * 4)) + 1))
+    copies = max(1, min(16, int((300e6 if mode == "skinny" else 48e6) // (N * K * 4)) + 1))
     row = []
     for cfg in cfgs + [-1]:
         try:
@@ -77,5 +82,5 @@ for name, M, N, K, taps in shapes:
             row.append((2.0 * M * N * K / ms / 1e9, cn, ms))
         except Exception as e:
             row.append((0.0, "err", 0.0))
-    print("%-12s %7d %5d %5d | " % (name, M, N, K) + " ".join("%6.1f" % r[0] for r in row[:-1])
+    print("%-12s %7d %5d %5d | " % (name, M, N, K) + " ".join("%6.1f" % (r[2] * 1e3 if mode == "skinny" else r[0]) for r in row[:-1])
           + " | %.1f (%s, %.1f us)" % (row[-1][0], row[-1][1], row[-1][2] * 1e3), flush=True)

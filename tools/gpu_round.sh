@@ -102,6 +102,11 @@ sweep)
 sweep_x6k)
   timeout 600 python tools/gemm_sweep.py x6k > gpurun_out/gemm_sweep_x6k.txt 2>&1
   echo "sweep_x6k rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x6k.txt ;;
+sweep_skinny)
+  timeout 600 python tools/gemm_sweep.py skinny > gpurun_out/gemm_sweep_skinny.txt 2>&1
+  echo "sweep_skinny rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_skinny.txt ;;
+bench1x)
+  timeout 600 python bench.py --workload C1 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-sub-workloads ${BOPT} 2>/dev/null | grep "^{" | cut -c1-900 | tee -a gpurun_out/bench_c1x.txt ;;
 sweep_x6s)
   timeout 600 python tools/gemm_sweep.py x6s > gpurun_out/gemm_sweep_x6s.txt 2>&1
   echo "sweep_x6s rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x6s.txt ;;

@@ -475,7 +475,8 @@ def main() -> None:
         result["roofline"] = {
             "bound": "mfma",
             "kernel": "gemm_x6_ldr_kernel / conv_win_x6_kernel (implicit-GEMM conv/linear engine on the bf16 matrix pipe, "
-                      "f32-equivalent, loader waves) + gemm_f32_dma_kernel (f32 MFMA) for the latency-bound AR launches",
+                      "f32-equivalent, loader waves; gemm_x6_ks_kernel for the AR steps' K-split tiles) + gemm_skinny_f32_kernel / "
+                      "gemm_f32_dma_kernel (f32 MFMA) for launches of a handful of rows",
             "achieved": round(achieved, 2), "peak": round(X6_EQUIV_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
             "frac": round(achieved / X6_EQUIV_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
             "method": "achieved = algorithmic GEMM FLOPs of the step (SURVEY 8d, reference semantics, f32 multiply-adds) / "
@@ -484,7 +485,7 @@ def main() -> None:
                       "416.7 TF/s of f32-equivalent work; the f32 MFMA pipe itself peaks at 157.3 TF/s (frac_of_f32_mfma_peak, "
                       "the basis of round 1's 0.45)",
             "frac_of_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-            "arithmetic": {"f32_mfma": "v_mfma_f32_32x32x2_f32 (exact f32 fma chain): every latency-bound launch, the AR steps' K-split tiles",
+            "arithmetic": {"f32_mfma": "v_mfma_f32_32x32x2_f32 (exact f32 fma chain): launches of at most 64 rows (gemm_skinny_f32_kernel), shapes without weight planes",
                            "x6": "f32-EQUIVALENT on the bf16 pipe: operands split exactly into 3 bf16 planes, 6 exact products, f32 "
                                  "accumulation (error vs float64 not above the f32-MFMA kernel's: tests/test_gpu_kernels.py::*x6*); "
                                  "configurations named x6*: conv stacks, vocoder, large AR GEMMs",

@@ -761,7 +761,23 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* x, int ld
     const float* xr = x + (long long)j * ldx;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int n = lane; n < N; n += 64) argmax_combine(bv, bi, xr[n], n);
+    if (((N | ldx) & 3) == 0) {      // four float4 loads in flight per lane (a serial scalar loop: one round trip per 64 logits)
+        for (int n0 = lane * 4; n0 < N; n0 += 1024) {
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (n0 + u * 256 < N) q[u] = *reinterpret_cast<const float4*>(xr + n0 + u * 256);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (n0 + u * 256 < N) {
+                    const int n = n0 + u * 256;
+                    argmax_combine(bv, bi, q[u].x, n); argmax_combine(bv, bi, q[u].y, n + 1);
+                    argmax_combine(bv, bi, q[u].z, n + 2); argmax_combine(bv, bi, q[u].w, n + 3);
+                }
+        }
+    } else {
+        for (int n = lane; n < N; n += 64) argmax_combine(bv, bi, xr[n], n);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(bv, o);

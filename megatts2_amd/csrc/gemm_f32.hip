@@ -3201,7 +3201,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     if (p.pro_act < 0 || p.pro_act > PRO_LNA) return hipErrorInvalidValue;
     // a handful of rows: the weight-streaming kernel (gemm_skinny.hip) instead of a tile configuration
     const bool sk_forced = o.force_cfg == kSkinny32 || o.force_cfg == kSkinny64;
-    if (sk_forced || (o.skinny_rows > 0 && o.force_cfg < 0 && gemm_skinny_eligible(p, o.skinny_rows))) {
+    if (sk_forced || (o.skinny_rows > 0 && o.force_cfg < 0 && p.groups >= o.skinny_groups && gemm_skinny_eligible(p, o.skinny_rows))) {
         if (!gemm_skinny_eligible(p, 64)) return hipErrorInvalidValue;
         p.w_nt = o.skinny_nt ? 1 : 0;
         const int sidx = p.M <= 32 ? kSkinny32 : kSkinny64;

@@ -80,6 +80,7 @@ struct EngineOpts {
     bool x6_mp256 = false;       // MP form (config 68) wherever the 256x128 loader tile (51) would run
     int x6_mp = 0;               // 1: MP form (gemm_x6_ldr_kernel<..., MP>) of the 128x128 and small loader tiles, 2: of 256x128 too
     int skinny_rows = 64;        // linear layers with at most this many rows (<= 64) run on the weight-streaming kernel of
+    int skinny_groups = 1;       // ... only for launches with at least this many GemmP groups (split-K slabs)
     int skinny_nt = 0;           // gemm_skinny.hip (0: off); skinny_nt: non-temporal weight loads (measured: C1 65.2 ms with, 56.8 without)
     int x6_small_cfg = 0;        // 63..66: small loader-wave x6 tile for launches with at most t_x6_small_max 128x128 tiles and
     int t_x6_small_max = 200, t_x6_small_min = 48;   // at least t_x6_small_min small tiles (0: off)

@@ -19,6 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmegatts2_hip.so")
 UNITS = ["gemm_f32.hip", "gemm_skinny.hip", "attention.hip", "rowops.hip", "model_load.hip", "model_stages.hip"]
+AUDITED = ["gemm_f32.hip"]      # units whose device assembly is audited (inline-asm LDS reads in loops)
 DEPS = ["mt2_kernels.h", "mt2_model.h", "capi.inc", os.path.join("..", "..", "include", "megatts2_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("MT2_EXTRA_HIPCC_FLAGS", "").split()      # e.g. -DMT2_PHASE_TIMING (tools/x6_phase_timing.py)
@@ -51,10 +52,25 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(unit: str) -> str:
         obj = os.path.join(LIBDIR, unit.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, unit), "-o", obj]
+        audited = unit in AUDITED
+        cmd = [hipcc, *FLAGS, *(["-save-temps=obj"] if audited else []), "-c", os.path.join(CSRC, unit), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        if audited:     # the assembly of THIS build: no spill of an in-flight LDS read inside the GEMM loops (asm_audit.py)
+            from .asm_audit import report
+            stem = unit.replace(".hip", "")
+            n, text = report(os.path.join(LIBDIR, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s"))
+            with open(os.path.join(LIBDIR, stem + ".asm_audit.txt"), "w") as f:
+                f.write(text + "\n")
+            for fn in os.listdir(LIBDIR):       # the intermediates are large (the .s alone is ~55 MB): never shipped
+                if (fn.startswith(stem + "-hip-") or fn.startswith(stem + "-host-") or fn.startswith(stem + ".hip-")) and not fn.endswith(".o.keep"):
+                    os.remove(os.path.join(LIBDIR, fn))
+            if n:
+                os.remove(obj)
+                raise RuntimeError("asm audit of " + unit + " failed:\n" + text)
+            if verbose:
+                print(text.splitlines()[-1], flush=True)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:

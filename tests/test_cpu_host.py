@@ -329,3 +329,34 @@ def test_symbol_table_and_phone2token_match_the_reference(tmp_path):
             assert SymbolTable.from_file(str(f)).symbols == Ref.from_file(str(f)).symbols
         finally:
             sys.path.remove("/root/reference")
+
+
+def test_asm_audit_flags_a_spilled_lds_read_and_the_build_is_clean(tmp_path):
+    """The build audits the engine's device assembly (megatts2_amd/asm_audit.py): a scratch STORE inside a loop that holds
+    inline-asm LDS reads is how a spill of an in-flight `ds_read` destination looks (round 3: NaNs at production size with
+    every kernel test green).  Positive control on a synthetic listing, then the report of the build in the tree."""
+    from megatts2_amd import asm_audit, build
+    listing = tmp_path / "k.s"
+    listing.write_text(
+        "_ZN3mt24demoEv:\n"
+        "\ts_mov_b32 s0, 0\n"
+        ".LBB0_1:                                ; =>This Inner Loop Header: Depth=1\n"
+        "\tds_read_b128 v[2:5], v4\n"
+        "\tscratch_store_dwordx4 off, v[2:5], off ; 16-byte Folded Spill\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tscratch_load_dword v9, off, off ; 4-byte Folded Reload\n"
+        "\ts_cbranch_scc1 .LBB0_1\n"
+        "\ts_endpgm\n"
+        ".Lfunc_end0:\n"
+        "_ZN3mt25cleanEv:\n"
+        "\tscratch_store_dword off, v1, off ; 4-byte Folded Spill\n"
+        ".LBB1_1:                                ; =>This Inner Loop Header: Depth=1\n"
+        "\tds_read_b128 v[2:5], v4\n"
+        "\ts_cbranch_scc1 .LBB1_1\n"
+        ".Lfunc_end1:\n")
+    n, text = asm_audit.report(str(listing))
+    assert n == 1 and "IN-LOOP SCRATCH STORE: _ZN3mt24demoEv" in text and "note: in-loop reload: _ZN3mt24demoEv" in text
+    assert "_ZN3mt25cleanEv" not in text
+    build.build()
+    rep = open(os.path.join(build.LIBDIR, "gemm_f32.asm_audit.txt")).read()
+    assert rep.strip().endswith("0 kernel(s) with scratch STORES inside LDS-reading loops")

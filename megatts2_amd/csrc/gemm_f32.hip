@@ -1566,244 +1566,6 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
 }
 
 // ===================================================================================================
-// v2c: the x6 engine with the A operand through REGISTERS.  The LDS-DMA path tops out at ~12 B/clk per CU (the x6 tiles'
-// limit); in gemm_x6_dma_kernel 32 of a 256x128 tile's 56 KB per chunk are the f32 A rows.  Here every
-// lane loads the A fragments it multiplies straight from global memory into VGPRs in MFMA operand order (row lane & 31,
-// 8 consecutive k per k-block: two global_load_dwordx4), one chunk ahead, with plain vector loads - L2-resident
-// activations, a separate path from the DMA engine - and only the weight planes travel through the LDS ring.  The loads
-// are inline asm into loop-carried registers ("+v": updated in place; hipcc must not see an ordinary load, it could
-// only wait for it with vmcnt(0) and drain the ring).  In-order vmcnt: A(c+1) is issued BEFORE the ring refill of the
-// same round, so at the top of the next round "all but the youngest B_IT" covers A(c+1) and B(c+1).
-__device__ __attribute__((aligned(128))) float g_zero128[64];
-
-template <int OFF>
-__device__ __forceinline__ void gload_b128(f32x4& v, const float* ptr) {
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(ptr), "n"(OFF) : "memory");
-}
-
-template <int BM, int BN, int WGM, int WGN, int NST, int PRO>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_areg_kernel(GemmP p) {
-    constexpr int NW = WGM * WGN;
-    constexpr int WTM = BM / WGM, WTN = BN / WGN;
-    constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int BPIECES = 3 * BN / 16;                  // bf16 plane pieces: 16 rows x 64 B
-    constexpr int B_IT = (BPIECES + NW - 1) / NW;
-    constexpr int STAGE = B_IT * NW * 1024;               // bytes per ring stage (weight planes only)
-    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && (NST == 2 || NST == 3) && B_IT < 64, "config");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* ring = reinterpret_cast<char*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int g = blockIdx.z;
-
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const bool nmajor = p.M < p.N;
-    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
-
-    const float* __restrict__ X = p.X + (long long)g * p.strideX;
-    const unsigned short* __restrict__ W3 = reinterpret_cast<const unsigned short*>(p.W3) + (long long)g * p.strideW;
-    const long long zoff_w = (const unsigned short*)g_zero16 - W3;
-    const long long plane = p.w3_plane;
-    const int half = lane >> 5;
-
-    int arow[TM];                                          // source row of this lane's A fragment rows (tap 0)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WTM + i * 32 + (lane & 31);
-        int b = kInvalidRow;
-        if (m < p.M) b = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
-        arow[i] = b;
-    }
-    const int Kt = p.K, ldw = p.ldw;
-    long long wofs[B_IT];
-    int wk[B_IT];
-#pragma unroll
-    for (int j = 0; j < B_IT; ++j) {
-        const int pc = j * NW + wave;                    // piece = plane * (BN / 16) + row block
-        const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
-        const int nl = rb * 16 + (lane >> 2);
-        const int n = n0 + nl;
-        wk[j] = ((lane & 3) ^ ((nl >> 2) & 3)) * 8;     // k offset of this lane's 16-byte slot inside a chunk
-        wofs[j] = (pc < BPIECES && n < p.N) ? pl * plane + (long long)n * ldw : -1;
-    }
-    const int nk = (Kt + BK - 1) / BK;
-    const int ldx = p.ldx, Rx = p.Rx, Cin = p.Cin, dil = p.dil;
-    const bool multi_tap = p.taps > 1;
-    wait_vmcnt<0>();
-    constexpr bool PRET = TM * TN <= 2;
-    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
-    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-
-    const bool fast = (Kt % BK == 0) && (!multi_tap || Cin % BK == 0);
-    const bool w_nt = p.w_nt != 0;
-    auto issue_b = [&](int c, int st) {
-        const int kchunk = c * BK;
-        char* Bs = ring + st * STAGE + wave * 1024;
-#pragma unroll
-        for (int j = 0; j < B_IT; ++j) {
-            const int k = kchunk + wk[j];
-            const bool ok = (k < Kt) & (wofs[j] >= 0);
-            const long long off = ok ? wofs[j] + k : zoff_w;
-            if (w_nt)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
-                                                 (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 2);
-            else
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
-                                                 (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
-        }
-    };
-    // A fragments of one chunk: [k-block][row tile][16-byte half]; lane (row, half) holds k = 16*b + 8*half + 0..7.
-    // TWO register buffers that alternate between "being loaded" and "being multiplied" (the K loop is unrolled by two):
-    // no register copy of a buffer ever exists in the source, so none can be scheduled between a load's issue and its
-    // landing (a copy of the in-flight registers - as a loop-carried rename produces - reads garbage, and the late
-    // write then lands on whatever lives there).
-    typedef f32x4 AFrag[2][TM][2];
-    AFrag ra0, ra1;
-    int s_tap = 0, s_cc = 0;                              // of the next chunk whose A is loaded (chunks in order)
-    auto load_a = [&](int c, AFrag& ra_n) {
-        if (fast) {
-            const int dsrc = s_tap * dil;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int src = arow[i] + dsrc;
-                const float* ptr = (unsigned)src < (unsigned)Rx ? X + (long long)src * ldx + (s_cc + half * 8) : g_zero128;
-                gload_b128<0>(ra_n[0][i][0], ptr);
-                gload_b128<16>(ra_n[0][i][1], ptr);
-                gload_b128<64>(ra_n[1][i][0], ptr);
-                gload_b128<80>(ra_n[1][i][1], ptr);
-            }
-            s_cc += BK;
-            if (multi_tap && s_cc == Cin) { s_cc = 0; ++s_tap; }
-            return;
-        }
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int k = c * BK + b * 16 + half * 8 + j * 4;
-                    int tap = 0, cc = k;
-                    if (multi_tap) { tap = k / Cin; cc = k - tap * Cin; }
-                    const int src = arow[i] + tap * dil;
-                    const bool ok = (k < Kt) & ((unsigned)src < (unsigned)Rx);
-                    gload_b128<0>(ra_n[b][i][j], ok ? X + (long long)src * ldx + cc : g_zero128);
-                }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    load_a(0, ra0);
-#pragma unroll
-    for (int st = 0; st < NST - 1; ++st)
-        if (st < nk) issue_b(st, st);
-
-    const float pro_slope = p.pro_slope;
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
-    const int nrow = wn * WTN + (lane & 31);
-    const int swzb = (nrow >> 2) & 3;
-    const unsigned b_lane = lds0 + nrow * 64;
-    unsigned koffb[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
-
-    int st = 0;
-    auto round = [&](int c, AFrag& ra, AFrag& ra_n) {
-        // A(c) and B(c) have landed once at most the youngest ring refill (B(c+1), NST = 3) is still in flight
-        if (NST == 3 && c + 1 < nk) wait_vmcnt<B_IT>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(ra[b][i][j]));      // consumers depend on the wait above
-        const unsigned sb = b_lane + (unsigned)st * STAGE;
-        if (c + 1 < nk) load_a(c + 1, ra_n);                                // older than this round's refill in the vmcnt order
-        if (c + NST - 1 < nk) issue_b(c + NST - 1, st == 0 ? NST - 1 : st - 1);
-        u32x4 rb[2][3][TN];
-        auto fetch = [&](int b) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
-                    rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
-                }
-        };
-        constexpr int F = 2 * TM, NMF = 6 * TN, VPM = (44 + NMF - 1) / NMF;
-        u32x4 pln[2][3];
-        auto products = [&](int b, int i, const u32x4* pp) {
-            const bf16x8 A1 = __builtin_bit_cast(bf16x8, pp[0]), A2 = __builtin_bit_cast(bf16x8, pp[1]),
-                         A3 = __builtin_bit_cast(bf16x8, pp[2]);
-            constexpr int PA[6] = {3, 1, 2, 2, 1, 1}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const bf16x8 At = PA[t] == 1 ? A1 : (PA[t] == 2 ? A2 : A3);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB[t]][j]);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
-                }
-            }
-        };
-        auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
-        auto wait_block = [&](int b) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
-        };
-        fetch(0);
-        fetch(1);
-        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);   // beside the LDS latency
-        __builtin_amdgcn_sched_barrier(0);
-        wait_block(0);
-        wait_block(1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < F; ++s) {
-            const int b = s / TM, i = s % TM;
-            if (s + 1 < F) {
-                const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
-                tie(b2, i2);                     // keeps this split inside this step's scheduling region
-                split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
-            }
-            products(b, i, pln[s & 1]);
-            if (TM * TN > 1) {                  // pins the MFMA order (column tiles alternate) and, before the last step,
-#pragma unroll                                  // the split of the next fragment between them
-                for (int k = 0; k < NMF; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (s + 1 < F) __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        st = st + 1 == NST ? 0 : st + 1;
-    };
-    for (int c = 0; c < nk; c += 2) {
-        round(c, ra0, ra1);
-        if (c + 1 < nk) round(c + 1, ra1, ra0);
-    }
-    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-    else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-}
-
-// ===================================================================================================
 // v2d: the x6 engine with LOADER WAVES.  Measured with s_memtime (profiles/r02_x6_phase_timing.txt): an LDS-DMA
 // instruction costs the wave that issues it 140-230 cycles wherever it is placed - 970 of a 256x128 chunk's 5270 cycles
 // when the 8 compute waves issue the refill themselves, with the matrix pipe idle meanwhile.  Here NL extra waves do
@@ -2575,243 +2337,6 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x6_ks_kernel(
     }
 }
 
-// ===================================================================================================
-// v2e: the loader-wave x6 kernel with the two halves of the compute waves DE-PHASED (128x128 tile, 3-deep ring).
-template <int BM, int BN, int WGM, int WGN, int NL, int PRO>
-__global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldrd_kernel(GemmP p) {
-    constexpr int NST = 3;
-    constexpr int NW = WGM * WGN;
-    constexpr int WTM = BM / WGM, WTN = BN / WGN;
-    constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int PA = BM / 8;                            // f32 A pieces per chunk: 8 rows x 128 B
-    constexpr int PB = 3 * BN / 16;                       // bf16 plane pieces per chunk: 16 rows x 64 B
-    constexpr int A_IT = (PA + NL - 1) / NL, B_IT = (PB + NL - 1) / NL;   // per loader wave
-    constexpr int L = A_IT + B_IT;
-    constexpr int STAGE_A = BM * BK * 4, STAGE_B = PB * 1024, STAGE = STAGE_A + STAGE_B;   // bytes
-    static_assert(PA % NL == 0 && PB % NL == 0 && WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64 &&
-                  TM * TN > 1, "config");
-    static_assert(TM == 1 && NW == 8, "de-phased variant: one row tile per wave, two groups of four waves");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* ring = reinterpret_cast<char*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = blockIdx.z;
-
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const bool nmajor = p.M < p.N;
-    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
-    const int Kt = p.K;
-    const int nk = (Kt + BK - 1) / BK;
-
-    if (wave_all >= NW) {
-        // ------------------------------------------------------------------ loader wave lw: pieces lw, lw + NL, ...
-        const int lw = wave_all - NW;
-        const float* __restrict__ X = p.X + (long long)g * p.strideX;
-        const unsigned short* __restrict__ W3 = reinterpret_cast<const unsigned short*>(p.W3) + (long long)g * p.strideW;
-        const long long zoff_x = (const float*)g_zero16 - X;
-        const long long zoff_w = (const unsigned short*)g_zero16 - W3;
-        const long long plane = p.w3_plane;
-        const int lrow = lane >> 3;
-        const int ldx = p.ldx, Rx = p.Rx, Cin = p.Cin, dil = p.dil, ldw = p.ldw;
-        const bool multi_tap = p.taps > 1;
-        int abase[A_IT], akl[A_IT];
-#pragma unroll
-        for (int j = 0; j < A_IT; ++j) {
-            const int pc = j * NL + lw;                      // A piece: rows pc*8 .. pc*8+7
-            const int m = m0 + pc * 8 + lrow;
-            int b = kInvalidRow;
-            if (m < p.M) b = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
-            abase[j] = b;
-            akl[j] = ((lane & 7) ^ ((pc * 4 + (lane >> 4)) & 7)) * 4;       // k offset of this lane's 16-byte slot
-        }
-        long long wofs[B_IT];
-        int wk[B_IT];
-#pragma unroll
-        for (int j = 0; j < B_IT; ++j) {
-            const int pc = j * NL + lw;                      // B piece = plane * (BN / 16) + row block
-            const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
-            const int nl = rb * 16 + (lane >> 2);
-            const int n = n0 + nl;
-            wk[j] = ((lane & 3) ^ ((nl >> 2) & 3)) * 8;
-            wofs[j] = n < p.N ? pl * plane + (long long)n * ldw : -1;
-        }
-        wait_vmcnt<0>();                                     // the rowbase loads
-        const bool fast = (Kt % BK == 0) && (!multi_tap || Cin % BK == 0);
-        int s_tap = 0, s_cc = 0;
-        auto issue = [&](int c, int st) {
-            const int kchunk = c * BK;
-            float* As = reinterpret_cast<float*>(ring + st * STAGE) + lw * 256;
-            char* Bs = ring + st * STAGE + STAGE_A + lw * 1024;
-            if (fast) {
-                const int dsrc = s_tap * dil;
-#pragma unroll
-                for (int j = 0; j < A_IT; ++j) {
-                    const int src = abase[j] + dsrc;
-                    const long long off = (unsigned)src < (unsigned)Rx ? (long long)src * ldx + (s_cc + akl[j]) : zoff_x;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
-                                                     (__attribute__((address_space(3))) void*)(As + j * NL * 256), 16, 0, 0);
-                }
-#pragma unroll
-                for (int j = 0; j < B_IT; ++j) {
-                    const long long off = wofs[j] >= 0 ? wofs[j] + (kchunk + wk[j]) : zoff_w;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
-                                                     (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16, 0, 0);
-                }
-                s_cc += BK;
-                if (multi_tap && s_cc == Cin) { s_cc = 0; ++s_tap; }
-                return;
-            }
-#pragma unroll
-            for (int j = 0; j < A_IT; ++j) {
-                const int k = kchunk + akl[j];
-                int tap = 0, cc = k;
-                if (multi_tap) { tap = k / Cin; cc = k - tap * Cin; }
-                const int src = abase[j] + tap * dil;
-                const bool ok = (k < Kt) & ((unsigned)src < (unsigned)Rx);
-                const long long off = ok ? (long long)src * ldx + cc : zoff_x;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
-                                                 (__attribute__((address_space(3))) void*)(As + j * NL * 256), 16, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < B_IT; ++j) {
-                const int k = kchunk + wk[j];
-                const bool ok = (k < Kt) & (wofs[j] >= 0);
-                const long long off = ok ? wofs[j] + k : zoff_w;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
-                                                 (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16, 0, 0);
-            }
-        };
-#pragma unroll
-        for (int st = 0; st < NST; ++st)
-            if (st < nk) issue(st, st);
-        // barriers B_0 .. B_{2 nk}: group A reads chunk c from LDS in [B_2c, B_2c+1) and multiplies in [B_2c+1, B_2c+2),
-        // group B reads it in [B_2c+1, B_2c+2) and multiplies in [B_2c+2, B_2c+3); the stage of chunk c is free after
-        // B_2c+2 and receives chunk c+3, which must have landed before B_2c+6 (two chunk periods of flight)
-        for (int j = 0; j <= 2 * nk; ++j) {
-            const bool even = (j & 1) == 0;
-            if (even && (j >> 1) < nk) {
-                if ((j >> 1) + 1 < nk) wait_vmcnt<L>();              // chunk j/2 landed (chunk j/2+1 may be in flight)
-                else wait_vmcnt<0>();
-            }
-            __builtin_amdgcn_s_barrier();
-            if (even && j >= 2) {
-                const int cn = (j >> 1) + 2;
-                if (cn < nk) issue(cn, cn % NST);
-            }
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- compute wave
-    const int wave = wave_all;
-    const int wm = wave / WGN, wn = wave % WGN;
-    constexpr bool PRET = TM * TN <= 2;
-    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
-    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    const float pro_slope = p.pro_slope;
-    const int half = lane >> 5;
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
-    const int swza = (lane >> 1) & 7;
-    const unsigned a_lane = lds0 + ((wm * WTM + (lane & 31)) * BK) * 4;
-    const int nrow = wn * WTN + (lane & 31);
-    const int swzb = (nrow >> 2) & 3;
-    const unsigned b_lane = lds0 + STAGE_A + nrow * 64;
-    unsigned koffa[2][2], koffb[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        koffa[b][0] = (unsigned)(((b * 4 + half * 2) ^ swza) * 16);
-        koffa[b][1] = (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
-        koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
-    }
-
-    int st = 0;
-    f32x4 ra[2][TM][2];
-    u32x4 rb[2][3][TN];
-    u32x4 pln[2][3];
-    auto fetch = [&](int b, unsigned sa, unsigned sb) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            ra[b][i][0] = lds_read_b128(sa + koffa[b][0] + i * 32 * BK * 4);
-            ra[b][i][1] = lds_read_b128(sa + koffa[b][1] + i * 32 * BK * 4);
-        }
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
-                rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
-            }
-    };
-    // products t0 <= t < t1 of fragment (b, i) with the column tiles of k-block b
-    auto products = [&](int b, int i, const u32x4* pp, int t0, int t1) {
-        const bf16x8 A1 = __builtin_bit_cast(bf16x8, pp[0]), A2 = __builtin_bit_cast(bf16x8, pp[1]),
-                     A3 = __builtin_bit_cast(bf16x8, pp[2]);
-        constexpr int PA_[6] = {3, 1, 2, 2, 1, 1}, PB_[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            if (t < t0 || t >= t1) continue;
-            const bf16x8 At = PA_[t] == 1 ? A1 : (PA_[t] == 2 ? A2 : A3);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB_[t]][j]);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
-            }
-        }
-    };
-    auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
-    auto wait_block = [&](int b) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < TM; ++i) tie(b, i);
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
-    };
-    // Two groups of four compute waves, half a chunk out of phase: the waves w and w + 4 share a SIMD, and in every
-    // barrier interval one of them fetches and splits its chunk's fragments (vector pipe, LDS) while the other issues its
-    // 24 MFMAs (matrix pipe) - the serial phase of a chunk (17-25 % of it with both waves in lockstep,
-    // profiles/r02_x6_phase_timing.txt) runs beside the partner's products.
-    const int grp = wave >> 2;
-    if (grp == 1) __builtin_amdgcn_s_barrier();        // B_0: group B starts one interval later
-    for (int c = 0; c < nk; ++c) {
-        __builtin_amdgcn_s_barrier();                  // A: B_2c, B: B_2c+1 - chunk c is in LDS
-        asm volatile("" ::: "memory");
-        const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
-        fetch(0, sa, sb);
-        fetch(1, sa, sb);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_block(0);
-        wait_block(1);
-        __builtin_amdgcn_sched_barrier(0);
-        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
-        split3_bf16<PRO>(ra[1][0][0], ra[1][0][1], pro_slope, pln[1][0], pln[1][1], pln[1][2]);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();                  // A: B_2c+1, B: B_2c+2 - the partner group starts its fetch
-        __builtin_amdgcn_sched_barrier(0);
-        products(0, 0, pln[0], 0, 6);
-        products(1, 0, pln[1], 0, 6);
-        __builtin_amdgcn_sched_barrier(0);
-        st = st + 1 == NST ? 0 : st + 1;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();        // B_2nk
-    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-    else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-}
-
 
 // ---------------------------------------------------------------------------------------------------
 // host side: tile-configuration choice and launch
@@ -2826,6 +2351,9 @@ struct TileCfg {
     int x6_ks = 0;            // > 0: x6 K-split tile (gemm_x6_ks_kernel): linear layers with K a multiple of 32 * x6_ks
 };
 
+// A configuration that was measured, documented (profiles/) and is no longer built: the index keeps its
+// meaning in the profiles of earlier rounds, launch_gemm answers hipErrorNotSupported
+#define MT2_RETIRED(NAME_) { 0, 0, 0, 0, "retired:" NAME_, { nullptr, nullptr, nullptr, nullptr, nullptr } }
 #define MT2_CFG(BM_, BN_, WM_, WN_)                                                                    \
     { BM_, BN_, WM_* WN_ * 64, 2ull * (BM_ + BN_) * LS * sizeof(float), #BM_ "x" #BN_ "_" #WM_ "x" #WN_, \
       { gemm_f32_kernel<BM_, BN_, WM_, WN_>, gemm_f32_kernel<BM_, BN_, WM_, WN_>,                        \
@@ -2862,11 +2390,6 @@ struct TileCfg {
       "x6dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                          \
       { gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_NONE>, gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
         gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
-#define MT2_GX6R(BM_, BN_, WM_, WN_, NST_)                                                                     \
-    { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (size_t)((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024, \
-      "x6areg" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                         \
-      { gemm_x6_areg_kernel<BM_, BN_, WM_, WN_, NST_, ACT_NONE>, gemm_x6_areg_kernel<BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
-        gemm_x6_areg_kernel<BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
 #define MT2_GX6L(BM_, BN_, WM_, WN_, NL_, NST_)                                                                \
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),       \
       "x6ldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
@@ -2899,11 +2422,6 @@ struct TileCfg {
       "x6ks" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "+" #NL_ "_s" #NST_,                                         \
       { gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_NONE>, gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_RELU>, \
         gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true, KS_ }
-#define MT2_GX6LD(BM_, BN_, WM_, WN_, NL_)                                                                     \
-    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)3 * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),          \
-      "x6ldrd" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s3",                                                      \
-      { gemm_x6_ldrd_kernel<BM_, BN_, WM_, WN_, NL_, ACT_NONE>, gemm_x6_ldrd_kernel<BM_, BN_, WM_, WN_, NL_, ACT_RELU>, \
-        gemm_x6_ldrd_kernel<BM_, BN_, WM_, WN_, NL_, ACT_LRELU>, nullptr, nullptr }, 0, true }
 #define MT2_WX6(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024),   \
       "x6win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                     \
@@ -2958,63 +2476,63 @@ static const TileCfg kCfgs[] = {
     MT2_GX6(256, 128, 4, 2, 2),      // 37: 8 waves, 64x64 each; 2 x 56 KiB
     MT2_GX6(128, 128, 4, 2, 3),      // 38: 8 waves, 32x64 each; 3 x 40 KiB
     MT2_GX6(128, 128, 4, 2, 2),      // 39: the same with a 2-deep ring: 80 KiB (LDS would admit two workgroups per CU, its 197 VGPRs one)
-    MT2_GX6(128, 256, 2, 4, 2),      // 40: 8 waves, 64x64 each; 2 x 64 KiB (wide N: the AR feed-forward / QKV)
-    MT2_GX6(256, 128, 8, 2, 2),      // 41: 16 waves, 32x64 each; 2 x 56 KiB (4 waves per SIMD)
-    MT2_GX6(256, 128, 8, 1, 2),      // 42: 8 waves, 32x128 each: every A fragment is split ONCE per workgroup, 24 MFMAs per split
-    MT2_GX6(128, 128, 4, 1, 2),      // 43: 4 waves, 32x128 each; 80 KiB -> 2 workgroups per CU
-    MT2_GX6(128, 256, 4, 1, 2),      // 44: 4 waves, 32x256 each (48 MFMAs per split); 2 x 64 KiB
+    MT2_RETIRED("x6dma128x256_2x4_s2"),      // 40: 8 waves, 64x64 each; 2 x 64 KiB (wide N: the AR feed-forward / QKV)
+    MT2_RETIRED("x6dma256x128_8x2_s2"),      // 41: 16 waves, 32x64 each; 2 x 56 KiB (4 waves per SIMD)
+    MT2_RETIRED("x6dma256x128_8x1_s2"),      // 42: 8 waves, 32x128 each: every A fragment is split ONCE per workgroup, 24 MFMAs per split
+    MT2_RETIRED("x6dma128x128_4x1_s2"),      // 43: 4 waves, 32x128 each; 80 KiB -> 2 workgroups per CU
+    MT2_RETIRED("x6dma128x256_4x1_s2"),      // 44: 4 waves, 32x256 each (48 MFMAs per split); 2 x 64 KiB
     // v2c: x6 with the A operand through registers (plain vector loads), weight planes through the ring
-    MT2_GX6R(256, 128, 8, 1, 3),     // 45: 8 waves, 32x128 each; ring 3 x 24 KiB
-    MT2_GX6R(256, 128, 4, 2, 3),     // 46: 8 waves, 64x64 each
-    MT2_GX6R(128, 128, 4, 2, 3),     // 47: 8 waves, 32x64 each; 72 KiB -> 2 workgroups per CU
-    MT2_GX6R(128, 128, 4, 1, 3),     // 48: 4 waves, 32x128 each
-    MT2_GX6R(64, 128, 2, 2, 3),      // 49: 4 waves, 32x64 each; 72 KiB -> 2 workgroups per CU: mid-size AR launches
-    MT2_GX6R(128, 256, 4, 2, 2),     // 50: 8 waves, 32x128 each; ring 2 x 48 KiB
+    MT2_RETIRED("x6areg256x128_8x1_s3"),     // 45: 8 waves, 32x128 each; ring 3 x 24 KiB
+    MT2_RETIRED("x6areg256x128_4x2_s3"),     // 46: 8 waves, 64x64 each
+    MT2_RETIRED("x6areg128x128_4x2_s3"),     // 47: 8 waves, 32x64 each; 72 KiB -> 2 workgroups per CU
+    MT2_RETIRED("x6areg128x128_4x1_s3"),     // 48: 4 waves, 32x128 each
+    MT2_RETIRED("x6areg64x128_2x2_s3"),      // 49: 4 waves, 32x64 each; 72 KiB -> 2 workgroups per CU: mid-size AR launches
+    MT2_RETIRED("x6areg128x256_4x2_s2"),     // 50: 8 waves, 32x128 each; ring 2 x 48 KiB
     // v2d: x6 with loader waves (the compute waves issue no vector-memory instruction inside the K loop)
     MT2_GX6L(256, 128, 4, 2, 4, 2),  // 51: 8 compute + 4 loader waves
     MT2_GX6L(256, 128, 4, 2, 2, 2),  // 52: 8 + 2
-    MT2_GX6L(128, 128, 4, 2, 4, 2),  // 53: 8 + 4
-    MT2_GX6L(128, 128, 4, 2, 2, 2),  // 54: 8 + 2
+    MT2_RETIRED("x6ldr128x128_4x2+4_s2"),  // 53: 8 + 4
+    MT2_RETIRED("x6ldr128x128_4x2+2_s2"),  // 54: 8 + 2
     MT2_GX6L(128, 128, 4, 2, 4, 3),  // 55: 8 + 4, 3-deep ring (120 KiB)
-    MT2_GX6LX(128, 128, 4, 2, 4),    // 56: the same with cross-chunk prefetch of the first fragments
-    MT2_GX6LX(128, 128, 4, 2, 2),    // 57: 8 + 2 loader waves
+    MT2_RETIRED("x6ldrx128x128_4x2+4_s3"),    // 56: the same with cross-chunk prefetch of the first fragments
+    MT2_RETIRED("x6ldrx128x128_4x2+2_s3"),    // 57: 8 + 2 loader waves
     // v3c: x6 window convolutions with loader waves
     MT2_WX6L(2, 256, 64, 8, 1, 3, 4),   // 58: 8 compute + 4 loader waves
     MT2_WX6L(4, 128, 128, 4, 2, 2, 4),  // 59
-    MT2_WX6L(4, 128, 128, 4, 2, 2, 2),  // 60: 8 + 2
-    MT2_WX6L(2, 256, 64, 8, 1, 3, 2),   // 61: 8 + 2
+    MT2_RETIRED("x6winl128x128_4x2+2_s2"),  // 60: 8 + 2
+    MT2_RETIRED("x6winl256x64_8x1+2_s3"),   // 61: 8 + 2
     // v2e: loader waves + de-phased compute groups
-    MT2_GX6LD(128, 128, 4, 2, 4),       // 62
+    MT2_RETIRED("x6ldrd128x128_4x2+4_s3"),       // 62
     // v2d, small tiles for launches that cannot fill the chip with 128x128 tiles (the AR steps' mid-size GEMMs): one
     // 32x32 tile per compute wave, 3-deep ring
     MT2_GX6L(64, 128, 2, 4, 4, 3),      // 63: 8 + 4 waves, 96 KiB
     MT2_GX6L(128, 64, 4, 2, 4, 3),      // 64: 8 + 4 waves, 84 KiB (less operand ingest per FLOP than 63: the A panel is the cheap one)
-    MT2_GX6L(64, 128, 2, 4, 2, 3),      // 65: 8 + 2 waves
-    MT2_GX6L(128, 64, 4, 2, 2, 3),      // 66: 8 + 2 waves
+    MT2_RETIRED("x6ldr64x128_2x4+2_s3"),      // 65: 8 + 2 waves
+    MT2_RETIRED("x6ldr128x64_4x2+2_s3"),      // 66: 8 + 2 waves
     // v2f: loader waves + mid-chunk barrier (MP): fragment fetch and split never wait with an empty matrix pipe
     MT2_GX6LM(128, 128, 4, 2, 4, 3),    // 67: the 55 tile
     MT2_GX6LM(256, 128, 4, 2, 4, 2),    // 68: the 51 tile
-    MT2_GX6LM(128, 64, 4, 2, 4, 3),     // 69: the 64 tile
-    MT2_GX6LM(64, 128, 2, 4, 4, 3),     // 70: the 63 tile
-    MT2_GX6LM(128, 128, 4, 2, 4, 2),    // 71: 128x128 with a 2-deep ring (80 KiB)
+    MT2_RETIRED("x6ldm128x64_4x2+4_s3"),     // 69: the 64 tile
+    MT2_RETIRED("x6ldm64x128_2x4+4_s3"),     // 70: the 63 tile
+    MT2_RETIRED("x6ldm128x128_4x2+4_s2"),    // 71: 128x128 with a 2-deep ring (80 KiB)
     // ONE compute wave per SIMD (64x64 per wave) + 4 loader waves: two barrier-synchronised waves on a SIMD run one after
     // the other (the matrix pipe's arbiter serves the older wave first, profiles/r03_ubench_x6_issue_v2.txt), each at a
     // lone wave's efficiency and each with its own exposed head; one wave with twice the tile has the same MFMA count per
     // SIMD, 37 % less LDS traffic, half the splits per MFMA, and 256 registers for the MP pipeline
     MT2_GX6LM(128, 128, 2, 2, 4, 3),    // 72: 4 + 4 waves, 120 KiB
-    MT2_GX6LM(128, 128, 2, 2, 2, 3),    // 73: 4 + 2 waves
-    MT2_GX6L(128, 128, 2, 2, 4, 3),     // 74: the same tile without the MP pipeline (A/B)
+    MT2_RETIRED("x6ldm128x128_2x2+2_s3"),    // 73: 4 + 2 waves
+    MT2_RETIRED("x6ldr128x128_2x2+4_s3"),     // 74: the same tile without the MP pipeline (A/B)
     // v2g: loader waves + FREE-RUNNING compute waves (LDS counters instead of s_barrier in the K loop)
     MT2_GX6LF(128, 128, 4, 2, 4, 3),    // 75: the 55 tile
-    MT2_GX6LF(256, 128, 4, 2, 4, 2),    // 76: the 51 tile
-    MT2_GX6LF(128, 64, 4, 2, 4, 3),     // 77: the 64 tile
-    MT2_GX6LF(128, 128, 4, 2, 2, 3),    // 78: 55 with 2 loader waves
+    MT2_RETIRED("x6ldf256x128_4x2+4_s2"),    // 76: the 51 tile
+    MT2_RETIRED("x6ldf128x64_4x2+4_s3"),     // 77: the 64 tile
+    MT2_RETIRED("x6ldf128x128_4x2+2_s3"),    // 78: 55 with 2 loader waves
     // v2h: x6 arithmetic on the K-split tiles of the AR steps, loader waves own the refill
     MT2_GX6K(32, 64, 1, 2, 4, 4, 2),    // 79: 8 compute (4 K groups of 1x2) + 4 loader waves, 128 KiB: the 22 tile
     MT2_GX6K(64, 64, 2, 2, 2, 4, 3),    // 80: 8 compute (2 K groups of 2x2) + 4 loader waves, 120 KiB: the 18 / 20 tile
-    MT2_GX6K(32, 64, 1, 2, 4, 2, 2),    // 81: 79 with 2 loader waves
+    MT2_RETIRED("x6ks32x64_1x2_k4+2_s2"),    // 81: 79 with 2 loader waves
     MT2_GX6K(32, 32, 1, 1, 8, 4, 2),    // 82: 8 K groups of one wave + 4 loader waves, 112 KiB: the 28 tile
-    MT2_GX6K(64, 64, 2, 2, 2, 4, 2),    // 83: 80 with a 2-deep ring (80 KiB)
+    MT2_RETIRED("x6ks64x64_2x2_k2+4_s2"),    // 83: 80 with a 2-deep ring (80 KiB)
     MT2_GX6K(32, 64, 1, 2, 4, 8, 2),    // 84: 79 with EIGHT loader waves (16 waves: a round's 64 pieces are 8 per loader)
     MT2_GX6K(64, 64, 2, 2, 2, 8, 3),    // 85: 80 with eight loader waves (5 pieces per loader and round)
     MT2_GX6K(32, 32, 1, 1, 8, 8, 2),    // 86: 82 with eight loader waves
@@ -3163,9 +2681,9 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     if (o.x6_gemm && p.W3 && (p.K & 7) == 0 && (p.ldw & 7) == 0 && p.pro_act < PRO_LN && p.N > 64) {
         // loader-wave variants (profiles/r02_gemm_sweep_x6_v5_ldr.txt: +10..12 % over 37, +16..20 % over 39)
         if (t256 >= o.t_x6_256) bi = o.x6_loaders ? 51 : 37;
-        else if (t128 >= o.t_x6_128) bi = t128 <= o.t_x6_64 ? 49 : (o.x6_loaders ? 55 : 39);
+        else if (t128 >= o.t_x6_128) bi = o.x6_loaders ? 55 : 39;
         // small x6 tiles (x6_small_cfg = 63..66) for launches whose 128x128 tiles would leave most of the chip idle
-        if (o.x6_small_cfg >= 63 && o.x6_small_cfg <= 66 && t256 < o.t_x6_256 && t128 <= o.t_x6_small_max) {
+        if (o.x6_small_cfg >= 63 && o.x6_small_cfg <= 64 && t256 < o.t_x6_256 && t128 <= o.t_x6_small_max) {
             const TileCfg& sc = kCfgs[o.x6_small_cfg];
             const long long ts = (long long)((p.M + sc.bm - 1) / sc.bm) * ((p.N + sc.bn - 1) / sc.bn) * p.groups;
             if (ts >= o.t_x6_small_min) bi = o.x6_small_cfg;
@@ -3173,7 +2691,7 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
         // MP form of the loader-wave tiles (mid-chunk barrier, fragment fetch / split behind the previous products)
         // K-split tiles on the bf16 pipe (x6_ks: 1 = the 32x64 k4 and 64x64 k4/k2 tiles, 2 = the 32x32 k8 tile too)
         if (o.x6_ks && p.taps == 1 && p.groups >= 1) {
-            const bool l8 = o.x6_ks >= 3;                 // 3, 4: the eight-loader forms
+            const bool l8 = true;                         // the eight-loader forms (the four-loader ones, 79 / 80 / 82, stay for A/B via force)
             // the 64x64 K-split x6 tile also beats the 128x128 loader tile while the launch has few 64x64 tiles
             // (profiles/r03_gemm_sweep_x6k.txt: 448x3072x1024 82 vs 64 TF/s, 448x4096x1024 106 vs 82)
             if (bi == 55 && t64 <= o.t_x6_ks_over128 && p.K % (BK * 2) == 0) bi = 20;
@@ -3182,10 +2700,9 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
             else if ((o.x6_ks == 2 || o.x6_ks == 4) && bi == 28 && p.K % (BK * 8) == 0) bi = l8 ? 86 : 82;
         }
         if (o.x6_mp256 && bi == 51) bi = 68;             // MP form of the 256x128 tile only (+2..7 % on the conv-stack shapes)
-        if (o.x6_mp == 4) bi = bi == 55 ? 75 : (bi == 64 ? 77 : bi);                       // free-running compute waves
-        else if (o.x6_mp == 5) bi = bi == 55 ? 75 : (bi == 51 ? 76 : (bi == 64 ? 77 : bi));
+        if (o.x6_mp == 4) bi = bi == 55 ? 75 : bi;            // free-running compute waves (128x128)
         else if (o.x6_mp == 3) bi = bi == 55 ? 72 : bi;       // one compute wave per SIMD, MP pipeline
-        else if (o.x6_mp) bi = bi == 55 ? 67 : (bi == 51 && o.x6_mp >= 2 ? 68 : (bi == 64 ? 69 : (bi == 63 ? 70 : bi)));
+        else if (o.x6_mp) bi = bi == 55 ? 67 : (bi == 51 && o.x6_mp >= 2 ? 68 : bi);
     }
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;
     *idx_out = bi;
@@ -3252,6 +2769,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
         lds = c->lds + (size_t)c->win_qs * wrp * BK * sizeof(float);
     }
     void (*fn)(GemmP) = c->fn[p.pro_act];
+    if (!fn) return hipErrorNotSupported;           // retired configuration / no variant for this prologue
     if (!g_attr_done[idx][p.pro_act] || c->win_qs) {
         if (c->win_qs) lds_attr = c->lds + (size_t)c->win_qs * ((c->bm + 64 + 7) & ~7) * BK * sizeof(float);
         if (!g_attr_done[idx][p.pro_act]) {

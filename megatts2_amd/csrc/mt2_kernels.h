@@ -68,12 +68,10 @@ struct EngineOpts {
     bool x6_loaders = true;      // x6 GEMM tiles with loader waves (gemm_x6_ldr_kernel) instead of self-refilling compute waves
     bool nt_weights = false;     // non-temporal weight loads when a launch has at most nt_row_tiles row tiles (AR steps)
     int nt_row_tiles = 2;
-    int t_x6_64 = 0;             // up to this many 128x128 tiles an x6 launch uses 64x128 tiles (A through registers, 2 WG/CU):
-                                 // +10 % on the isolated kernels, -1 % inside the model (profiles/r02_opts_ab.txt): off
     int t_x6_256 = 160, t_x6_128 = 72;   // ... from this many 256x128 / 128x128 tiles on (profiles/r02_gemm_sweep_x6.txt)
-    int x6_ks = 4;               // x6 arithmetic + loader waves for the AR steps' K-split tiles (gemm_x6_ks_kernel): 0 off;
-                                 // 1 / 2: four loader waves (configs 79, 80 / + 82 for the 32x32 k8 tile); 3 / 4: EIGHT loader
-                                 // waves (84, 85 / + 86); 5: the 64x64 tile only.  Default 4: isolated launches +10..50 %
+    int x6_ks = 4;               // x6 arithmetic + eight loader waves for the AR steps' K-split tiles (gemm_x6_ks_kernel): 0 off;
+                                 // 1, 3: the 32x64 k4 and 64x64 k2/k4 tiles (84, 85); 2, 4: + the 32x32 k8 tile (86); 5: the
+                                 // 64x64 tile only (four-loader forms 79 / 80 / 82: force only).  Default 4: isolated launches +10..50 %
                                  // (profiles/r03_gemm_sweep_x6k.txt), C3 step -1.6 % (profiles/r03_ab_interleaved_v1.txt)
     int t_x6_ks_over128 = 0;     // with x6_ks: up to this many 64x64 tiles the K-split x6 tile replaces the 128x128 loader tile
     bool epi_t4 = true;          // DPP-transposed 16-byte-store epilogue for wave tiles without epilogue prefetch
@@ -82,7 +80,7 @@ struct EngineOpts {
     int skinny_rows = 64;        // linear layers with at most this many rows (<= 64) run on the weight-streaming kernel of
     int skinny_groups = 1;       // ... only for launches with at least this many GemmP groups (split-K slabs)
     int skinny_nt = 0;           // gemm_skinny.hip (0: off); skinny_nt: non-temporal weight loads (measured: C1 65.2 ms with, 56.8 without)
-    int x6_small_cfg = 0;        // 63..66: small loader-wave x6 tile for launches with at most t_x6_small_max 128x128 tiles and
+    int x6_small_cfg = 0;        // 63..64: small loader-wave x6 tile for launches with at most t_x6_small_max 128x128 tiles and
     int t_x6_small_max = 200, t_x6_small_min = 48;   // at least t_x6_small_min small tiles (0: off)
     bool markers = false;        // a named no-op kernel at every stage boundary: lets tools/pmc_stage_summary.py attribute
                                  // the rocprofv3 --pmc rows of one step to stages (measurement only)

@@ -48,6 +48,20 @@ def test_gemm_linear_all_tile_configs(rt, cfg, M, N, K):
     assert rel(out.cpu().numpy(), ref) < 2e-6
 
 
+def test_retired_configurations_answer_not_supported(rt):
+    """Measured-and-rejected kernel variants are no longer built (DESIGN 4.2 / 4.5 keep their numbers): the index keeps its
+    name with a "retired:" prefix and a forced launch fails loudly instead of silently running something else."""
+    import ctypes
+    lib = rt.load_library()
+    lib.mt2_gemm_config_name.restype = ctypes.c_char_p
+    names = [lib.mt2_gemm_config_name(i).decode() for i in range(lib.mt2_gemm_config_count())]
+    retired = [i for i, n in enumerate(names) if n.startswith("retired:")]
+    assert 49 in retired and 62 in retired and 55 not in retired and 51 not in retired and len(retired) == 30
+    X = dev(np.ones((64, 64), np.float32))
+    with pytest.raises(rt.NativeError):
+        rt.op_conv_x6(X, X, None, None, force_cfg=49)
+
+
 def test_gemm_is_transpose_detecting(rt):
     # asymmetric operands: a swapped C layout or operand order cannot pass
     M, N, K = 64, 96, 32
@@ -191,8 +205,8 @@ def test_gemm_with_layernorm_prologue(rt, cfg, M, N, K):
 
 @pytest.mark.parametrize("k,dil,C,cfg", [(3, 1, 32, 34), (7, 3, 32, 34), (11, 5, 32, -1), (3, 5, 64, 35), (7, 1, 64, -1),
                                          (11, 5, 64, 35), (3, 3, 128, 36), (7, 5, 128, -1), (11, 1, 128, 36),
-                                         (3, 5, 64, 58), (11, 5, 64, 58), (7, 1, 64, 61), (3, 3, 128, 59), (11, 5, 128, 59),
-                                         (7, 5, 128, 60), (11, 1, 128, 60)])
+                                         (3, 5, 64, 58), (11, 5, 64, 58), (7, 1, 64, 58), (3, 3, 128, 59), (11, 5, 128, 59),
+                                         (7, 5, 128, 59), (11, 1, 128, 59)])
 @pytest.mark.parametrize("pro", ["none", "lrelu"])
 def test_window_conv_x6_is_f32_equivalent(rt, k, dil, C, cfg, pro):
     """The window convolution on the bf16 matrix pipe (weights as three bf16 planes, activations split in registers,
@@ -239,7 +253,7 @@ def test_window_conv_x6_is_f32_equivalent(rt, k, dil, C, cfg, pro):
     assert rel(x6, f32) < 2e-6
 
 
-@pytest.mark.parametrize("cfg", [37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71, 72, 73, 74, 75, 76, 77, 78])
+@pytest.mark.parametrize("cfg", [37, 38, 39, 51, 52, 55, 63, 64, 67, 68, 72, 75])
 @pytest.mark.parametrize("M,N,taps,cin,dil", [(300, 512, 1, 256, 1), (77, 96, 1, 104, 1), (1000, 384, 5, 384, 1),
                                                (700, 64, 3, 80, 1), (515, 256, 7, 256, 3), (2240, 4096, 1, 1024, 1)])
 def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
@@ -269,7 +283,7 @@ def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
     assert not x6[valid == 0].any()
 
 
-@pytest.mark.parametrize("cfg", [79, 80, 81, 82, 83, 84, 85, 86])
+@pytest.mark.parametrize("cfg", [79, 80, 82, 84, 85, 86])
 @pytest.mark.parametrize("M,N,K", [(300, 512, 256), (77, 96, 512), (448, 3072, 1024), (33, 200, 768), (224, 1024, 4096),
                                    (16, 1024, 1024)])
 def test_gemm_x6_ks_is_f32_equivalent(rt, cfg, M, N, K):
@@ -316,7 +330,7 @@ def test_gemm_skinny_streams_weights_for_a_handful_of_rows(rt, M, N, K, a_mul, s
         y = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=cfg, **kw).cpu().numpy()
         assert rel(y, ref) < 1e-6, (cfg, rel(y, ref))
         assert not y[valid == 0].any()
-    f32 = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=5, **kw).cpu().numpy()
+    f32 = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=22, **kw).cpu().numpy()
     assert rel(y, ref) <= 2.0 * rel(f32, ref) + 1e-7
 
 
@@ -351,7 +365,7 @@ def test_gemm_x6_every_prologue_at_production_size(rt, cfg, pro):
         assert np.abs(x6 - ref).max() < 2e-5 * np.abs(ref).max(), (cfg, pro, M)
 
 
-@pytest.mark.parametrize("cfg", [51, 55, 39, 67, 69, 72, 75])
+@pytest.mark.parametrize("cfg", [51, 55, 39, 67, 64, 72, 75])
 def test_gemm_x6_corner_cases(rt, cfg):
     """Documented corner behaviour of the 3-plane split (DESIGN 4.2 "Corner cases"), against the f32-MFMA kernel and float64:
       * magnitudes 1e+30 / 1e-30 (all three planes normal bf16 numbers): f32-equivalent like any other input, and the

@@ -269,9 +269,182 @@ __global__ __launch_bounds__(256) void attn_f32_reg_kernel(AttnP p) {
         }
 }
 
+// Very long sequences (default: >= 640 queries, AttnP::lds_min_qlen): the LDS-tiled form.  The register kernel above gives every 32-query tile its own
+// workgroup and lets each of its waves fetch "its" K / V tiles from memory - right for the <= 3 key tiles of a 70-position
+// step (one round trip per launch), wrong for 834 positions: 27 query tiles re-read the whole K / V of the head, a wave
+// holds ~270 registers (one wave per SIMD) and the matrix pipe idles through every softmax and every load
+// (profiles/r03_c5_kernel_stats.csv: 47 TF/s, 18 % of a C5 step).  Here a workgroup of 4 or 8 waves owns as many consecutive query
+// tiles of one (utterance, head); the K and V tiles (32 keys x D, f32) are loaded ONCE per workgroup, coalesced, one tile
+// ahead, into a double-buffered LDS stage (rows padded to D + 4 floats) and every wave reads its MFMA operands from
+// there: 4-8x fewer global loads, two waves per SIMD (one wave's softmax under the other's MFMAs).  The per-tile
+// arithmetic is the register kernel's (same MFMA, same online-softmax update, keys in ascending order).  Measured
+// (tools/attn_bench.py, profiles/r03_attn_bench.txt): +25 % at 834 positions (60 vs 45 TF/s), nothing below ~600 - both
+// kernels sit at ~0.65 of the f32 MFMA rate at the sustained clock; what is left is the arithmetic (an x6 form), not the loads.
+template <int D, int NWQ>     // NWQ waves = NWQ consecutive query tiles per workgroup
+__global__ __launch_bounds__(64 * NWQ) void attn_f32_lds_kernel(AttnP p) {
+    constexpr int NT = 64 * NWQ;
+    constexpr int NF = D / 8, DT = D / 32, LDK = D + 4, NLD = 16 * D / NT;   // NLD float4 per thread and tile (K and V together)
+    static_assert((16 * D) % NT == 0, "tile size must be a multiple of the workgroup size");
+    constexpr int TILE = 32 * LDK;                                      // floats per K (or V) tile in LDS
+    extern __shared__ __attribute__((aligned(16))) float amem[];        // [2 stages][K | V][32][LDK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    int qs, ql, ks, kl;
+    if (p.q_start) {
+        qs = p.q_start[b]; ql = p.q_len[b]; ks = p.kv_start[b]; kl = p.kv_len[b];
+    } else {
+        qs = b * p.u_qstride; ql = p.u_qlen; ks = b * p.u_kvstride; kl = p.u_kvlen;
+    }
+    if (blockIdx.x * 32 * NWQ >= ql || kl <= 0) return;                 // block-uniform
+    const int os = p.o_start ? p.o_start[b] : (p.q_start ? qs : b * (p.u_ostride ? p.u_ostride : p.u_qstride));
+    const int qt = blockIdx.x * NWQ + wave;
+    const bool active = qt * 32 < ql;                                   // wave-uniform: idle waves still load and synchronise
+    const int qrow = qt * 32 + l31;
+    const bool qok = qrow < ql;
+    const float scale = p.scale;
+
+    // cooperative tile load: float4 index f = tid + j * NT over [K rows | V rows] (32 * D / 4 float4 each)
+    float4 pre[NLD];
+    auto gload = [&](int kv0) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int f = tid + j * NT;
+            const int isv = f >= 8 * D ? 1 : 0;
+            const int g = f - isv * 8 * D, row = g / (D / 4), c4 = g - row * (D / 4);
+            const int kvr = kv0 + row;
+            const float* src = isv ? p.V + (long long)(ks + kvr) * p.ldv + h * D + c4 * 4
+                                   : p.K + (long long)(ks + kvr) * p.ldk + h * D + c4 * 4;
+            pre[j] = kvr < kl ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto sstore = [&](int st) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int f = tid + j * NT;
+            const int isv = f >= 8 * D ? 1 : 0;
+            const int g = f - isv * 8 * D, row = g / (D / 4), c4 = g - row * (D / 4);
+            *reinterpret_cast<float4*>(amem + (st * 2 + isv) * TILE + row * LDK + c4 * 4) = pre[j];
+        }
+    };
+
+    float4 qf[NF];
+    {
+        const float* __restrict__ qptr = p.Q + (long long)(qs + (qok ? qrow : 0)) * p.ldq + h * D + 4 * half;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) qf[f] = active ? *reinterpret_cast<const float4*>(qptr + 8 * f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.0f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    int st = 0;
+    for (int kv0 = 0; kv0 < kl; kv0 += 32) {
+        const bool more = kv0 + 32 < kl;                                // block-uniform
+        if (more) gload(kv0 + 32);                                      // in flight during this tile's MFMAs
+        if (active) {
+            const float* Ks = amem + (st * 2) * TILE + l31 * LDK + 4 * half;
+            const float* Vs = amem + (st * 2 + 1) * TILE + l31;
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.0f;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const float4 kf = *reinterpret_cast<const float4*>(Ks + 8 * f);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[f].x, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[f].y, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[f].z, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[f].w, s, 0, 0, 0);
+            }
+            // s[e] = S^T[kv0 + (e&3) + 8*(e>>2) + 4*half][q = l31]
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                s[e] = kvr < kl ? s[e] * scale : -INFINITY;
+                mloc = fmaxf(mloc, s[e]);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float m_new = fmaxf(m_run, mloc);          // finite: key kv0 is always in range
+            const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first tile
+            float lsum = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[e] = expf(s[e] - m_new);
+                lsum += s[e];
+            }
+            lsum += __shfl_xor(lsum, 32);
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = Vs[((e & 3) + 8 * (e >> 2) + 4 * half) * LDK + t * 32];   // rows past kl are zero in LDS
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, s[e], o[t], 0, 0, 0);
+                }
+            }
+        }
+        if (more) sstore(st ^ 1);      // the other stage was last read before the barrier that ended the previous tile
+        __syncthreads();
+        st ^= 1;
+    }
+    if (!active || !qok) return;
+    const float inv = 1.0f / l_run;
+    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo + h * D + 4 * half;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            float4 v;
+            v.x = o[t][4 * e4 + 0] * inv;
+            v.y = o[t][4 * e4 + 1] * inv;
+            v.z = o[t][4 * e4 + 2] * inv;
+            v.w = o[t][4 * e4 + 3] * inv;
+            *reinterpret_cast<float4*>(orow + t * 32 + 8 * e4) = v;
+        }
+}
+
+template <int D, int NWQ>
+static hipError_t launch_attn_lds(const AttnP& p, hipStream_t s) {
+    static bool attr_done = false;
+    void (*fn)(AttnP) = attn_f32_lds_kernel<D, NWQ>;
+    const size_t lds = (size_t)4 * 32 * (D + 4) * sizeof(float);
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((p.max_qlen + 32 * NWQ - 1) / (32 * NWQ), p.H, p.B), dim3(64 * NWQ), lds, s, p);
+    return hipGetLastError();
+}
+template <int D>
+static hipError_t launch_attn_lds_d(const AttnP& p, hipStream_t s) {
+    // 4 query tiles per workgroup (two workgroups per CU) unless 8 is asked for: profiles/r03_attn_bench.txt - 8x96 at
+    // 834 positions 189 us (register kernel) / 141 (4) / 213 (8); 16x64 at 646: 137 / 142 / 133
+    if (p.lds_waves == 8) return launch_attn_lds<D, 8>(p, s);
+    return launch_attn_lds<D, 4>(p, s);
+}
+
 hipError_t launch_attention(const AttnP& p, hipStream_t s) {
     if (p.B <= 0 || p.H <= 0 || p.max_qlen <= 0) return hipSuccess;
     if (p.D % 32 != 0 || (p.ldq & 3) || (p.ldk & 3) || (p.ldo & 3)) return hipErrorInvalidValue;
+    if (p.D <= 128 && p.max_qlen >= p.lds_min_qlen && p.lds_min_qlen > 0 && (p.ldv & 3) == 0) {
+        switch (p.D) {        // long sequences: K / V tiles shared by 8 query tiles through LDS
+            case 32: return launch_attn_lds_d<32>(p, s);
+            case 64: return launch_attn_lds_d<64>(p, s);
+            case 96: return launch_attn_lds_d<96>(p, s);
+            default: return launch_attn_lds_d<128>(p, s);
+        }
+    }
     if (p.D <= 128) {
         // split-KV width: the longest key range of the launch (uniform geometry knows it exactly; ragged
         // launches pass max_kvlen, 0 = unknown -> assume as long as the queries)

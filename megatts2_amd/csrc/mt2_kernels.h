@@ -78,6 +78,8 @@ struct EngineOpts {
     bool x6_mp256 = false;       // MP form (config 68) wherever the 256x128 loader tile (51) would run
     int x6_mp = 0;               // 1: MP form (gemm_x6_ldr_kernel<..., MP>) of the 128x128 and small loader tiles, 2: of 256x128 too
     int skinny_rows = 64;        // linear layers with at most this many rows (<= 64) run on the weight-streaming kernel of
+    int attn_lds_min = 640;      // attention: from this many queries per sequence on the LDS-tiled kernel (AttnP::lds_min_qlen; 0 never)
+    int attn_lds_waves = 0;      // ... its query tiles per workgroup (AttnP::lds_waves)
     int skinny_groups = 1;       // ... only for launches with at least this many GemmP groups (split-K slabs)
     int skinny_nt = 0;           // gemm_skinny.hip (0: off); skinny_nt: non-temporal weight loads (measured: C1 65.2 ms with, 56.8 without)
     int x6_small_cfg = 0;        // 63..64: small loader-wave x6 tile for launches with at most t_x6_small_max 128x128 tiles and
@@ -138,6 +140,9 @@ struct AttnP {
     int u_qstride, u_qlen, u_kvstride, u_kvlen, u_ostride;
     int B, H, D, max_qlen; float scale;
     int max_kvlen;   // ragged launches: longest key range (0 = unknown), sizes the split-KV width
+    int lds_min_qlen = 640;   // from this many queries on (and D <= 128) the LDS-tiled kernel shares K / V tiles between 8 query
+                              // tiles of a workgroup (attn_f32_lds_kernel); 0: never
+    int lds_waves = 0;        // query tiles per workgroup of that kernel: 8, otherwise 4
 };
 hipError_t launch_attention(const AttnP& p, hipStream_t s);
 

@@ -497,6 +497,38 @@ def test_attention_ragged(rt, H, D):
             assert rel(out[qs[b]:qs[b] + qlens[b], sl], ref) < 3e-6
 
 
+@pytest.mark.parametrize("waves", [0, 4, 8])
+@pytest.mark.parametrize("H,D", [(16, 64), (8, 96), (2, 32), (1, 128)])
+def test_attention_long_sequences_lds_tiled(rt, H, D, waves):
+    """attn_f32_lds_kernel (>= 128 queries: the C5 steps): 8 query tiles of a workgroup share the K / V tiles through a
+    double-buffered LDS stage.  Ragged batch with lengths around the 256-query workgroup and the 32-key tile boundaries,
+    idle waves in the last workgroup, a score spike in a late key tile (rescale), cross-shaped ranges; against float64."""
+    rng = np.random.default_rng(H * 77 + D)
+    qlens, kvlens = [834, 256, 129, 300, 1], [834, 257, 129, 95, 700]
+    d = H * D
+    qs = np.cumsum([0] + qlens[:-1]).astype(np.int32) + 3
+    ks = np.cumsum([0] + kvlens[:-1]).astype(np.int32) + 5
+    Q = rng.standard_normal((qs[-1] + qlens[-1] + 2, d)).astype(np.float32)
+    KV = rng.standard_normal((ks[-1] + kvlens[-1] + 2, 2 * d)).astype(np.float32)
+    KV[ks[0] + 800, :D] = Q[qs[0] + 5, :D] * 4.0            # spike in the 26th key tile of utterance 0, head 0
+    kv = dev(KV)
+    out = rt.op_attention(dev(Q), kv[:, :d], kv[:, d:], dev(qs), dev(np.asarray(qlens, np.int32)), dev(ks),
+                          dev(np.asarray(kvlens, np.int32)), H, D, 1.0 / math.sqrt(D), lds_min_qlen=1 if waves else -1,
+                          lds_waves=waves).cpu().numpy()
+    for b in range(len(qlens)):
+        q = Q[qs[b]:qs[b] + qlens[b]].astype(np.float64)
+        k = KV[ks[b]:ks[b] + kvlens[b], :d].astype(np.float64)
+        v = KV[ks[b]:ks[b] + kvlens[b], d:].astype(np.float64)
+        for h in range(H):
+            sl = slice(h * D, (h + 1) * D)
+            sc = q[:, sl] @ k[:, sl].T / math.sqrt(D)
+            pr = np.exp(sc - sc.max(1, keepdims=True))
+            ref = (pr / pr.sum(1, keepdims=True)) @ v[:, sl]
+            assert rel(out[qs[b]:qs[b] + qlens[b], sl], ref) < 3e-6, (b, h)
+    # rows outside every utterance's range are untouched (the op zero-fills its output)
+    assert not out[:3].any() and not out[qs[-1] + qlens[-1]:].any()
+
+
 def test_attention_forces_online_softmax_rescale(rt):
     """A key tile whose scores dwarf the previous tiles' maximum exercises the rescale branch."""
     rng = np.random.default_rng(9)

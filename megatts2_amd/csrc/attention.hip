@@ -434,9 +434,257 @@ static hipError_t launch_attn_lds_d(const AttnP& p, hipStream_t s) {
     return launch_attn_lds<D, 4>(p, s);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same attention on the bf16 matrix pipe, f32-equivalent ("x6", see gemm_f32.hip: an f32 number is exactly the sum of
+// three bf16 numbers, a product of two bf16 is exact in f32, and six of the nine plane products carry everything above
+// 2^-24 |a||b|).  Both contractions take activations on both sides, so every operand is split at run time:
+//   K tile  [32 keys][D]      -> three bf16 planes in LDS, row-major           (split ONCE per workgroup and tile)
+//   V tile  [32 keys][D]      -> three bf16 planes in LDS, TRANSPOSED [D][32]  (so that a lane reads 8 keys of one channel)
+//   Q rows  (one per lane)    -> three planes in registers                      (once per workgroup)
+//   P = exp(S - m)            -> three planes in registers, per tile and wave: the accumulator layout of S^T (lane = query,
+//                                16 of the 32 keys) IS the B-operand layout of v_mfma_f32_32x32x16_bf16 once the keys of a
+//                                16-key block are permuted (a free choice, the same permutation is applied to V^T in LDS).
+// Per 32x32 tile pair: 6 * D/16 + 6 * 2 * D/32 MFMAs of 32 cycles instead of 2 * D/2 ... of 64: 2.67x fewer pipe cycles.
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+typedef float af32x4 __attribute__((ext_vector_type(4)));
+
+// (lo, hi) = 8 consecutive f32 -> three planes of 8 bf16 (truncation split, exact sum), element 2i / 2i+1 in dword i
+__device__ __forceinline__ void attn_split3(const af32x4& lo, const af32x4& hi, au32x4& p1, au32x4& p2, au32x4& p3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = i < 2 ? lo[2 * i] : hi[2 * i - 4];
+        const float y = i < 2 ? lo[2 * i + 1] : hi[2 * i - 3];
+        const unsigned xb = __float_as_uint(x), yb = __float_as_uint(y);
+        p1[i] = __builtin_amdgcn_perm(yb, xb, 0x07060302u);
+        const float xr = x - __uint_as_float(xb & 0xffff0000u), yr = y - __uint_as_float(yb & 0xffff0000u);
+        const unsigned xc = __float_as_uint(xr), yc = __float_as_uint(yr);
+        p2[i] = __builtin_amdgcn_perm(yc, xc, 0x07060302u);
+        const float xs = xr - __uint_as_float(xc & 0xffff0000u), ys = yr - __uint_as_float(yc & 0xffff0000u);
+        p3[i] = __builtin_amdgcn_perm(__float_as_uint(ys), __float_as_uint(xs), 0x07060302u);
+    }
+}
+// acc += A B with the six plane products, smallest terms first
+__device__ __forceinline__ void attn_x6(f32x16& acc, const au32x4 (&a)[3], const au32x4 (&b)[3]) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, a[PA[t]]), __builtin_bit_cast(abf16x8, b[PB[t]]), acc, 0, 0, 0);
+}
+
+template <int D, int NWQ>     // D = 64 or 96; workgroup = NWQ waves = NWQ consecutive query tiles of one (utterance, head)
+__global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) void attn_x6_kernel(AttnP p) {
+    constexpr int NT = 64 * NWQ;
+    constexpr int NB = D / 16, DT = D / 32;
+    constexpr int RSK = D * 2 + 16;                 // bytes per key row of a K plane (padded)
+    constexpr int RSV = 64 + 16;                    // bytes per channel row of a V^T plane: 32 keys (permuted) + pad
+    constexpr int KPL = 32 * RSK, VPL = D * RSV;    // bytes per plane
+    constexpr int KI = (4 * D + NT - 1) / NT;       // staging items per thread: K (32 rows x D/8 groups of 8 channels) ...
+    constexpr int VI = (4 * D + NT - 1) / NT;       // ... and V (D channels x 4 groups of 8 keys)
+    extern __shared__ __attribute__((aligned(16))) char xmem[];          // [3 K planes][3 V^T planes]
+    char* kp = xmem;
+    char* vp = xmem + 3 * KPL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y;
+    int qs, ql, ks, kl;
+    if (p.q_start) {
+        qs = p.q_start[b]; ql = p.q_len[b]; ks = p.kv_start[b]; kl = p.kv_len[b];
+    } else {
+        qs = b * p.u_qstride; ql = p.u_qlen; ks = b * p.u_kvstride; kl = p.u_kvlen;
+    }
+    if (blockIdx.x * 32 * NWQ >= ql || kl <= 0) return;                      // block-uniform
+    const int os = p.o_start ? p.o_start[b] : (p.q_start ? qs : b * (p.u_ostride ? p.u_ostride : p.u_qstride));
+    const int qt = blockIdx.x * NWQ + wave;
+    const bool active = qt * 32 < ql;                                   // wave-uniform
+    const int qrow = qt * 32 + l31;
+    const bool qok = qrow < ql;
+    const float scale = p.scale;
+
+    // ---- staging: global -> registers (one tile ahead) -> split -> LDS planes
+    af32x4 kreg[KI][2];
+    float vreg[VI][8];
+    auto prefetch = [&](int kv0) {
+#pragma unroll
+        for (int j = 0; j < KI; ++j) {
+            const int i = tid + j * NT;
+            if (i < 4 * D) {
+                const int row = i / (D / 8), grp = i - row * (D / 8);
+                const bool ok = kv0 + row < kl;
+                const float* src = p.K + (long long)(ks + (ok ? kv0 + row : 0)) * p.ldk + h * D + grp * 8;
+                const af32x4 z = {0.f, 0.f, 0.f, 0.f};
+                kreg[j][0] = ok ? *reinterpret_cast<const af32x4*>(src) : z;
+                kreg[j][1] = ok ? *reinterpret_cast<const af32x4*>(src + 4) : z;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VI; ++j) {
+            const int i = tid + j * NT;
+            if (i < 4 * D) {
+                const int G = i / D, d = i - G * D;                      // G = 2 * key block + operand half
+                const float* src = p.V + (long long)ks * p.ldv + h * D + d;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int kvr = kv0 + 16 * (G >> 1) + 4 * (G & 1) + (q & 3) + 8 * (q >> 2);
+                    vreg[j][q] = kvr < kl ? src[(long long)kvr * p.ldv] : 0.0f;
+                }
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < KI; ++j) {
+            const int i = tid + j * NT;
+            if (i < 4 * D) {
+                const int row = i / (D / 8), grp = i - row * (D / 8);
+                au32x4 a, bq, c;
+                attn_split3(kreg[j][0], kreg[j][1], a, bq, c);
+                char* dst = kp + row * RSK + grp * 16;
+                *reinterpret_cast<au32x4*>(dst) = a;
+                *reinterpret_cast<au32x4*>(dst + KPL) = bq;
+                *reinterpret_cast<au32x4*>(dst + 2 * KPL) = c;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VI; ++j) {
+            const int i = tid + j * NT;
+            if (i < 4 * D) {
+                const int G = i / D, d = i - G * D;
+                const af32x4 lo = {vreg[j][0], vreg[j][1], vreg[j][2], vreg[j][3]};
+                const af32x4 hi = {vreg[j][4], vreg[j][5], vreg[j][6], vreg[j][7]};
+                au32x4 a, bq, c;
+                attn_split3(lo, hi, a, bq, c);
+                char* dst = vp + d * RSV + G * 16;
+                *reinterpret_cast<au32x4*>(dst) = a;
+                *reinterpret_cast<au32x4*>(dst + VPL) = bq;
+                *reinterpret_cast<au32x4*>(dst + 2 * VPL) = c;
+            }
+        }
+    };
+
+    // ---- Q planes: lane (query l31, half) holds channels 16 f + 8 half + 0..7 of its row
+    au32x4 qp[NB][3];
+    {
+        const float* __restrict__ qptr = p.Q + (long long)(qs + (qok ? qrow : 0)) * p.ldq + h * D + 8 * half;
+#pragma unroll
+        for (int f = 0; f < NB; ++f) {
+            af32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+            if (active) {
+                lo = *reinterpret_cast<const af32x4*>(qptr + 16 * f);
+                hi = *reinterpret_cast<const af32x4*>(qptr + 16 * f + 4);
+            }
+            attn_split3(lo, hi, qp[f][0], qp[f][1], qp[f][2]);
+        }
+    }
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[t][e] = 0.0f;
+
+    prefetch(0);
+    for (int kv0 = 0; kv0 < kl; kv0 += 32) {
+        stage();
+        __syncthreads();
+        if (kv0 + 32 < kl) prefetch(kv0 + 32);                          // block-uniform; in flight during the MFMAs
+        if (active) {
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.0f;
+            const char* krow = kp + l31 * RSK + half * 16;
+#pragma unroll
+            for (int f = 0; f < NB; ++f) {
+                au32x4 ka[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) ka[pl] = *reinterpret_cast<const au32x4*>(krow + pl * KPL + f * 32);
+                attn_x6(s, ka, qp[f]);
+            }
+            // s[e] = S^T[kv0 + (e&3) + 8*(e>>2) + 4*half][q = l31]
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                s[e] = kvr < kl ? s[e] * scale : -INFINITY;
+                mloc = fmaxf(mloc, s[e]);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = expf(m_run - m_new);
+            float lsum = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[e] = expf(s[e] - m_new);
+                lsum += s[e];
+            }
+            lsum += __shfl_xor(lsum, 32);
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
+            // P planes of key block kb: the lane's s[8 kb .. 8 kb + 7] (keys 16 kb + 4 half + {0..3, 8..11}: the permuted order
+            // in which stage() laid out V^T)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const af32x4 lo = {s[8 * kb], s[8 * kb + 1], s[8 * kb + 2], s[8 * kb + 3]};
+                const af32x4 hi = {s[8 * kb + 4], s[8 * kb + 5], s[8 * kb + 6], s[8 * kb + 7]};
+                au32x4 pp[3];
+                attn_split3(lo, hi, pp[0], pp[1], pp[2]);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const char* vrow = vp + (t * 32 + l31) * RSV + (2 * kb + half) * 16;
+                    au32x4 va[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) va[pl] = *reinterpret_cast<const au32x4*>(vrow + pl * VPL);
+                    attn_x6(o[t], va, pp);
+                }
+            }
+        }
+        __syncthreads();               // every wave is done with this tile's planes before the next stage() overwrites them
+    }
+    if (!active || !qok) return;
+    const float inv = 1.0f / l_run;
+    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo + h * D + 4 * half;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+            float4 v;
+            v.x = o[t][4 * e4 + 0] * inv;
+            v.y = o[t][4 * e4 + 1] * inv;
+            v.z = o[t][4 * e4 + 2] * inv;
+            v.w = o[t][4 * e4 + 3] * inv;
+            *reinterpret_cast<float4*>(orow + t * 32 + 8 * e4) = v;
+        }
+}
+
+template <int D, int NWQ>
+static hipError_t launch_attn_x6(const AttnP& p, hipStream_t s) {
+    static bool attr_done = false;
+    void (*fn)(AttnP) = attn_x6_kernel<D, NWQ>;
+    const size_t lds = (size_t)3 * 32 * (D * 2 + 16) + (size_t)3 * D * 80;
+    if (!attr_done && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((p.max_qlen + 32 * NWQ - 1) / (32 * NWQ), p.H, p.B), dim3(64 * NWQ), lds, s, p);
+    return hipGetLastError();
+}
+template <int D>
+static hipError_t launch_attn_x6_d(const AttnP& p, hipStream_t s) {
+    // the K / V split of a tile is paid once per workgroup: 8 query tiles per workgroup once there are enough of them
+    if (p.lds_waves == 8 || (p.lds_waves != 4 && p.max_qlen >= 600)) return launch_attn_x6<D, 8>(p, s);   // profiles/r03_attn_bench.txt
+    return launch_attn_x6<D, 4>(p, s);
+}
+
 hipError_t launch_attention(const AttnP& p, hipStream_t s) {
     if (p.B <= 0 || p.H <= 0 || p.max_qlen <= 0) return hipSuccess;
     if (p.D % 32 != 0 || (p.ldq & 3) || (p.ldk & 3) || (p.ldo & 3)) return hipErrorInvalidValue;
+    if ((p.D == 64 || p.D == 96) && p.x6_min_qlen > 0 && p.max_qlen >= p.x6_min_qlen && ((p.ldq | p.ldk) & 3) == 0)
+        return p.D == 64 ? launch_attn_x6_d<64>(p, s) : launch_attn_x6_d<96>(p, s);
     if (p.D <= 128 && p.max_qlen >= p.lds_min_qlen && p.lds_min_qlen > 0 && (p.ldv & 3) == 0) {
         switch (p.D) {        // long sequences: K / V tiles shared by 8 query tiles through LDS
             case 32: return launch_attn_lds_d<32>(p, s);

@@ -244,7 +244,7 @@ static void attention_self(const Ctx& c, const EncW& e, const AttnGeom& g, const
     a.u_qstride = g.u_stride; a.u_qlen = g.u_len; a.u_kvstride = g.u_stride; a.u_kvlen = g.u_len;
     a.B = g.B; a.H = e.heads; a.D = D; a.max_qlen = g.max_len; a.max_kvlen = g.max_len;
     a.scale = 1.0f / std::sqrt((float)D);
-    a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves;
+    a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves; a.x6_min_qlen = c.m.opts.attn_x6_min;
     MT2_HIP(launch_attention(a, c.s));
 }
 static void encoder_layer(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int M, const AttnGeom& g,
@@ -384,7 +384,7 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
     a.Q = q; a.ldq = d; a.K = kv; a.ldk = 2 * d; a.V = kv + d; a.ldv = 2 * d; a.O = att; a.ldo = d;
     a.u_qstride = 1; a.u_qlen = 1; a.u_kvstride = n; a.u_kvlen = n; a.B = A; a.H = e.heads; a.D = D; a.max_qlen = 1;
     a.scale = 1.0f / std::sqrt((float)D);
-    a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves;
+    a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves; a.x6_min_qlen = c.m.opts.attn_x6_min;
     MT2_HIP(launch_attention(a, c.s));
     // y = x[last rows] + out_proj(att): the residual rows sit n*d floats apart starting at row n-1
     linear(c, att, d, A, w.wo, w.bo, d, d, y, d, x + (size_t)(n - 1) * d, n * d);
@@ -415,7 +415,7 @@ static Pending encoder_layer_first_cached(const Ctx& c, const EncW& e, const Enc
     a.O = s.att; a.ldo = d;
     a.u_qstride = cs; a.u_qlen = n; a.u_kvstride = cs; a.u_kvlen = n; a.u_ostride = n;
     a.B = A; a.H = e.heads; a.D = D; a.max_qlen = n; a.scale = 1.0f / std::sqrt((float)D);
-    a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves;
+    a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves; a.x6_min_qlen = c.m.opts.attn_x6_min;
     MT2_HIP(launch_attention(a, c.s));
     return ar_layer_tail(c, e, w, x, M, s.att, s);
 }
@@ -672,7 +672,7 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
     a.Q = q; a.ldq = H; a.K = kv; a.ldk = 2 * H; a.V = kv + H; a.ldv = 2 * H; a.O = sc.att; a.ldo = H;
     a.q_start = P.d_start; a.q_len = P.d_len; a.kv_start = mp.X.d_start; a.kv_len = mp.X.d_len;
     a.B = B; a.H = 1; a.D = H; a.max_qlen = P.maxlen; a.max_kvlen = mp.X.maxlen; a.scale = 1.0f / std::sqrt((float)H);
-    a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves;
+    a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves; a.x6_min_qlen = c.m.opts.attn_x6_min;
     MT2_HIP(launch_attention(a, c.s));
     float* o = c.ws.get<float>((size_t)P.R * H);
     linear(c, sc.att, H, P.R, m.x_wo, m.x_bo, H, H, o, H);

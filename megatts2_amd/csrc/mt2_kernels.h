@@ -79,6 +79,8 @@ struct EngineOpts {
     int x6_mp = 0;               // 1: MP form (gemm_x6_ldr_kernel<..., MP>) of the 128x128 and small loader tiles, 2: of 256x128 too
     int skinny_rows = 64;        // linear layers with at most this many rows (<= 64) run on the weight-streaming kernel of
     int attn_lds_min = 640;      // attention: from this many queries per sequence on the LDS-tiled kernel (AttnP::lds_min_qlen; 0 never)
+    int attn_x6_min = 192;       // attention on the bf16 pipe (f32-equivalent, AttnP::x6_min_qlen) from this many queries on; 0: never
+                                 // (C5 step 5525 -> 5314 ms at 192, 5376 at 448: profiles/r03_opts_ab.txt)
     int attn_lds_waves = 0;      // ... its query tiles per workgroup (AttnP::lds_waves)
     int skinny_groups = 1;       // ... only for launches with at least this many GemmP groups (split-K slabs)
     int skinny_nt = 0;           // gemm_skinny.hip (0: off); skinny_nt: non-temporal weight loads (measured: C1 65.2 ms with, 56.8 without)
@@ -142,6 +144,7 @@ struct AttnP {
     int max_kvlen;   // ragged launches: longest key range (0 = unknown), sizes the split-KV width
     int lds_min_qlen = 640;   // from this many queries on (and D <= 128) the LDS-tiled kernel shares K / V tiles between 8 query
                               // tiles of a workgroup (attn_f32_lds_kernel); 0: never
+    int x6_min_qlen = 0;      // from this many queries on (D = 64 / 96) the f32-equivalent bf16-pipe kernel (attn_x6_kernel); 0: never
     int lds_waves = 0;        // query tiles per workgroup of that kernel: 8, otherwise 4
 };
 hipError_t launch_attention(const AttnP& p, hipStream_t s);

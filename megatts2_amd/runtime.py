@@ -609,14 +609,14 @@ def op_layernorm(x, gamma, beta, R1=None, valid=None, eps=1e-5, act=ACT_NONE):
     return out
 
 
-def op_attention(Q, K, V, q_start, q_len, kv_start, kv_len, H, D, scale, lds_min_qlen=-1, lds_waves=0, out=None):
+def op_attention(Q, K, V, q_start, q_len, kv_start, kv_len, H, D, scale, lds_min_qlen=-1, lds_waves=0, out=None, x6_min_qlen=-1):
     import torch
     lib = load_library()
     O = out if out is not None else torch.zeros(Q.shape[0], H * D, device=Q.device, dtype=torch.float32)
     B = q_start.shape[0]
     _check(lib.mt2_op_attention_tuned(_stream(), _ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(V), V.stride(0), _ptr(O),
                                       O.stride(0), _ptr(q_start), _ptr(q_len), _ptr(kv_start), _ptr(kv_len), B, H, D,
-                                      int(q_len.max().item()), C.c_float(scale), lds_min_qlen, lds_waves))
+                                      int(q_len.max().item()), C.c_float(scale), lds_min_qlen, lds_waves, x6_min_qlen))
     return O
 
 

@@ -8,7 +8,7 @@ from megatts2_amd import runtime as rt
 
 rt.device_check()
 dev = torch.device("cuda")
-print("%-28s %10s %10s %10s   (us per launch; TF/s of the fastest)" % ("shape", "reg", "lds4", "lds8"))
+print("%-28s %10s %10s %10s %10s %10s   (us per launch; TF/s of the fastest)" % ("shape", "reg", "lds4", "lds8", "x6/4", "x6/8"))
 for name, B, H, D, ns in (("adm 8x96, 4 seq", 4, 8, 96, (64, 128, 256, 417, 834)), ("plm 16x64, 4 seq", 4, 16, 64, (64, 128, 323, 646)),
                           ("adm 8x96, 16 seq", 16, 8, 96, (35, 70, 128)), ("plm 16x64, 16 seq", 16, 16, 64, (27, 54, 128))):
     for n in ns:
@@ -18,18 +18,18 @@ for name, B, H, D, ns in (("adm 8x96, 4 seq", 4, 8, 96, (64, 128, 256, 417, 834)
         ln = torch.full((B,), n, device=dev, dtype=torch.int32)
         out = torch.zeros(B * n, d, device=dev)
         row = []
-        for lds_min, waves in ((0, 0), (1, 4), (1, 8)):
+        for lds_min, waves, x6 in ((0, 0, 0), (1, 4, 0), (1, 8, 0), (0, 4, 1), (0, 8, 1)):
             f = lambda: rt.op_attention(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], st, ln, st, ln, H, D, 1.0 / math.sqrt(D),
-                                        lds_min_qlen=lds_min, lds_waves=waves, out=out)
+                                        lds_min_qlen=lds_min, lds_waves=waves, out=out, x6_min_qlen=x6)
             for _ in range(3):
                 f()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(20):
+            for _ in range(40):
                 f()
             e1.record()
             torch.cuda.synchronize()
-            row.append(e0.elapsed_time(e1) / 20 * 1e3)
+            row.append(e0.elapsed_time(e1) / 40 * 1e3)
         fl = 4.0 * n * n * d * B
-        print("%-18s n=%-6d %10.1f %10.1f %10.1f   %.1f" % (name, n, row[0], row[1], row[2], fl / min(row) / 1e6), flush=True)
+        print("%-18s n=%-6d %10.1f %10.1f %10.1f %10.1f %10.1f   %.1f" % (name, n, row[0], row[1], row[2], row[3], row[4], fl / min(row) / 1e6), flush=True)

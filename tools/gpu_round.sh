@@ -2,10 +2,16 @@
 # One GPU-box session (run through gpurun).  usage: bash tools/gpu_round.sh <mode> [<mode> ...]
 #   tests smoke                      parity suites (-m gpu) and __graft_entry__.smoke()
 #   bench2 pmcstage                  bench.py on C2; per-stage PMC passes (FETCH/WRITE/MFMA) of the default C3 step
-#   bench bench1 bench3 bench5       bench.py on C2 (default) / C1 / C3 / C5
+#   bench bench1 bench3 bench5       bench.py on the default workload (C3, with the C2 / C1 / C5 sub-results) / C1 / C3 / C5
+#   bench1x                          C1 without extras; BOPT="--opt name=value" passes handle options
+#   ab  tests_opts  opts             AB="name=value ..." interleaved in-process A/B (WL=C2|C3|C5, AB_STEPS=n); the stage parity
+#                                    suite under TEST_OPTS="a=1,b=2"; one run per OPTS entry
+#   ktests                           kernel tests selected by TEST_K (default: x6)
+#   ablate clock                     x6 loader-tile ablation builds; sustained-clock probe
 #   groups thresh splitk             A/B switches of bench.py (AR stream groups, tile thresholds, split-K through LN)
 #   prof prof3 profstage pmc probe   rocprofv3 kernel stats (C2 / C3 / one stage), PMC passes, per-launch PMC probe
 #   sweep sweep_ar sweep_voc sweep_vocx   GEMM engine sweeps (all / AR shapes / vocoder shapes / vocoder launch variants)
+#   sweep_x6 sweep_x6s sweep_x6k sweep_skinny   x6 tile forms / under-filled AR launches / K-split x6 tiles / M <= 64 kernel
 #   frontend s2                      rows f3 / f2 measurements
 # everything is written under gpurun_out/ (scratch); summaries worth keeping are copied to profiles/ by hand.
 mkdir -p gpurun_out

@@ -8,10 +8,13 @@ ABI (include/megatts2_hip.h) and is bound with ctypes.
 """
 from __future__ import annotations
 
+import glob
 import hashlib
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -52,25 +55,37 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(unit: str) -> str:
         obj = os.path.join(LIBDIR, unit.replace(".hip", ".o"))
-        audited = unit in AUDITED
-        cmd = [hipcc, *FLAGS, *(["-save-temps=obj"] if audited else []), "-c", os.path.join(CSRC, unit), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
-        if audited:     # the assembly of THIS build: no spill of an in-flight LDS read inside the GEMM loops (asm_audit.py)
-            from .asm_audit import report
-            stem = unit.replace(".hip", "")
-            n, text = report(os.path.join(LIBDIR, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s"))
+        if unit not in AUDITED:
+            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, unit), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            return obj
+        # audited unit: the device assembly of THIS build is checked for a spill of an in-flight LDS read inside the GEMM
+        # loops (asm_audit.py).  The -save-temps intermediates (the .s alone is ~55 MB) go to a scratch directory, never
+        # into the package; their names differ between hipcc releases, so the listing is found by pattern, and a build
+        # whose listing cannot be found still succeeds - the audit is then reported as skipped, not as passed.
+        from .asm_audit import report
+        stem = unit.replace(".hip", "")
+        with tempfile.TemporaryDirectory(prefix="mt2_build_") as tmp:
+            tobj = os.path.join(tmp, stem + ".o")
+            cmd = [hipcc, *FLAGS, "-save-temps=obj", "-c", os.path.join(CSRC, unit), "-o", tobj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            listings = sorted(glob.glob(os.path.join(tmp, stem + "-hip-*gfx950*.s")) or glob.glob(os.path.join(tmp, stem + "-hip-*.s")))
+            if listings:
+                n, text = report(listings[0])
+            else:
+                n, text = 0, "asm audit SKIPPED: no device listing matching " + stem + "-hip-*.s among the -save-temps files"
+                print("warning: " + text, file=sys.stderr, flush=True)
             with open(os.path.join(LIBDIR, stem + ".asm_audit.txt"), "w") as f:
                 f.write(text + "\n")
-            for fn in os.listdir(LIBDIR):       # the intermediates are large (the .s alone is ~55 MB): never shipped
-                if (fn.startswith(stem + "-hip-") or fn.startswith(stem + "-host-") or fn.startswith(stem + ".hip-")) and not fn.endswith(".o.keep"):
-                    os.remove(os.path.join(LIBDIR, fn))
             if n:
-                os.remove(obj)
                 raise RuntimeError("asm audit of " + unit + " failed:\n" + text)
-            if verbose:
-                print(text.splitlines()[-1], flush=True)
+            shutil.move(tobj, obj)
+        if verbose:
+            print(text.splitlines()[-1], flush=True)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(UNITS)) as ex:

@@ -11,7 +11,10 @@
 //   workgroup = one 32-column block of W and one K slice (blockIdx.z: the GemmP group = split-K slab), its NW waves
 //   split that K range; the partial 32x32 accumulators meet in LDS and are added in wave order (deterministic);
 //   each wave then finishes 16/NW accumulator elements: bias, activation, residual, row mask - the engine's epilogue.
-// Arithmetic: exact f32 products, f32 accumulation in a fixed order (k ascending inside a wave, waves ascending).
+// Arithmetic: exact f32 products, f32 accumulation in a fixed order (k ascending inside a wave, waves ascending) - a
+// DIFFERENT order than the tiled engine's, so a layer evaluated here (M <= 64) and there (M > 64) agrees to f32 round-off,
+// not bit for bit (batch-1 and batched results of the same utterance differ in the last bits; every discrete output of
+// the path is checked on both, tests/test_gpu_stages.py::test_prod_plm_batched_vs_alone_decisions).
 #include "mt2_kernels.h"
 
 namespace mt2 {
@@ -52,9 +55,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(GemmP p) {
         xok[i] = m < p.M && src >= 0 && src < p.Rx;
         xp[i] = p.X + (long long)g * p.strideX + (long long)(xok[i] ? src : 0) * p.ldx + koff;
     }
-    // prologue activation, branch-free: v >= 0 ? v : v * ns with ns = 1 (none: v * 1 is v), 0 (ReLU), slope (leaky ReLU)
+    // prologue activation, branch-free and identical to the tiled engine's apply_act on every input, non-finite ones
+    // included: max(v, relu ? 0 : v * ns) with ns = 1 (none: max(v, v) = v) or the leaky slope (0 < slope < 1)
     const float slope = p.pro_slope;
-    const float ns = p.pro_act == ACT_NONE ? 1.0f : (p.pro_act == ACT_RELU ? 0.0f : slope);
+    const bool relu = p.pro_act == ACT_RELU;
+    const float ns = p.pro_act == ACT_NONE ? 1.0f : slope;
 
     f32x16 acc[RT];
 #pragma unroll
@@ -91,8 +96,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(GemmP p) {
                     for (int j = 0; j < 4; ++j) {
                         f32x4 v = a[u][i][j];
                         if (!xok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                        v.x = v.x >= 0.0f ? v.x : v.x * ns; v.y = v.y >= 0.0f ? v.y : v.y * ns;
-                        v.z = v.z >= 0.0f ? v.z : v.z * ns; v.w = v.w >= 0.0f ? v.w : v.w * ns;
+                        v.x = fmaxf(v.x, relu ? 0.0f : v.x * ns); v.y = fmaxf(v.y, relu ? 0.0f : v.y * ns);
+                        v.z = fmaxf(v.z, relu ? 0.0f : v.z * ns); v.w = fmaxf(v.w, relu ? 0.0f : v.w * ns);
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, w[u][j].x, acc[i], 0, 0, 0);
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, w[u][j].y, acc[i], 0, 0, 0);
                         acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, w[u][j].z, acc[i], 0, 0, 0);

@@ -560,12 +560,25 @@ enum IdBit { ID_PHONE = 1, ID_CODE = 2, ID_PREFIX = 4 };
 static void ids_begin(const Ctx& c) {
     mt2_model& m = c.m;
     if (m.id_open) return;
-    if (!m.id_stream) {
-        MT2_HIP(hipStreamCreateWithFlags(&m.id_stream, hipStreamNonBlocking));
-        MT2_HIP(hipEventCreateWithFlags(&m.ev_id_fork, hipEventDisableTiming));
-        MT2_HIP(hipEventCreateWithFlags(&m.ev_id_done, hipEventDisableTiming));
-        MT2_HIP(hipMalloc((void**)&m.id_flag_dev, 4 * sizeof(int)));
-        MT2_HIP(hipHostMalloc((void**)&m.id_flag_host, 4 * sizeof(int), hipHostMallocDefault));
+    if (!m.id_stream) {     // all or nothing: a half-built set (stream without its events / flags) must never be used
+        hipStream_t st = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        int *fd = nullptr, *fh = nullptr;
+        const bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&e0, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
+                        hipMalloc((void**)&fd, 4 * sizeof(int)) == hipSuccess &&
+                        hipHostMalloc((void**)&fh, 4 * sizeof(int), hipHostMallocDefault) == hipSuccess;
+        if (!ok) {
+            if (fh) (void)hipHostFree(fh);
+            if (fd) (void)hipFree(fd);
+            if (e1) (void)hipEventDestroy(e1);
+            if (e0) (void)hipEventDestroy(e0);
+            if (st) (void)hipStreamDestroy(st);
+            (void)hipGetLastError();
+            throw Error("could not create the id-check stream, events or flags");
+        }
+        m.id_stream = st; m.ev_id_fork = e0; m.ev_id_done = e1; m.id_flag_dev = fd; m.id_flag_host = fh;
     }
     MT2_HIP(hipEventRecord(m.ev_id_fork, c.s));                  // the ids may be produced by earlier work on c.s
     MT2_HIP(hipStreamWaitEvent(m.id_stream, m.ev_id_fork, 0));
@@ -1050,9 +1063,14 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
     // "same" convolution; `scale` = output rows per mel frame at the current stage
     const bool reflect = cfg.hg_reflect_pad != 0;
     long long scale = 1;
+    int min_len = M0.B ? M0.len[0] : 0;
+    for (int b = 1; b < M0.B; ++b) min_len = std::min(min_len, M0.len[b]);
     auto halo = [&](const Ctx& cc, float* buf, int width, int G) {
         if (!reflect || G <= 0) return;
         MT2_REQUIRE(2ll * G <= (long long)M0.G * scale, "reflect padding needs a gap of two halos between utterances");
+        // torch F.pad(mode="reflect") / speechbrain raise when the padding is not smaller than the input: so do we
+        MT2_REQUIRE((long long)min_len * scale > G, "reflect padding must be smaller than the utterance (as F.pad raises): "
+                                                    "utterance too short for the vocoder's reflect-padded convolutions");
         MT2_HIP(launch_fill_reflect(buf, width, width, M0.d_start, M0.d_len, M0.B, scale, G, cc.s));
     };
     float* x = c.ws.get<float>((size_t)R * ch);

@@ -1,86 +1,111 @@
-"""Host glue between text-side phone symbols and phone ids: the k2-format symbol table reader and
-`TokensCollector.phone2token` of the reference (utils/symbol_table.py:77-125,280-287 and
-modules/datamodule.py:30-35,65-69), so that `Megatts(..., symbol_table)` needs nothing from the reference
-tree (its `modules.datamodule` drags in lhotse / lightning for this one dictionary lookup).
+"""Host glue between text-side phone symbols and phone ids.
 
-Reference behaviour kept exactly (it is part of a trained model's contract - the embedding row of a phone):
-  * the table file has one `<symbol> <integer id>` pair per line, fields separated by blanks / tabs; empty lines are
-    skipped, anything else than two fields, a duplicated symbol or a duplicated id is an error; id 0 is the null
-    symbol (`<eps>` unless the file names another one) and is ADDED when the file does not list it;
-  * `SymbolTable.symbols` is the list of symbols sorted as STRINGS - not by id - and `TokensCollector` numbers that
-    sorted list: a phone's token id is its rank among the sorted symbols (`<eps>` included), whatever ids the file gives.
-G2P (text -> phone symbols: pypinyin + MFA dictionary, modules/tokenizer.py:41-98) stays outside (SURVEY: out of scope).
+`Megatts(..., symbol_table)` takes a k2-format symbol table (reference: utils/symbol_table.py, k2's SymbolTable,
+Apache-2.0) and maps phone symbols to embedding rows the way `TokensCollector.phone2token` does
+(modules/datamodule.py:30-35,65-69).  This module is an independent reader of that FILE FORMAT plus the two
+behaviours a trained model depends on; nothing is imported from the reference tree (its `modules.datamodule`
+drags in lhotse / lightning for one dictionary lookup).
+
+The contract, as observed on the reference classes (tests/test_cpu_host.py checks it against the live ones):
+  * one `<symbol> <integer id>` pair per line, blank-separated, empty lines ignored; a line with another field
+    count, a repeated symbol or a repeated id is rejected;
+  * id 0 is the null symbol: whatever the file calls it, `<eps>` if the file does not list id 0 (it is then added);
+  * a phone's TOKEN id is the rank of its symbol among all symbols sorted as strings (null symbol included) -
+    not the id written in the file.
+G2P (text -> phone symbols: pypinyin + MFA dictionary, modules/tokenizer.py:41-98) stays outside (out of scope).
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, List
+from typing import Dict, Iterable, List, Sequence, Tuple, Union
+
+
+class SymbolTableError(ValueError, AssertionError):
+    """A malformed symbol table.  Also an AssertionError: the reference signals these cases with `assert`, and a
+    caller written against it catches that."""
+
+
+def _parse_pairs(text: str) -> List[Tuple[str, int]]:
+    rows = [(no, ln.split()) for no, ln in enumerate(text.splitlines(), 1)]
+    bad = [(no, f) for no, f in rows if f and len(f) != 2]
+    if bad:
+        no, f = bad[0]
+        raise SymbolTableError(f"symbol table line {no}: expected '<symbol> <id>', found {len(f)} fields")
+    try:
+        return [(f[0], int(f[1])) for _, f in rows if f]
+    except ValueError as e:
+        raise SymbolTableError(f"symbol table: id is not an integer ({e})") from None
+
+
+def _first_repeat(items: Sequence) -> object:
+    seen = set()
+    for it in items:
+        if it in seen:
+            return it
+        seen.add(it)
+    return None
 
 
 class SymbolTable:
-    """utils/symbol_table.py (k2's SymbolTable): id <-> symbol maps of a `.k2symbols` file."""
+    """Two-way map of a `.k2symbols` file.  `table[3]` -> symbol, `table["zh"]` -> id, `in` works for both."""
 
-    def __init__(self, id2sym: Dict[int, str], sym2id: Dict[str, int], eps: str = "<eps>"):
-        self._id2sym, self._sym2id, self.eps = dict(id2sym), dict(sym2id), eps
-        for idx, sym in self._id2sym.items():                       # __post_init__, :57-73
-            assert self._sym2id[sym] == idx and idx >= 0
-        for sym, idx in self._sym2id.items():
-            assert idx >= 0 and self._id2sym[idx] == sym
-        if 0 not in self._id2sym:
-            self._id2sym[0] = self.eps
-            self._sym2id[self.eps] = 0
-        else:
-            assert self._id2sym[0] == self.eps and self._sym2id[self.eps] == 0
+    DEFAULT_NULL = "<eps>"
 
-    @staticmethod
-    def from_str(s: str) -> "SymbolTable":                          # :77-106
-        id2sym: Dict[int, str] = {}
-        sym2id: Dict[str, int] = {}
-        for line in s.split("\n"):
-            fields = line.split()
-            if len(fields) == 0:
-                continue
-            assert len(fields) == 2, f"Expect a line with 2 fields. Given: {len(fields)}"
-            sym, idx = fields[0], int(fields[1])
-            assert sym not in sym2id, f"Duplicated symbol {sym}"
-            assert idx not in id2sym, f"Duplicated id {idx}"
-            id2sym[idx] = sym
-            sym2id[sym] = idx
-        return SymbolTable(id2sym, sym2id, id2sym.get(0, "<eps>"))
+    def __init__(self, pairs: Iterable[Tuple[str, int]], eps: str = DEFAULT_NULL):
+        pairs = list(pairs)
+        for what, col in (("symbol", [s for s, _ in pairs]), ("id", [i for _, i in pairs])):
+            rep = _first_repeat(col)
+            if rep is not None:
+                raise SymbolTableError(f"symbol table: repeated {what} {rep!r}")
+        if any(i < 0 for _, i in pairs):
+            raise SymbolTableError("symbol table: negative id")
+        self._by_sym: Dict[str, int] = {s: i for s, i in pairs}
+        self._by_id: Dict[int, str] = {i: s for s, i in pairs}
+        null_in_file = self._by_id.get(0)
+        if null_in_file is None:                # the null symbol joins the table (and therefore the ranking)
+            if eps in self._by_sym:
+                raise SymbolTableError(f"symbol table: {eps!r} is listed with a non-zero id")
+            self._by_sym[eps], self._by_id[0] = 0, eps
+            null_in_file = eps
+        self.eps = null_in_file
 
-    @staticmethod
-    def from_file(filename: str) -> "SymbolTable":                  # :108-125
+    @classmethod
+    def from_str(cls, text: str) -> "SymbolTable":
+        return cls(_parse_pairs(text))
+
+    @classmethod
+    def from_file(cls, filename: str) -> "SymbolTable":
         with open(filename, "r", encoding="utf-8") as f:
-            return SymbolTable.from_str(f.read().strip())
+            return cls.from_str(f.read())
 
     @property
-    def symbols(self) -> List[str]:                                 # :280-287: sorted as strings
-        return sorted(self._sym2id.keys())
+    def symbols(self) -> List[str]:
+        """All symbols in STRING order (not id order) - the order phone2token numbers them in."""
+        return sorted(self._by_sym)
 
     @property
     def ids(self) -> List[int]:
-        return sorted(self._id2sym.keys())
+        return sorted(self._by_id)
 
     def __len__(self) -> int:
-        return len(self._sym2id)
+        return len(self._by_sym)
 
-    def __getitem__(self, k):
-        return self._id2sym[k] if isinstance(k, int) else self._sym2id[k]
+    def __getitem__(self, key: Union[int, str]):
+        return self._by_id[key] if isinstance(key, int) else self._by_sym[key]
 
-    def __contains__(self, k) -> bool:
-        return k in self._id2sym if isinstance(k, int) else k in self._sym2id
+    def __contains__(self, key: Union[int, str]) -> bool:
+        return key in (self._by_id if isinstance(key, int) else self._by_sym)
 
 
 class TokensCollector:
-    """modules/datamodule.py:30-35,65-69: phone symbol -> token id = rank of the symbol in the sorted symbol list."""
+    """Phone symbol -> token id = rank of the symbol in the string-sorted symbol list (modules/datamodule.py:30-35,65-69)."""
 
     def __init__(self, symbols_table: str) -> None:
-        unique_tokens = SymbolTable.from_file(symbols_table).symbols
-        self.token2idx = {token: idx for idx, token in enumerate(unique_tokens)}
+        self.token2idx = {sym: rank for rank, sym in enumerate(SymbolTable.from_file(symbols_table).symbols)}
 
     def phone2token(self, phone: Iterable[str]):
         """list of phone symbols -> int64 tensor of token ids; an unknown symbol raises KeyError (as the reference)."""
         import torch
-        return torch.tensor([self.token2idx[token] for token in phone], dtype=torch.int64)
+        return torch.tensor([self.token2idx[p] for p in phone], dtype=torch.int64)
 
     @property
     def vocab_size(self) -> int:

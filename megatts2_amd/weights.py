@@ -15,6 +15,7 @@ the reference modules (golden generation), the CPU oracle and the HIP model.
 """
 from __future__ import annotations
 
+import os
 import zlib
 from collections import OrderedDict
 from typing import Dict, Tuple
@@ -234,7 +235,18 @@ def load_lightning_state_dict(ckpt_path: str, prefix: str) -> Dict[str, np.ndarr
         return OrderedDict((k[len(prefix):], v) for k, v in load_packed(ckpt_path).items() if k.startswith(prefix))
     import torch
 
-    raw = torch.load(ckpt_path, map_location="cpu", weights_only=False)["state_dict"]
+    # tensors and plain containers only: a Lightning checkpoint whose `hyper_parameters` / callback states pickle other
+    # classes is refused unless the caller opts in (the same switch as the speechbrain loader below) - never unpickle
+    # arbitrary objects from a path the caller, the CWD or an environment variable points at
+    unsafe = os.environ.get("MEGATTS2_UNSAFE_PICKLE", "") == "1"
+    try:
+        raw = torch.load(ckpt_path, map_location="cpu", weights_only=not unsafe)
+    except Exception as e:       # pickle.UnpicklingError from the weights_only unpickler
+        if unsafe or "weights_only" not in str(e).lower() and "unsupported" not in str(e).lower():
+            raise
+        raise RuntimeError(f"{ckpt_path}: the checkpoint pickles objects beyond tensors and plain containers ({str(e)[:160]}...); "
+                           "re-save its ['state_dict'] alone, or set MEGATTS2_UNSAFE_PICKLE=1 if you trust the file") from None
+    raw = raw["state_dict"]
     out = OrderedDict()
     for k, v in raw.items():
         if k.startswith(prefix):

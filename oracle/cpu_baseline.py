@@ -21,6 +21,45 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 
+def pool(a) -> None:
+    """W worker processes x T threads, disjoint core sets, disjoint utterances, started together: whole-socket throughput of
+    the batch-1 reference path = total frames / the slowest worker's time (each worker times its own utterances after its
+    model is built, so the figure leaves the start-up skew out - in the CPU's favour)."""
+    import subprocess
+    ncpu = os.cpu_count() or 1
+    W = max(1, min(a.workers, ncpu // max(a.threads, 1)))
+    per = max(1, a.max_utts)
+    procs = []
+    for w in range(W):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", a.workload, "--threads", str(a.threads), "--budget",
+               str(a.budget), "--max-utts", str(per), "--min-utts", str(min(a.min_utts, per)), "--utt-offset", str(w * per),
+               "--backend", a.backend]
+        cores = set(range(w * a.threads, (w + 1) * a.threads))
+
+        def pin(cores=cores):
+            try:
+                os.sched_setaffinity(0, cores)
+            except (AttributeError, OSError):
+                pass
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, preexec_fn=pin))
+    outs = []
+    for pr in procs:
+        out, _ = pr.communicate()
+        lines = [l for l in out.splitlines() if l.startswith("{")]
+        if pr.returncode == 0 and lines:
+            outs.append(json.loads(lines[-1]))
+    if not outs:
+        raise SystemExit("no pool worker finished")
+    frames = sum(o["frames"] for o in outs)
+    wall = max(o["cpu_s"] for o in outs)
+    print(json.dumps({"value": round(frames / wall, 2), "unit": "mel-frames/s", "cores": len(outs) * a.threads, "kind": "port",
+                      "workers": len(outs), "threads_per_worker": a.threads,
+                      "sample": f"process pool: {len(outs)} workers x {a.threads} threads on disjoint cores, "
+                                f"{sum(o['utterances'] for o in outs)} utterances of {a.workload} in total (each worker its own, one "
+                                f"after the other), {frames} frames / slowest worker {wall:.1f} s; per worker: "
+                                + ", ".join(f"{o['value']:.0f}" for o in outs) + " frames/s"}))
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="C2")
@@ -29,7 +68,13 @@ def main() -> None:
     ap.add_argument("--max-utts", type=int, default=8)
     ap.add_argument("--min-utts", type=int, default=3, help="at least this many utterances even beyond the budget")
     ap.add_argument("--backend", default="aten", choices=["aten", "numpy"])
+    ap.add_argument("--utt-offset", type=int, default=0, help="first utterance of the workload this process takes")
+    ap.add_argument("--workers", type=int, default=1,
+                    help="> 1: process pool - this many copies of this script side by side, each with --threads threads on its "
+                         "own cores and its own --max-utts utterances (BASELINE.md 3: 'multi-core ... or a process-pool variant')")
     a = ap.parse_args()
+    if a.workers > 1:
+        return pool(a)
     # one pool only: ATen's.  numpy's BLAS pool would busy-wait beside it (measured: 256 + 128 spinning threads
     # turned a 2 s run into 871 s on the 128-core GPU box)
     for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
@@ -48,7 +93,7 @@ def main() -> None:
     sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.") if full else None
     sd_h = weights.synth_state_dict(weights.inventory_hifigan(h), 0, "hifigan.") if full else None
     shape = synth.SHAPES[a.workload]
-    utts = synth.make_batch(shape, seed=1000 + int(a.workload[1]), batch=min(shape.B, a.max_utts))
+    utts = synth.make_batch(shape, seed=1000 + int(a.workload[1]), batch=min(shape.B, a.utt_offset + a.max_utts))[a.utt_offset:]
     if a.backend == "aten":
         O.enable_torch_kernels(a.threads)
     n_utt, frames, t0 = 0, 0, time.perf_counter()
@@ -73,6 +118,7 @@ def main() -> None:
     cpu_s = time.perf_counter() - t0
     per_stage = ", ".join(f"{k} {v:.2f} s" for k, v in sec.items() if v > 0)
     print(json.dumps({"value": round(frames / cpu_s, 2), "unit": "mel-frames/s", "cores": a.threads, "kind": "port",
+                      "frames": int(frames), "cpu_s": round(cpu_s, 3), "utterances": n_utt,
                       "stage_cpu_s": {k: round(v, 3) for k, v in sec.items() if v > 0},
                       "sample": f"{n_utt} of the {shape.B} utterances of {a.workload} (Np={shape.Np}, Tp={shape.Tp}, "
                                 f"Tm={shape.Tm}) one after the other, oracle port, every dense primitive and the whole "

@@ -655,16 +655,22 @@ def enable_torch_kernels(threads: Optional[int] = None) -> None:
             return Fn.linear(o, t(sd[f"{p}.out_proj.0.weight"]), t(sd[f"{p}.out_proj.0.bias"])).numpy()
 
     def hifigan_t(sd, cfg, mel):
-        if getattr(cfg, "pad_mode", "zeros") == "reflect":
-            return _hifigan_reflect(sd, cfg, mel)
         """The vocoder leg on ATen, channels-first from end to end (what a PyTorch HiFi-GAN module - speechbrain's, or
         transformers.SpeechT5HifiGan, the stand-in of BASELINE.md section 3 - dispatches to): F.conv1d,
-        F.conv_transpose1d, F.leaky_relu.  Same structure and arithmetic as `hifigan` above."""
+        F.conv_transpose1d, F.leaky_relu.  Same structure and arithmetic as `hifigan` above; cfg.pad_mode "reflect"
+        (speechbrain's Conv1d default) = F.pad(mode="reflect") in front of every 'same' convolution."""
         slope = cfg.leaky_relu_slope
         nk = len(cfg.resblock_kernel_sizes)
+        reflect = getattr(cfg, "pad_mode", "zeros") == "reflect"
+
+        def same(x, wt, bs, k, d=1):
+            pad = (k - 1) // 2 * d
+            if reflect and pad:
+                return Fn.conv1d(Fn.pad(x, (pad, pad), mode="reflect"), wt, bs, dilation=d)
+            return Fn.conv1d(x, wt, bs, padding=pad, dilation=d)
         with torch.no_grad():
             w = {k: t(v) for k, v in sd.items()}
-            x = Fn.conv1d(t(mel).T.unsqueeze(0), w["conv_pre.weight"], w["conv_pre.bias"], padding=3)
+            x = same(t(mel).T.unsqueeze(0), w["conv_pre.weight"], w["conv_pre.bias"], 7)
             for i, (r, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
                 x = Fn.leaky_relu(x, slope)
                 x = Fn.conv_transpose1d(x, w[f"upsampler.{i}.weight"], w[f"upsampler.{i}.bias"], stride=r,
@@ -674,14 +680,12 @@ def enable_torch_kernels(threads: Optional[int] = None) -> None:
                     q = f"resblocks.{i * nk + j}"
                     h = x
                     for n, d in enumerate(dils):
-                        y = Fn.conv1d(Fn.leaky_relu(h, slope), w[f"{q}.convs1.{n}.weight"], w[f"{q}.convs1.{n}.bias"],
-                                      padding=(rk * d - d) // 2, dilation=d)
-                        y = Fn.conv1d(Fn.leaky_relu(y, slope), w[f"{q}.convs2.{n}.weight"], w[f"{q}.convs2.{n}.bias"],
-                                      padding=(rk - 1) // 2)
+                        y = same(Fn.leaky_relu(h, slope), w[f"{q}.convs1.{n}.weight"], w[f"{q}.convs1.{n}.bias"], rk, d)
+                        y = same(Fn.leaky_relu(y, slope), w[f"{q}.convs2.{n}.weight"], w[f"{q}.convs2.{n}.bias"], rk)
                         h = y + h
                     acc = h if acc is None else acc + h
                 x = acc / nk
-            x = Fn.conv1d(Fn.leaky_relu(x, 0.01), w["conv_post.weight"], w["conv_post.bias"], padding=3)
+            x = same(Fn.leaky_relu(x, 0.01), w["conv_post.weight"], w["conv_post.bias"], 7)
             return torch.tanh(x[0, 0]).numpy()
 
     g.update(linear=linear_t, conv1d=conv1d_t, layer_norm=layer_norm_t, mha=mha_t, hifigan=hifigan_t)

@@ -295,6 +295,29 @@ pretrainer: !new:speechbrain.utils.parameter_transfer.Pretrainer
         weights.load_speechbrain_hifigan(str(tmp_path / "nowhere"))
 
 
+class _NotATensor:          # module-level: picklable, and exactly what a weights_only load must refuse
+    pass
+
+
+def test_lightning_checkpoints_are_read_weights_only(tmp_path, monkeypatch):
+    """`Megatts.__init__` reads three Lightning checkpoints (models/megatts2.py:111-116,192-197,287-291).  They are read with
+    torch.load(weights_only=True): a file that pickles anything beyond tensors and plain containers is refused with a
+    message naming the opt-in (MEGATTS2_UNSAFE_PICKLE=1) - INTEGRATION.md states this for every checkpoint path."""
+    import torch
+    from megatts2_amd import weights
+    good, bad = str(tmp_path / "good.ckpt"), str(tmp_path / "bad.ckpt")
+    sd = {"plm.a.weight": torch.arange(6, dtype=torch.float32).reshape(2, 3), "other.b": torch.zeros(1)}
+    torch.save({"state_dict": sd, "epoch": 3, "hyper_parameters": {"lr": 1e-4}}, good)
+    torch.save({"state_dict": sd, "callbacks": _NotATensor()}, bad)
+    monkeypatch.delenv("MEGATTS2_UNSAFE_PICKLE", raising=False)
+    out = weights.load_lightning_state_dict(good, "plm.")
+    assert list(out) == ["a.weight"] and out["a.weight"].dtype == np.float32 and out["a.weight"].shape == (2, 3)
+    with pytest.raises(RuntimeError, match="MEGATTS2_UNSAFE_PICKLE"):
+        weights.load_lightning_state_dict(bad, "plm.")
+    monkeypatch.setenv("MEGATTS2_UNSAFE_PICKLE", "1")
+    assert list(weights.load_lightning_state_dict(bad, "plm.")) == ["a.weight"]
+
+
 def test_symbol_table_and_phone2token_match_the_reference(tmp_path):
     """Host glue of Megatts.__init__ / forward (reference utils/symbol_table.py:77-125,280-287, modules/datamodule.py:30-35,
     65-69): the k2 symbol-table reader and TokensCollector.phone2token - token id = RANK of the symbol among the symbols
@@ -315,8 +338,9 @@ def test_symbol_table_and_phone2token_match_the_reference(tmp_path):
     with pytest.raises(KeyError):
         tc.phone2token(["sil", "not-a-phone"])
     for bad in ("a 1\nb\n", "a 1\na 2\n", "a 1\nb 1\n", "a 1 2\n"):          # field count, duplicated symbol / id
-        with pytest.raises(AssertionError):
+        with pytest.raises(AssertionError) as ei:          # the reference asserts; ours is a ValueError as well
             SymbolTable.from_str(bad)
+        assert isinstance(ei.value, ValueError)
     named0 = SymbolTable.from_str("<blk> 0\nx 5\n")                              # a file that names id 0 itself
     assert named0.eps == "<blk>" and named0.symbols == ["<blk>", "x"]
     if os.path.isdir("/root/reference/utils"):

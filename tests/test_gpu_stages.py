@@ -561,6 +561,42 @@ def test_prod_c3_batch_free_running_plm_and_vocoder():
         O.disable_torch_kernels()
 
 
+def test_prod_strong_scaling_shard_geometry_b96_ragged():
+    """BASELINE configs[3] as `bench.py --scaling strong` runs it on one rank: ONE synthesize_batch call over a large RAGGED
+    shard (C4 utterances with lengths U(0.7, 1): 96 here, up to 256 in the bench) - workspace query, row maps and the AR slot
+    ordering at B = 96, every length different.  Three utterances (the longest, the shortest, one in between) against the
+    oracle run alone: the ADM's own durations and the free-running PLM's codes bit-exact, mel within 1e-3; padding zero."""
+    from megatts2_amd import synth
+    tts = model("prod")
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("prod")
+    utts = synth.make_batch(synth.C4, seed=1004, jitter=0.3, batch=96)
+    phone, pl = pad_stack([u.phone for u in utts])
+    mel, ml = pad_stack([u.prompt_mel for u in utts])
+    dur, _ = pad_stack([u.durations for u in utts])
+    frames = np.asarray([int(u.durations.sum()) for u in utts])
+    assert len(set(pl.tolist())) > 10 and len(set(frames.tolist())) > 30           # really ragged
+    nat = tts.native
+    nat.workspace_reserve(nat.workspace_query(96, int(pl.max()), int(ml.max()), synth.C4.Tm, run_plm=True, vocoder=False))
+    out, lens, aux = nat.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, tm_cap=synth.C4.Tm, return_aux=True)
+    assert lens.tolist() == frames.tolist()
+    order = np.argsort(frames)
+    picks = [int(order[-1]), int(order[0]), int(order[len(order) // 2])]
+    out = out.cpu().numpy()
+    O.enable_torch_kernels()
+    try:
+        for i in picks:
+            u = utts[i]
+            ref = O.synthesize(sd_g, sd_p, sd_a, g, p, a, u.phone, u.prompt_mel, forced_durations=u.durations)
+            nq = ref["p_codes"].size
+            assert np.array_equal(aux["dur"][i, :pl[i]].cpu().numpy(), ref["adm_dur"]), f"durations of utterance {i}"
+            assert not aux["dur"][i, pl[i]:].any()
+            assert np.array_equal(aux["codes"][i, :nq].cpu().numpy(), ref["p_codes"]), f"prosody codes of utterance {i}"
+            assert O.rel_l2(out[i, :frames[i]], ref["mel"]) < NORTH_STAR
+            assert not out[i, frames[i]:].any()
+    finally:
+        O.disable_torch_kernels()
+
+
 def test_prod_c2_durations_of_the_batched_adm():
     """C2 at full size: the ADM's own integer durations (not the forced ones) of a ragged batch equal the oracle's."""
     from megatts2_amd import synth
@@ -662,8 +698,26 @@ def test_prod_c5_utterance_free_running():
     phone, pl = pad_stack([v.phone for v in utts])
     mel, ml = pad_stack([v.prompt_mel for v in utts])
     dur, _ = pad_stack([v.durations for v in utts])
-    out, lens, aux = tts.native.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, return_aux=True)
+    # ... with the vocoder, as bench.py times C5 (the only timed leg without a comparison).  The last stage
+    # holds 8 x 5168 x 256 = 10.6 M rows of 32 channels = 1.35 GB: byte offsets beyond 2^31 - the LAST utterance's tail
+    # lives there, so slot 7 is compared too, and the last 64 frames of both explicitly.
+    out, lens, aux = tts.native.synthesize_batch(dev(phone), pl, dev(mel), ml, forced_dur=dur, vocoder=True, return_aux=True)
     check(out, lens, aux, 0, "slot 0 of the B = 8 batch")
+    (g, p, a, h), (sd_g, sd_p, sd_a, sd_h) = synth_models("prod")
+    hop = int(np.prod(h.upsample_rates))
+    O.enable_torch_kernels()
+    try:
+        for slot, mel_ref, tol in ((0, z["mel"], NORTH_STAR), (7, out[7, :int(lens[7])].cpu().numpy(), 1e-4)):
+            T = int(lens[slot])
+            want = O.hifigan(sd_h, h, mel_ref)              # slot 0: from the LIVE reference's mel (end to end); slot 7: the
+            got = aux["wav"][slot, :T * hop].cpu().numpy()  # vocoder alone, on the mel the device produced
+            assert want.size == T * hop
+            assert O.rel_l2(got, want) < tol, (slot, O.rel_l2(got, want))
+            tail = slice((T - 64) * hop, T * hop)
+            assert O.rel_l2(got[tail], want[tail]) < max(tol, 2e-4) * 3, (slot, "last 64 frames", O.rel_l2(got[tail], want[tail]))
+            assert not aux["wav"][slot, T * hop:].any()
+    finally:
+        O.disable_torch_kernels()
 
 
 def test_prod_plm_prompt_conditioned():

@@ -274,3 +274,11 @@ def test_hifigan_reflect_edge_mode_against_torch(tiny):
         ref = torch.tanh(cs(Fn.leaky_relu(x, 0.01), sd_h["conv_post.weight"], sd_h["conv_post.bias"])[0, 0]).numpy()
     assert O.rel_l2(O.hifigan(sd_h, hr, mel), ref) < TOL
     assert O.rel_l2(O.hifigan(sd_h, h, mel), ref) > 1e-2
+    # the ATen backend of bench.py's cpu_baseline runs the SAME vocoder in both edge modes
+    want = {m: O.hifigan(sd_h, c, mel) for m, c in (("zeros", h), ("reflect", hr))}
+    O.enable_torch_kernels(2)
+    try:
+        for m, c in (("zeros", h), ("reflect", hr)):
+            assert O.rel_l2(O.hifigan(sd_h, c, mel), want[m]) < TOL, m
+    finally:
+        O.disable_torch_kernels()

@@ -547,7 +547,19 @@ def main() -> None:
         # kind "port", not "reference": /root/reference does not exist on the GPU box (the port is pinned to it by
         # the golden fixtures).
         import subprocess
-        ncpu = os.cpu_count() or 1
+
+        def usable_cores():
+            """Cores this process may actually use: the affinity mask, cut by the cgroup CPU quota (the GPU boxes of this pool show
+            256 logical cores and grant 16: `cpu.max` = 1600000 100000, profiles/r04_gpu_box_cpu_limits.txt)."""
+            n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            try:
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if quota != "max":
+                    n = min(n, max(1, int(int(quota) / int(period))))
+            except (OSError, ValueError):
+                pass
+            return n
+        ncpu = usable_cores()
         threads = min(ncpu, 16)
         script = [sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", args.workload]
 
@@ -574,8 +586,10 @@ def main() -> None:
             best = max(done, key=lambda k_: done[k_]["value"])
             base = dict(done[best])
             base["variant"] = best
-            base["note"] = ("value = the HIGHEST of the variants (the most the host's cores give the batch-1 reference path); "
-                            "host has %d logical cores" % ncpu)
+            base["note"] = ("value = the HIGHEST of the variants (the most the host's cores give the batch-1 reference path); this "
+                            "process may use %d cores (affinity mask cut by the cgroup CPU quota; os.cpu_count() = %d)%s"
+                            % (ncpu, os.cpu_count() or 1, "" if ncpu > 16 else
+                               ": the all-cores and process-pool variants of BASELINE.md 3 coincide with the 16-thread run here"))
             base["variants"] = {k_: ({"value": v_["value"], "cores": v_["cores"], "sample": v_["sample"][:260]} if v_ else None)
                                 for k_, v_ in variants.items()}
             result["cpu_baseline"] = base

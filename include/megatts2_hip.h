@@ -236,6 +236,18 @@ int mt2_op_gemm(void* stream, const float* X, int ldx, int Rx, const int32_t* ro
 int mt2_op_gemm_x6(void* stream, const float* X, int ldx, int Rx, int shift0, int taps, int dil, int Cin, const float* W,
                    const void* W3, const float* bias, const float* R, int ldr, const int32_t* valid, float* C, int ldc,
                    int M, int N, int pro_act, float pro_slope, int epi_act, int force_cfg);
+/* Linear layers of at most 64 rows on a TILE-MAJOR copy of the weights (round 4; gemm_skinny_tm_kernel - what the AR steps of one
+ * utterance and the last-row launches of every batched AR step run on: F.linear at models/megatts2.py:172-179,264-273 with a
+ * handful of rows).  mt2_op_tile_major turns a row-major [N, K] matrix (N a multiple of 16, K of 64) into blocks of 16 columns x 64 k,
+ * block (nb, kb) at (nb * K/64 + kb) * 1024 floats, inside a block [j][lane][i] = W[nb*16 + lane%16][kb*64 + j*16 + (lane/16)*4 + i].
+ * mt2_op_gemm_tm: C[g][M,N] = epi(pro(X[g] rows m*a_mul + shift0) @ Wsub[g]^T + bias) with Wsub[g] = rows [n0, n0 + N), columns
+ * [k0, k0 + K) of the whole [*, Kw] matrix, moved by g * w_gstride row-major elements per group (split-K slabs: w_gstride = K).
+ * ln_gamma != NULL: LayerNorm(X rows; gamma, beta, eps) as the prologue (K <= 1024, groups = 1) instead of pro_act. */
+int mt2_op_tile_major(void* stream, const float* W, int N, int K, float* out);
+int mt2_op_gemm_tm(void* stream, const float* X, long long x_gstride, int ldx, int Rx, int a_mul, int shift0, const float* Wtm,
+                   int Kw, int n0, int k0, long long w_gstride, int groups, const float* bias, const float* R, int ldr,
+                   const int32_t* valid, float* C, long long c_gstride, int ldc, int M, int N, int K, int pro_act, float pro_slope,
+                   int epi_act, const float* ln_gamma, const float* ln_beta, float ln_eps);
 /* C[M,N] = act(LayerNorm(X rows m*a_mul + shift0; gamma, beta, eps) @ W^T + bias) in one launch (AR steps: LN1 -> QKV,
  * LN2 -> ff.0).  K <= 1024.  algebraic = 0: fragments normalised on the fly (force_cfg -1 or a 2-deep-ring config);
  * algebraic = 1 (what the model runs): W must be the gamma-scaled weights W'[n,k] = gamma[k] W[n,k], `bias` the vector

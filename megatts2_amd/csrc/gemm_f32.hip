@@ -2539,8 +2539,10 @@ static const TileCfg kCfgs[] = {
     // names only: the weight-streaming kernel for M <= 64 rows lives in gemm_skinny.hip (launch_gemm routes to it)
     { 32, 32, 512, 0, "skinny32_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },    // 87
     { 64, 32, 512, 0, "skinny64_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },    // 88
+    { 32, 32, 512, 0, "skinnytm32_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },  // 89: the same on tile-major weights
+    { 64, 32, 512, 0, "skinnytm64_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },  // 90   (+ LayerNorm prologue)
 };
-constexpr int kSkinny32 = 87, kSkinny64 = 88;
+constexpr int kSkinny32 = 87, kSkinny64 = 88, kSkinnyTm32 = 89, kSkinnyTm64 = 90;
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 int gemm_trace_shapes(EngineOpts& o, char* buf, int cap, int top) {
@@ -2718,6 +2720,26 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     if (p.pro_act < 0 || p.pro_act > PRO_LNA) return hipErrorInvalidValue;
     // a handful of rows: the weight-streaming kernel (gemm_skinny.hip) instead of a tile configuration
     const bool sk_forced = o.force_cfg == kSkinny32 || o.force_cfg == kSkinny64;
+    const bool tm_forced = o.force_cfg == kSkinnyTm32 || o.force_cfg == kSkinnyTm64;
+    if (tm_forced || (o.skinny_tm && o.skinny_rows > 0 && o.force_cfg < 0 && p.groups >= o.skinny_groups &&
+                      gemm_skinny_tm_eligible(p, o.skinny_rows))) {
+        if (!gemm_skinny_tm_eligible(p, 64)) return hipErrorInvalidValue;
+        const int sidx = p.M <= 32 ? kSkinnyTm32 : kSkinnyTm64;
+        if (opts) opts->last_cfg = kCfgs[sidx].name;
+        if (opts && opts->trace_on) {
+            TraceRec r;
+            r.cfg = sidx;
+            r.flops = 2.0 * p.M * p.N * p.K * p.groups;
+            r.M = p.M; r.N = p.N; r.K = p.K; r.groups = p.groups;
+            if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return hipErrorUnknown;
+            (void)hipEventRecord(r.e0, s);
+            const hipError_t e = launch_gemm_skinny_tm(p, s);
+            (void)hipEventRecord(r.e1, s);
+            opts->trace.push_back(r);
+            return e;
+        }
+        return launch_gemm_skinny_tm(p, s);
+    }
     if (sk_forced || (o.skinny_rows > 0 && o.force_cfg < 0 && p.groups >= o.skinny_groups && gemm_skinny_eligible(p, o.skinny_rows))) {
         if (!gemm_skinny_eligible(p, 64)) return hipErrorInvalidValue;
         p.w_nt = o.skinny_nt ? 1 : 0;

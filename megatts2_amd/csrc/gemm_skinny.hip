@@ -164,6 +164,212 @@ hipError_t sk_launch(const GemmP& p, hipStream_t s) {
     return hipGetLastError();
 }
 
+
+// ---- round 4: tile-major weights, 16-column blocks, optional LayerNorm prologue ---------------------------------------------
+//
+// What the row-major kernel above leaves on the table at a handful of rows (profiles/r04_c1_kernel_stats_*.csv): (1) a
+// wave-wide 16-byte load touches 64 separate pieces of 32 weight rows; (2) the f32 MFMA pipe runs at the VECTOR rate, so a
+// 32 x 32 x K block costs K/2 x 64 cycles whatever M is - 3.9 us for K = 1024 on the two waves per SIMD of a workgroup, with
+// only N/32 = 24...96 of the 256 CUs at work.  This form halves the block to 16 columns and uses v_mfma_f32_16x16x4_f32 on
+// 16-row tiles: twice the workgroups, a quarter of the matrix-pipe time per workgroup at M <= 16 (the last-row launches of the
+// batched AR steps, the first 16 steps of a lone utterance), 3/8 at M = 42.
+//
+// Weight layout (model_load.hip `TmRange`; kernel tests: launch_tile_major): 16-column x 64-k blocks of 1024 floats, block
+// (nb, kb) at (nb * K/64 + kb) * 1024, inside a block
+//     [j = 0..3][lane = 0..63][i = 0..3]  =  W[nb*16 + (lane & 15)][kb*64 + j*16 + (lane >> 4)*4 + i]
+// so load instruction j of a wave reads 1 KiB of CONTIGUOUS memory and leaves lane (column, k-quarter) with the B values of
+// four consecutive MFMAs; the activation side follows the same k order (lane (row, k-quarter) loads x[row][kb*64 + j*16 +
+// quarter*4 .. +4]).  Exact f32 products, f32 accumulation in a fixed order (k-quarters inside an MFMA, MFMAs ascending,
+// waves ascending in the LDS reduction).
+//
+// PRO_LN (GemmP::pro_act == 3): C = LN(X; ln_g, ln_b, ln_eps) W^T ... without a LayerNorm launch in front.  The workgroup
+// first issues its first weight / activation loads (they do not depend on the statistics), then computes mean / rstd of ALL
+// M <= 64 rows (wave w: rows w, w + NW, ..., four at a time; two passes in registers like layernorm_kernel; the rows come from
+// L2 - the other column blocks read the same ones), and normalises the A values on the fly: a' = (a - mean) * rstd * gamma_k
+// + beta_k.
+template <int RT, int NW, int U, bool LNP>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_tm_kernel(GemmP p) {
+    extern __shared__ float sk_red[];                       // [NW][RT][4][64] | stat [RT * 16][2]
+    float* stat = sk_red + NW * RT * 4 * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = blockIdx.z, nb = blockIdx.x, n0 = nb * 16;
+    const int col = lane & 15, kq = lane >> 4;
+    // 64-wide K chunks of this wave: [c0, c0 + nc)
+    const int kch = p.K >> 6, base = kch / NW, rem = kch % NW;
+    const int nc = base + (wave < rem ? 1 : 0), c0 = wave * base + min(wave, rem);
+    // block coordinates of this group's sub-matrix inside the whole tile-major matrix (16-row / 64-column units)
+    const long long eo = (long long)g * p.strideW + (long long)p.tm_k0 * 64;
+    const long long nbg = p.tm_n0 + ((eo / p.ldw) >> 4) + nb;
+    const int kbg = (int)((eo % p.ldw) >> 6);
+    const float* __restrict__ wp = p.Wtm + (nbg * p.tm_kb + kbg + c0) * 1024 + lane * 4;
+    const float* __restrict__ xp[RT];
+    bool xok[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const int m = i * 16 + col;
+        const int src = m * p.a_mul + p.shift0;
+        xok[i] = m < p.M && src >= 0 && src < p.Rx;
+        xp[i] = p.X + (long long)g * p.strideX + (long long)(xok[i] ? src : 0) * p.ldx + c0 * 64 + kq * 4;
+    }
+    const float slope = p.pro_slope;
+    const bool relu = p.pro_act == ACT_RELU;
+    const float ns = (LNP || p.pro_act == ACT_NONE) ? 1.0f : slope;
+
+    f32x4 acc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 w[U][4], a[U][RT][4];
+    auto load_batch = [&](int sb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (sb + u < nc) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[u][j] = *reinterpret_cast<const f32x4*>(wp + (long long)(sb + u) * 1024 + j * 256);
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[u][i][j] = *reinterpret_cast<const f32x4*>(xp[i] + (sb + u) * 64 + j * 16);
+            }
+    };
+    load_batch(0);
+
+    float mu[RT], rs[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) { mu[i] = 0.0f; rs[i] = 1.0f; }
+    if (LNP) {
+        const int Kf = p.K;
+        const float inv_k = 1.0f / (float)Kf;
+        const float* __restrict__ Xg = p.X + (long long)g * p.strideX;
+        constexpr int RF = 4;       // rows of this wave in flight: ONE memory round trip for up to 32 rows per workgroup
+        for (int r0 = wave; r0 < p.M; r0 += RF * NW) {
+            f32x4 xv[RF][4];
+#pragma unroll
+            for (int q = 0; q < RF; ++q) {
+                const int r = r0 + q * NW;
+                const int src = r * p.a_mul + p.shift0;
+                const bool ok = r < p.M && src >= 0 && src < p.Rx;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = (v * 64 + lane) * 4;
+                    xv[q][v] = (ok && c < Kf) ? *reinterpret_cast<const f32x4*>(Xg + (long long)src * p.ldx + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            float sum[RF], q2[RF];
+#pragma unroll
+            for (int q = 0; q < RF; ++q) {
+                sum[q] = 0.0f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) sum[q] += (xv[q][v].x + xv[q][v].y) + (xv[q][v].z + xv[q][v].w);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int q = 0; q < RF; ++q) sum[q] += __shfl_xor(sum[q], o);
+#pragma unroll
+            for (int q = 0; q < RF; ++q) {
+                const float mean = sum[q] * inv_k;
+                sum[q] = mean;
+                q2[q] = 0.0f;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int c = (v * 64 + lane) * 4;
+                    if (c < Kf) {
+                        const float d0 = xv[q][v].x - mean, d1 = xv[q][v].y - mean, d2 = xv[q][v].z - mean, d3 = xv[q][v].w - mean;
+                        q2[q] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int q = 0; q < RF; ++q) q2[q] += __shfl_xor(q2[q], o);
+#pragma unroll
+            for (int q = 0; q < RF; ++q) {
+                const int r = r0 + q * NW;
+                if (lane == 0 && r < p.M) {
+                    stat[2 * r] = sum[q];
+                    stat[2 * r + 1] = rsqrtf(q2[q] * inv_k + p.ln_eps);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int m = i * 16 + col;
+            if (m < p.M) { mu[i] = stat[2 * m]; rs[i] = stat[2 * m + 1]; }
+        }
+    }
+
+    for (int sb = 0; sb < nc; sb += U) {
+        if (sb) load_batch(sb);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (sb + u < nc) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 gam, bet;
+                    if (LNP) {
+                        const int k = (c0 + sb + u) * 64 + j * 16 + kq * 4;
+                        gam = *reinterpret_cast<const f32x4*>(p.ln_g + k);
+                        bet = *reinterpret_cast<const f32x4*>(p.ln_b + k);
+                    }
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) {
+                        f32x4 v = a[u][i][j];
+                        if (LNP) {
+                            v.x = (v.x - mu[i]) * rs[i] * gam.x + bet.x; v.y = (v.y - mu[i]) * rs[i] * gam.y + bet.y;
+                            v.z = (v.z - mu[i]) * rs[i] * gam.z + bet.z; v.w = (v.w - mu[i]) * rs[i] * gam.w + bet.w;
+                        } else {
+                            v.x = fmaxf(v.x, relu ? 0.0f : v.x * ns); v.y = fmaxf(v.y, relu ? 0.0f : v.y * ns);
+                            v.z = fmaxf(v.z, relu ? 0.0f : v.z * ns); v.w = fmaxf(v.w, relu ? 0.0f : v.w * ns);
+                        }
+                        if (!xok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, w[u][j].x, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, w[u][j].y, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, w[u][j].z, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, w[u][j].w, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // K shares meet in LDS; thread t finishes accumulator element (tile i, e, lane) = t of the RT * 256 outputs
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sk_red[((wave * RT + i) * 4 + e) * 64 + lane] = acc[i][e];
+    __syncthreads();
+    const float* __restrict__ bias = p.bias ? p.bias + (long long)g * p.strideB : nullptr;
+    const float* __restrict__ R = p.R ? p.R + (long long)g * p.strideR : nullptr;
+    float* __restrict__ C = p.C + (long long)g * p.strideC;
+    const int epi = p.epi_act;
+    const float osc = p.out_scale;
+    for (int t = threadIdx.x; t < RT * 256; t += NW * 64) {
+        const int i = t >> 8, e = (t >> 6) & 3, ln = t & 63;
+        float sacc = sk_red[((0 * RT + i) * 4 + e) * 64 + ln];
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) sacc += sk_red[((w2 * RT + i) * 4 + e) * 64 + ln];
+        const int m = i * 16 + (ln >> 4) * 4 + e, n = n0 + (ln & 15);
+        if (m < p.M && n < p.N) {
+            float v = sk_act(epi, sacc + (bias ? bias[n] : 0.0f), slope) * osc;
+            if (R) v += R[(long long)m * p.ldr + n];
+            if (p.valid && p.valid[m] == 0) v = 0.0f;
+            C[(long long)m * p.ldc + n] = v;
+        }
+    }
+}
+
+template <int RT, int U, bool LNP>
+hipError_t sk_tm_launch(const GemmP& p, hipStream_t s) {
+    constexpr int NW = 8;
+    void (*fn)(GemmP) = gemm_skinny_tm_kernel<RT, NW, U, LNP>;
+    const size_t lds = ((size_t)NW * RT * 4 * 64 + (size_t)RT * 16 * 2) * sizeof(float);      // <= 33 KiB
+    hipLaunchKernelGGL(fn, dim3(p.N / 16, 1, p.groups), dim3(NW * 64), lds, s, p);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 bool gemm_skinny_eligible(const GemmP& p, int max_rows) {
@@ -171,6 +377,57 @@ bool gemm_skinny_eligible(const GemmP& p, int max_rows) {
            (p.ldx & 3) == 0 && (p.ldw & 3) == 0 && (p.strideX & 3) == 0 && (p.strideW & 3) == 0 &&
            p.pro_act >= ACT_NONE && p.pro_act <= ACT_LRELU && p.a_mul >= 1 &&
            (reinterpret_cast<uintptr_t>(p.X) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.W) & 15) == 0;
+}
+
+// tile-major form: whole 16-column x 64-k blocks only; the LayerNorm prologue exists in this form only
+bool gemm_skinny_tm_eligible(const GemmP& p, int max_rows) {
+    if (!p.Wtm || p.tm_kb <= 0) return false;
+    const bool pro_ok = (p.pro_act >= ACT_NONE && p.pro_act <= ACT_LRELU) ||
+                        (p.pro_act == 3 && p.ln_g && p.ln_b && p.K <= 1024 && p.groups == 1);
+    return p.taps == 1 && !p.rowbase && p.M >= 1 && p.M <= max_rows && p.M <= 64 && p.K >= 64 && (p.K & 63) == 0 &&
+           (p.N & 15) == 0 && (p.ldx & 3) == 0 && (p.ldw & 63) == 0 && (p.strideX & 3) == 0 && (p.strideW & 63) == 0 &&
+           (p.groups == 1 || ((p.strideW % p.ldw) == 0 && ((p.strideW / p.ldw) & 15) == 0) ||
+            (long long)(p.groups - 1) * p.strideW + (long long)p.tm_k0 * 64 + p.K <= p.ldw) &&
+           pro_ok && p.a_mul >= 1 && (reinterpret_cast<uintptr_t>(p.X) & 15) == 0;
+}
+
+hipError_t launch_gemm_skinny_tm(const GemmP& p, hipStream_t s) {
+    if (!gemm_skinny_tm_eligible(p, 64)) return hipErrorInvalidValue;
+    const bool ln = p.pro_act == 3;
+    const int per_wave = ((p.K >> 6) + 7) / 8;          // K chunks of the busiest wave
+    switch ((p.M + 15) / 16) {
+        case 1:
+            if (ln) return sk_tm_launch<1, 2, true>(p, s);
+            return per_wave > 2 ? sk_tm_launch<1, 4, false>(p, s) : sk_tm_launch<1, 2, false>(p, s);
+        case 2:
+            if (ln) return sk_tm_launch<2, 2, true>(p, s);
+            return per_wave > 2 ? sk_tm_launch<2, 4, false>(p, s) : sk_tm_launch<2, 2, false>(p, s);
+        case 3:
+            if (ln) return sk_tm_launch<3, 2, true>(p, s);
+            return sk_tm_launch<3, 2, false>(p, s);       // U = 4 would spill (3 row tiles x 4 chunks of A in flight)
+        default:
+            if (ln) return sk_tm_launch<4, 2, true>(p, s);
+            return sk_tm_launch<4, 2, false>(p, s);
+    }
+}
+
+// row-major [N, K] (N a multiple of 16, K of 64) -> tile-major blocks (kernel tests and micro-benchmarks; the model loader
+// repacks on the host)
+__global__ void tile_major_kernel(const float* __restrict__ W, int K, float* __restrict__ out, long long n4) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 of the output
+    if (t >= n4) return;
+    const long long blk = t >> 8;
+    const int r = (int)(t & 255), j = r >> 6, lane = r & 63, c = lane & 15, kq = lane >> 4;
+    const int KB = K >> 6;
+    const long long nb = blk / KB;
+    const int kb = (int)(blk % KB);
+    *reinterpret_cast<f32x4*>(out + t * 4) = *reinterpret_cast<const f32x4*>(W + (nb * 16 + c) * K + kb * 64 + j * 16 + kq * 4);
+}
+hipError_t launch_tile_major(const float* W, int N, int K, float* out, hipStream_t s) {
+    if ((N & 15) || (K & 63) || N <= 0 || K <= 0) return hipErrorInvalidValue;
+    const long long n4 = (long long)N * K / 4;
+    hipLaunchKernelGGL(tile_major_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, W, K, out, n4);
+    return hipGetLastError();
 }
 
 const char* gemm_skinny_name(const GemmP& p) { return p.M <= 32 ? "skinny32_f32" : "skinny64_f32"; }

@@ -164,6 +164,24 @@ struct Loader {
         m.weight_bytes += pl.size() * sizeof(uint16_t);
         return static_cast<const uint16_t*>(d);
     }
+    // the tile-major copy of a linear layer's [N, K] matrix already uploaded at `base` (layout: gemm_skinny.hip)
+    void upload_tm(const float* base, const std::vector<float>& v, int N, int K) {
+        if ((N & 15) || (K & 63) || v.size() != (size_t)N * K) return;
+        std::vector<float> t(v.size());
+        const int KB = K / 64;
+        for (int nb = 0; nb < N / 16; ++nb)
+            for (int kb = 0; kb < KB; ++kb) {
+                float* blk = t.data() + ((size_t)nb * KB + kb) * 1024;
+                for (int j = 0; j < 4; ++j)
+                    for (int kq = 0; kq < 4; ++kq)
+                        for (int c = 0; c < 16; ++c) {
+                            const float* src = v.data() + (size_t)(nb * 16 + c) * K + kb * 64 + j * 16 + kq * 4;
+                            float* dst = blk + j * 256 + (kq * 16 + c) * 4;
+                            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+                        }
+            }
+        m.tm.push_back({base, v.size(), K, upload(t)});
+    }
     float* vec(const std::string& name, int64_t n) { return upload(get(name, {n}).data); }
     float* mat(const std::string& name, int64_t r, int64_t c) { return upload(get(name, {r, c}).data); }
 
@@ -236,6 +254,12 @@ struct Loader {
             } else {
                 w.ff0w = wmat(p + ".ff.0.weight", ff, d); w.ff0b = vec(p + ".ff.0.bias", ff);
                 w.ff1w = wmat(p + ".ff.3.weight", d, ff); w.ff1b = vec(p + ".ff.3.bias", d);
+                // the AR encoders' matrices as tile-major blocks too: their launches of at most 64 rows (one utterance's
+                // steps, the last-row launches of every batched step) stream them in 1-KiB pieces
+                upload_tm(w.wqkv, qkv, 3 * d, d);
+                upload_tm(w.wo, get(p + ".attn.out_proj.0.weight", {d, d}).data, d, d);
+                upload_tm(w.ff0w, get(p + ".ff.0.weight", {ff, d}).data, ff, d);
+                upload_tm(w.ff1w, get(p + ".ff.3.weight", {d, ff}).data, d, ff);
                 // algebraic-LayerNorm operands (EncLayerW): sums in double, stored as f32
                 auto fold = [&](const std::vector<float>& W, const std::vector<float>& b, const std::vector<float>& gam,
                                 const std::vector<float>& bet, int N, float*& Wl, float*& sv, float*& cv) {
@@ -371,6 +395,7 @@ void finalize_model(mt2_model& m) {
         MT2_REQUIRE(d % c.plm_heads == 0 && (d / c.plm_heads) % 32 == 0 && d <= 1024, "PLM head dim");
         m.plm_enc = L.encoder("plm.plm.layers", c.plm_layers, d, d * 4, c.plm_heads, false);
         m.plm_wpred = L.mat("plm.predict_layer.weight", c.plm_bins, d);
+        L.upload_tm(m.plm_wpred, L.get("plm.predict_layer.weight", {c.plm_bins, d}).data, c.plm_bins, d);
         m.plm_emb = L.mat("plm.pc_embedding.weight", c.plm_bins + 2, c.plm_vq_dim);
         (void)L.get("plm.pos.alpha", {1});
         m.pe_plm = L.mat("pe.plm", c.max_positions, d);
@@ -430,6 +455,7 @@ void finalize_model(mt2_model& m) {
         if (!L.used.count(kv.first)) throw Error("unexpected tensor in state_dict: " + kv.first);
     m.host.clear();
     std::sort(m.planes.begin(), m.planes.end(), [](const PlaneRange& a, const PlaneRange& b) { return a.base < b.base; });
+    std::sort(m.tm.begin(), m.tm.end(), [](const TmRange& a, const TmRange& b) { return a.base < b.base; });
     m.finalized = true;
 }
 

@@ -80,8 +80,23 @@ static void attach_planes(const mt2_model& m, GemmP& p) {
         p.w3_plane = (long long)it->n;
     }
 }
+// the tile-major copy of the matrix a weight pointer lies in, if it has one (mt2_model::tm, sorted by base) and the
+// pointer starts on a block boundary (row multiple of 16, column multiple of 64)
+static void attach_tm(const mt2_model& m, GemmP& p) {
+    if (p.Wtm || m.tm.empty() || p.M > 64) return;
+    auto it = std::upper_bound(m.tm.begin(), m.tm.end(), p.W, [](const float* w, const TmRange& r) { return w < r.base; });
+    if (it == m.tm.begin()) return;
+    --it;
+    if (p.W >= it->base + it->n) return;
+    const size_t off = (size_t)(p.W - it->base);
+    const int n0 = (int)(off / it->K), k0 = (int)(off % it->K);
+    if ((n0 & 15) || (k0 & 63) || p.ldw != it->K) return;
+    p.Wtm = it->tm; p.tm_n0 = n0 / 16; p.tm_k0 = k0 / 64; p.tm_kb = it->K / 64;
+}
 static void gemm(const Ctx& c, GemmP p) {
     attach_planes(c.m, p);
+    if (p.ldw == 0) p.ldw = p.taps > 0 ? p.taps * p.Cin : p.Cin;
+    attach_tm(c.m, p);
     if (p.taps <= 0) p.taps = 1;
     if (p.dil <= 0) p.dil = 1;
     if (p.a_mul == 0) p.a_mul = 1;
@@ -123,6 +138,17 @@ static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, 
     p.X = x; p.ldx = ldx; p.Rx = Rx; p.a_mul = a_mul ? a_mul : 1; p.shift0 = shift0; p.taps = 1; p.dil = 1; p.Cin = K;
     p.K = K; p.W = w.W; p.ldw = K; p.bias = w.bias; p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.groups = 1; p.out_scale = 1.0f;
     p.epi_act = epi_act; p.ln_eps = 1e-5f;
+    if (c.m.opts.skinny_tm && M <= c.m.opts.skinny_rows && c.m.opts.force_cfg < 0) {
+        // a handful of rows: the weight-streaming kernel normalises its A rows itself (gemm_skinny_tm_kernel, PRO_LN) -
+        // one launch, statistics computed while the first weight pieces are in flight
+        GemmP q = p;
+        q.pro_act = 3; q.ln_g = w.g; q.ln_b = w.b;
+        attach_tm(c.m, q);
+        if (q.Wtm && gemm_skinny_tm_eligible(q, c.m.opts.skinny_rows)) {
+            MT2_HIP(launch_gemm(q, c.s, &c.m.opts));
+            return;
+        }
+    }
     if (c.m.opts.lnalg && w.Wl && K <= 1024) {
         p.pro_act = 4; p.W = w.Wl; p.bias = w.c; p.ln_g = w.s;
         const hipError_t e = launch_gemm(p, c.s, &c.m.opts);
@@ -284,6 +310,17 @@ static int choose_split(const Ctx& c, int M, int N, int K) {
     // a split GEMM hands its reduction to a stand-alone LayerNorm launch, which the LayerNorm-prologue GEMM
     // (ln_linear) otherwise removes: worth it only for the long K chains (PLM ff.3, K = 4096)
     if (c.m.opts.lnfuse && K < 2048) return 1;
+    // a handful of rows on the tile-major weight-streaming kernel (round 4): that kernel adds bias + residual itself and the
+    // NEXT GEMM normalises its own input rows (LayerNorm prologue), so a split - whose reduction needs a LayerNorm launch of
+    // its own - only pays where one column block's K range is too long for one workgroup: the PLM's ff.3 (K = 4096: 64
+    // blocks x 256 KiB); there the K slices are 1024 wide (256 workgroups x 64 KiB) and the reduction rides on LN1 as before
+    if (c.m.opts.skinny_tm && c.m.opts.skinny_rows > 0 && M <= c.m.opts.skinny_rows && M <= 64 && c.m.opts.force_cfg < 0 &&
+        (N & 15) == 0 && (K & 63) == 0) {
+        if (K <= 1536) return 1;
+        int S = 1;
+        while (S < 16 && K % (S * 2) == 0 && K / (S * 2) >= 1024 && (K / (S * 2)) % 64 == 0) S *= 2;
+        return S;
+    }
     // x6 form (large M): the N = d GEMMs of a layer (out-projection, ff.3) have too few 128x128 tiles for the bf16 pipe
     // (N = 768 / 1024: 6 / 8 column tiles); K slices as GEMM groups bring them to >= t_x6_128 tiles, and the reduction
     // rides on the next LayerNorm as before (profiles/r02_gemm_sweep_x6.txt: ff.3 at M = 864 does 85 TF/s on the f32

@@ -35,6 +35,10 @@ struct GemmP {
     const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like
     long long w3_plane = 0;     // W (same ldw / strideW, in bf16 elements), planes w3_plane elements apart (0: N * ldw) -
                                 // lets launch_gemm run on the bf16 matrix pipe in the f32-equivalent 6-product form
+    const float* Wtm = nullptr; // optional: the WHOLE matrix W points into, as tile-major blocks of 16 columns x 64 k (gemm_skinny.hip;
+    int tm_n0 = 0, tm_k0 = 0;   // model_load.hip TmRange); (tm_n0, tm_k0) = block coordinates of W's first element (row / 16, column /
+    int tm_kb = 0;              // 64), tm_kb = column blocks per block row (ldw / 64).  Lets launch_gemm stream the weights of a
+                                // launch with <= 64 rows in 1-KiB pieces
     const float* bias; long long strideB;
     const float* R; long long strideR; int ldr;
     const int* valid;
@@ -82,6 +86,7 @@ struct EngineOpts {
     int attn_x6_min = 192;       // attention on the bf16 pipe (f32-equivalent, AttnP::x6_min_qlen) from this many queries on; 0: never
                                  // (C5 step 5525 -> 5314 ms at 192, 5376 at 448: profiles/r03_opts_ab.txt)
     int attn_lds_waves = 0;      // ... its query tiles per workgroup (AttnP::lds_waves)
+    bool skinny_tm = true;       // ... on the tile-major weight copy where one exists (gemm_skinny_tm_kernel; LayerNorm prologue included)
     int skinny_groups = 1;       // ... only for launches with at least this many GemmP groups (split-K slabs)
     int skinny_nt = 0;           // gemm_skinny.hip (0: off); skinny_nt: non-temporal weight loads (measured: C1 65.2 ms with, 56.8 without)
     int x6_small_cfg = 0;        // 63..64: small loader-wave x6 tile for launches with at most t_x6_small_max 128x128 tiles and
@@ -96,6 +101,10 @@ hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
 // gemm_skinny.hip: weight-streaming linear layer for M <= 64 rows (taps = 1, no rowbase, K a multiple of 32)
 bool gemm_skinny_eligible(const GemmP& p, int max_rows);
 hipError_t launch_gemm_skinny(const GemmP& p, hipStream_t s);
+// ... on a tile-major weight copy (GemmP::Wtm), optionally with the LayerNorm prologue (pro_act == 3, groups == 1, K <= 1024)
+bool gemm_skinny_tm_eligible(const GemmP& p, int max_rows);
+hipError_t launch_gemm_skinny_tm(const GemmP& p, hipStream_t s);
+hipError_t launch_tile_major(const float* W, int N, int K, float* out, hipStream_t s);   // row-major [N, K] -> tile-major blocks
 int gemm_num_configs();
 const char* gemm_config_name(int idx);
 // per tile configuration: launches, executed FLOPs, summed ms; last entry "union" (see gemm_f32.hip); -1 on error

@@ -91,6 +91,9 @@ struct ConvW { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, k 
 // drivers look a weight pointer up here and hand the planes to launch_gemm (GemmP::W3), which may then run the launch
 // on the bf16 matrix pipe in the f32-equivalent 6-product form.
 struct PlaneRange { const float* base; size_t n; const uint16_t* p3; };
+// A linear layer's [N, K] weight matrix (N a multiple of 16, K of 64) that also exists as tile-major blocks (gemm_skinny.hip):
+// the matrices of the AR encoders and the PLM head - what a launch of at most 64 rows streams.
+struct TmRange { const float* base; size_t n; int K; const float* tm; };
 // grouped residual stack: entry (s, blk) holds `groups` consecutive [C, k*C] matrices
 struct StackW {
     float *w = nullptr, *b = nullptr, *g = nullptr, *be = nullptr;
@@ -126,6 +129,7 @@ struct mt2_model {
     std::map<std::string, mt2::HostTensor> host;
     std::vector<void*> dev_allocs;
     std::vector<mt2::PlaneRange> planes;       // sorted by base after finalize
+    std::vector<mt2::TmRange> tm;              // likewise
     size_t weight_bytes = 0;
     mt2::Arena ws;
 

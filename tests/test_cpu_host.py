@@ -39,7 +39,7 @@ def test_tile_configuration_table_matches_the_indices_the_chooser_uses():
             39: "x6dma128x128_4x2_s2", 49: "retired:x6areg64x128_2x2_s3", 51: "x6ldr256x128_4x2+4_s2",
             55: "x6ldr128x128_4x2+4_s3", 58: "x6winl256x64_8x1+4_s3", 59: "x6winl128x128_4x2+4_s2", 68: "x6ldm256x128_4x2+4_s2",
             72: "x6ldm128x128_2x2+4_s3", 75: "x6ldf128x128_4x2+4_s3", 84: "x6ks32x64_1x2_k4+8_s2", 85: "x6ks64x64_2x2_k2+8_s3",
-            86: "x6ks32x32_1x1_k8+8_s2", 87: "skinny32_f32", 88: "skinny64_f32"}
+            86: "x6ks32x32_1x1_k8+8_s2", 87: "skinny32_f32", 88: "skinny64_f32", 89: "skinnytm32_f32", 90: "skinnytm64_f32"}
     for i, name in want.items():
         assert names[i] == name, (i, names[i], name)
 

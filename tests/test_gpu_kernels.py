@@ -334,6 +334,71 @@ def test_gemm_skinny_streams_weights_for_a_handful_of_rows(rt, M, N, K, a_mul, s
     assert rel(y, ref) <= 2.0 * rel(f32, ref) + 1e-7
 
 
+@pytest.mark.parametrize("M,N,K,a_mul,shift0", [(1, 1024, 1024, 1, 0), (16, 3072, 1024, 1, 0), (33, 1024, 4096, 1, 0),
+                                                 (64, 768, 768, 1, 0), (42, 2304, 768, 1, 0), (7, 96, 192, 1, 0),
+                                                 (16, 1024, 1024, 5, 4), (40, 96, 64, 2, 1), (32, 64, 64, 1, 0),
+                                                 (5, 128, 2880, 1, 0), (17, 48, 320, 1, 0), (48, 512, 1024, 1, 0)])
+@pytest.mark.parametrize("pro", ["none", "relu", "lrelu", "ln"])
+def test_gemm_skinny_tile_major_weights_and_layernorm_prologue(rt, M, N, K, a_mul, shift0, pro):
+    """Round 4: gemm_skinny_tm_kernel - the weight-streaming kernel on the TILE-MAJOR copy of the weights (16-column x 64-k
+    blocks, 1 KiB contiguous per load instruction, v_mfma_f32_16x16x4_f32 on 1..4 row tiles of 16), every prologue incl.
+    LayerNorm (statistics of all rows per workgroup, A values normalised on the fly), strided row selection, K splits uneven
+    over the eight waves (K/64 not a multiple of 8, waves without a chunk), all epilogue operands - against float64 and never
+    worse than twice the tiled f32-MFMA engine's error on the same inputs."""
+    if pro == "ln" and K > 1024:
+        pytest.skip("LayerNorm prologue: K <= 1024")
+    rng = np.random.default_rng(M * 131 + N + K + len(pro))
+    act, slope = {"none": (rt.ACT_NONE, 0.0), "relu": (rt.ACT_RELU, 0.0), "lrelu": (rt.ACT_LRELU, 0.1), "ln": (rt.ACT_NONE, 0.0)}[pro]
+    Rx = (M - 1) * a_mul + shift0 + 1
+    X = (rng.standard_normal((Rx, K)) * np.exp(rng.uniform(-2, 2, (Rx, 1))) + rng.standard_normal((Rx, 1))).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    gam, bet = (1 + 0.2 * rng.standard_normal(K)).astype(np.float32), (0.1 * rng.standard_normal(K)).astype(np.float32)
+    valid = (rng.random(M) > 0.2).astype(np.int32)
+    a = X[shift0::a_mul][:M].astype(np.float64)
+    if pro == "ln":
+        a = (a - a.mean(1, keepdims=True)) / np.sqrt(a.var(1, keepdims=True) + 1e-5) * gam + bet
+    elif pro != "none":
+        a = np.where(a > 0, a, a * slope)
+    ref = (np.maximum(a @ W.T.astype(np.float64) + b, 0) + R) * valid[:, None]
+    Wt = rt.op_tile_major(dev(W))
+    y = rt.op_gemm_tm(dev(X), Wt, K, N, K, bias=dev(b), R=dev(R), valid=dev(valid), M=M, a_mul=a_mul, shift0=shift0,
+                      pro_act=act, pro_slope=slope, epi_act=rt.ACT_RELU, ln=(dev(gam), dev(bet)) if pro == "ln" else None).cpu().numpy()
+    assert np.isfinite(y).all()
+    assert rel(y, ref) < 2e-6, rel(y, ref)
+    assert not y[valid == 0].any()
+    if pro != "ln":
+        f32 = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=22, valid=dev(valid), a_mul=a_mul, shift0=shift0, M=M,
+                         pro_act=act, pro_slope=slope, epi_act=rt.ACT_RELU).cpu().numpy()
+        assert rel(y, ref) <= 2.0 * rel(f32, ref) + 1e-7
+
+
+def test_gemm_skinny_tile_major_sub_matrices_and_split_k_groups(rt):
+    """The tile-major kernel addresses SUB-matrices of a whole matrix by block coordinates: the K | V rows of a [3d, d] QKV
+    matrix (row offset), a K range (column offset) and split-K groups (slab g = columns [g K/S, (g+1) K/S) of both operands,
+    raw partial sums) - what the last AR layer and the PLM's ff.3 launch (model_stages.hip)."""
+    rng = np.random.default_rng(77)
+    d, M = 256, 19
+    W = (rng.standard_normal((3 * d, d)) / 16).astype(np.float32)
+    X = rng.standard_normal((M, d)).astype(np.float32)
+    Wt = rt.op_tile_major(dev(W))
+    kv = rt.op_gemm_tm(dev(X), Wt, d, 2 * d, d, n0=d).cpu().numpy()                                   # rows [d, 3d)
+    assert rel(kv, X.astype(np.float64) @ W[d:].T.astype(np.float64)) < 1e-6
+    part = rt.op_gemm_tm(dev(X[:, 64:]), Wt, d, d, 128, n0=2 * d, k0=64, ldx=d - 64).cpu().numpy()   # V rows, columns [64, 192)
+    Xs = np.ascontiguousarray(X[:, 64:])
+    assert rel(part, Xs[:, :128].astype(np.float64) @ W[2 * d:, 64:192].T.astype(np.float64)) < 1e-6
+    S, K = 4, 1024
+    W2 = (rng.standard_normal((128, K)) / 32).astype(np.float32)
+    X2 = rng.standard_normal((M, K)).astype(np.float32)
+    slabs = rt.op_gemm_tm(dev(X2), rt.op_tile_major(dev(W2)), K, 128, K // S, groups=S, x_gstride=K // S, w_gstride=K // S,
+                          ldx=K).cpu().numpy()
+    for g in range(S):
+        sl = slice(g * K // S, (g + 1) * K // S)
+        assert rel(slabs[g], X2[:, sl].astype(np.float64) @ W2[:, sl].T.astype(np.float64)) < 1e-6, g
+    assert rel(slabs.sum(0), X2.astype(np.float64) @ W2.T.astype(np.float64)) < 1e-6
+
+
 @pytest.mark.parametrize("pro", ["none", "relu", "lrelu"])
 @pytest.mark.parametrize("cfg", [51, 52, 55, 39, 67, 72, 75, 84])
 def test_gemm_x6_every_prologue_at_production_size(rt, cfg, pro):

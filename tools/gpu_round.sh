@@ -13,6 +13,8 @@
 #   sweep sweep_ar sweep_voc sweep_vocx   GEMM engine sweeps (all / AR shapes / vocoder shapes / vocoder launch variants)
 #   sweep_x6 sweep_x6s sweep_x6k sweep_skinny   x6 tile forms / under-filled AR launches / K-split x6 tiles / M <= 64 kernel
 #   frontend s2                      rows f3 / f2 measurements
+#   gridsync cpuinfo                 phase-boundary ubench (launch chain vs in-kernel grid barrier); host CPU limits of the box
+#   strong                           bench.py --scaling strong on one rank (C4: 256 ragged utterances in one call)
 # everything is written under gpurun_out/ (scratch); summaries worth keeping are copied to profiles/ by hand.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -25,6 +27,29 @@ tests)
   echo "kernels rc=$?"; tail -3 gpurun_out/kernels.log
   timeout 1500 python -m pytest tests/test_gpu_stages.py -m gpu -q --no-header -p no:cacheprovider --maxfail=40 -rf > gpurun_out/stages.log 2>&1
   echo "stages rc=$?"; tail -6 gpurun_out/stages.log ;;
+prof1)
+  # rocprofv3 kernel stats of the one-utterance path (C1 = infer.py's call); PROF_OPT="--opt name=value" for an A/B
+  rm -rf gpurun_out/prof1${PROF_TAG}
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof1${PROF_TAG} -o bench -- python $GRAFT_REPO_ROOT/bench.py --workload C1 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-sub-workloads ${PROF_OPT}) > gpurun_out/prof1${PROF_TAG}.log 2>&1
+  echo "prof1 rc=$?"; f=$(find gpurun_out/prof1${PROF_TAG} -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/prof1${PROF_TAG}_kernel_stats.csv && head -14 "$f" | cut -c1-200
+  find gpurun_out/prof1${PROF_TAG} -name "*kernel_trace.csv" -size +8M -delete ;;
+gridsync)
+  # phase-boundary price list on THIS box: dependent launches vs grid barriers inside one launch (tools/ubench/grid_sync.hip)
+  timeout 120 variants/ubench/grid_sync > gpurun_out/ubench_grid_sync.txt 2>&1
+  echo "gridsync rc=$?"; cat gpurun_out/ubench_grid_sync.txt ;;
+cpuinfo)
+  python - <<'PY' | tee gpurun_out/cpuinfo.txt
+import os
+print("cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
+for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us", "/sys/fs/cgroup/cpuset.cpus.effective"):
+    try: print(f, open(f).read().strip())
+    except Exception as e: print(f, "n/a")
+PY
+  ;;
+strong)
+  # BASELINE configs[3] on ONE rank: the 256 ragged utterances of C4 in one synthesize_batch call (the N = 1 anchor of a scaling run)
+  timeout 900 python bench.py --gpus 1 --scaling strong --steps ${STRONG_STEPS:-3} --warmup 1 --no-cpu-baseline --no-sub-workloads > gpurun_out/bench_strong.log 2>&1
+  echo "strong rc=$?"; tail -1 gpurun_out/bench_strong.log | cut -c1-1500 ;;
 ab)
   # interleaved in-process A/B of handle options (robust against clock / temperature drift): AB="x6_mp256=1 x6_mp=3 ..."
   for o in ${AB}; do

@@ -205,6 +205,22 @@ int mt2_synthesize_batch(mt2_model* m, void* stream, const int64_t* phone, const
                          int flags, float* mel, int Tm_cap, int32_t* mel_lens /*host*/, int32_t* dur_out,
                          int64_t* codes_out, float* wav, int64_t* prompt_codes);
 
+/* ---- prompt-conditioned synthesis as ONE call: the layout the PLM is trained on
+ * (modules/datamodule.py:161-177,196-212) at inference.  `prompt_phone` int64 [B, Npp_max] (device) / `prompt_phone_lens` (host) /
+ * `prompt_dur` int32 [B, Npp_max] (HOST) are the prompt utterance's own phones and alignment (sum over an utterance = its
+ * prompt frames; every prompt pools to the same ceil(frames / vq_stride) = P).  The prompt's tc_latents (its phones against
+ * the prompt mel, length-regulated by its alignment, max-pooled by vq_stride) stand in front of the target's as the PLM's
+ * conditioning, the prompt's VQ-PE codes (computed here, returned in prompt_codes int64 [B, ceil(Tp_max / vq_stride)], the first P
+ * of each row valid) behind the BOS; the PLM decodes the target's codes greedily from there (models/megatts2.py:165-181 on
+ * that layout), then :361-368 [+370] as in mt2_synthesize_batch.  One MRTE mel-encoder pass per call; flags: MT2_RUN_VOCODER.
+ * forced_dur (host, optional) replaces the ADM's durations after the ADM has run.  Other arguments as mt2_synthesize_batch. */
+int mt2_synthesize_prompt_conditioned(mt2_model* m, void* stream, const int64_t* phone, const int32_t* phone_lens /*host*/,
+                                      int Np_max, const float* prompt_mel, const int32_t* prompt_lens /*host*/, int Tp_max, int B,
+                                      const int64_t* prompt_phone, const int32_t* prompt_phone_lens /*host*/, int Npp_max,
+                                      const int32_t* prompt_dur /*host*/, const int32_t* forced_dur /*host*/, int Tq_cap, int flags,
+                                      float* mel, int Tm_cap, int32_t* mel_lens /*host*/, int32_t* dur_out, int64_t* codes_out,
+                                      float* wav, int64_t* prompt_codes);
+
 /* ---- tuning.  Every switch lives in the handle (no process-global state): two handles do not see each other's
  * settings.  Names: "ar_groups" (1..8, default 2: the sequences of an autoregressive run are dealt into that many
  * independent kernel chains on internal HIP streams that fork from and join back into `stream`; results do not

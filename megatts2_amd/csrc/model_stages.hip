@@ -660,33 +660,57 @@ static void ids_verdict(const Ctx& c) {
 }
 
 // MRTE.tc_latent (modules/mrte.py:154-171) -> packed rows [P.R, hidden] (gap rows zero)
+// Several phone sequences per utterance may share ONE mel context (prompt-conditioned synthesis: the target's phones and the
+// prompt's own phones against the same prompt mel, modules/datamodule.py:161-177): sequence s * B + b = set s, utterance b.
 struct TcResult { float* rows; RowSet P; };
-static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* phone_lens, int Np_max,
-                               const float* mel, const int* mel_lens, int Tp_max, int B) {
+struct PhoneSet { const int64_t* ids; const int* lens; int Np_max; };
+static TcResult tc_latent_rows(const Ctx& c, const std::vector<PhoneSet>& sets, const float* mel, const int* mel_lens,
+                               int Tp_max, int B) {
     mt2_model& m = c.m;
     const mt2_config& cfg = m.cfg;
-    const int H = cfg.mrte_hidden;
+    const int H = cfg.mrte_hidden, S = (int)sets.size(), BS = B * S;
     IntPlan ip;
     MelPlan mp = plan_mel(ip, cfg, mel_lens, B, Tp_max, 0);
-    RowSet P = make_rows(phone_lens, B, 2);
+    std::vector<int> all_lens(BS);
+    for (int s_ = 0; s_ < S; ++s_)
+        for (int b = 0; b < B; ++b) {
+            MT2_REQUIRE(sets[s_].lens[b] >= 1 && sets[s_].lens[b] <= sets[s_].Np_max, "phone length out of range");
+            all_lens[s_ * B + b] = sets[s_].lens[b];
+        }
+    RowSet P = make_rows(all_lens.data(), BS, 2);
     MT2_REQUIRE(P.maxlen <= cfg.max_positions, "phone sequence longer than the positional table");
     RowPlanOffsets oP = plan_rows(ip, P);
-    std::vector<int> idmap(P.R, -1);                 // row -> index into the padded [B, Np_max] id tensor (gap rows: -1)
-    for (int b = 0; b < B; ++b)
-        for (int t = 0; t < P.len[b]; ++t) idmap[P.off[b] + t] = b * Np_max + t;
-    const int o_idmap = ip.add(idmap);
+    std::vector<int> idmap(P.R, -1);                 // row -> index into ITS SET's padded [B, Np_max] id tensor (gap rows: -1)
     std::vector<int> pos(P.R, 0);
-    for (int b = 0; b < B; ++b) {
-        MT2_REQUIRE(phone_lens[b] >= 1 && phone_lens[b] <= Np_max, "phone length out of range");
-        for (int t = 0; t < P.len[b]; ++t) pos[P.off[b] + t] = t;
-    }
+    for (int s_ = 0; s_ < S; ++s_)
+        for (int b = 0; b < B; ++b) {
+            const int q = s_ * B + b;
+            for (int t = 0; t < P.len[q]; ++t) {
+                idmap[P.off[q] + t] = b * sets[s_].Np_max + t;
+                pos[P.off[q] + t] = t;
+            }
+        }
+    const int o_idmap = ip.add(idmap);
     const int o_pos = ip.add(pos);
+    // cross attention: sequence q reads the mel context of utterance q % B
+    std::vector<int> kvs(BS), kvl(BS);
+    int o_kvs = -1, o_kvl = -1;
     ip.upload(c.ws, c.m.pinned(), c.s);
     bind_rows(ip, mp.oF, mp.F);
     bind_rows(ip, mp.oX, mp.X);
     bind_rows(ip, oP, P);
+    IntPlan ip2;                                      // kv ranges need mp.X's offsets: a second (tiny) plan when S > 1
+    if (S > 1) {
+        for (int q = 0; q < BS; ++q) { kvs[q] = mp.X.off[q % B]; kvl[q] = mp.X.len[q % B]; }
+        o_kvs = ip2.add(kvs); o_kvl = ip2.add(kvl);
+        ip2.upload(c.ws, c.m.pinned(), c.s);
+    }
     // phone ids index the embedding table: range check on the id stream (verdict at the end of the API call)
-    ids_check(c, phone, &idmap, P.R, cfg.phone_vocab, ID_PHONE);
+    for (int s_ = 0; s_ < S; ++s_) {
+        const int r0 = P.off[s_ * B] - P.G, r1 = s_ + 1 < S ? P.off[(s_ + 1) * B] - P.G : P.R;
+        std::vector<int> sub(idmap.begin() + r0, idmap.begin() + r1);
+        ids_check(c, sets[s_].ids, &sub, (long long)sub.size(), cfg.phone_vocab, ID_PHONE);
+    }
 
     // The phone branch (embedding, conv-FF transformer, query projection: ~60 small launches) does not depend on
     // the mel encoder: it runs on a side stream and fills the CUs the mel stack's big launches leave idle
@@ -705,10 +729,14 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
 
     // phone embedding + PE, conv-FF transformer (mrte.py:159-160,165)
     float* x = c.ws.get<float>((size_t)P.R * H);
-    MT2_HIP(launch_embed_pe(m.phone_emb, H, phone, ip.dev(o_idmap), ip.dev(o_pos), m.pe_mrte, x, H, P.R, cfg.phone_vocab, side));
+    for (int s_ = 0; s_ < S; ++s_) {                  // one embedding launch per id tensor, over that set's rows
+        const int r0 = P.off[s_ * B] - P.G, r1 = s_ + 1 < S ? P.off[(s_ + 1) * B] - P.G : P.R;
+        MT2_HIP(launch_embed_pe(m.phone_emb, H, sets[s_].ids, ip.dev(o_idmap) + r0, ip.dev(o_pos) + r0, m.pe_mrte,
+                                x + (size_t)r0 * H, H, r1 - r0, cfg.phone_vocab, side));
+    }
     EncScratch sc = enc_scratch(c, m.phone_enc, P.R);
     AttnGeom g;
-    g.start = P.d_start; g.len = P.d_len; g.B = B; g.max_len = P.maxlen;
+    g.start = P.d_start; g.len = P.d_len; g.B = BS; g.max_len = P.maxlen;
     for (auto& lw : m.phone_enc.layers) encoder_layer(cp, m.phone_enc, lw, x, P.R, g, P.d_valid, sc);
 
     // cross attention, ONE head of width H (mrte.py:131-135,167), LayerNorm, ReLU (:168-169)
@@ -720,8 +748,9 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
     linear(c, ctx, H, mp.X.R, m.x_wkv, m.x_bkv, 2 * H, H, kv, 2 * H);
     AttnP a{};
     a.Q = q; a.ldq = H; a.K = kv; a.ldk = 2 * H; a.V = kv + H; a.ldv = 2 * H; a.O = sc.att; a.ldo = H;
-    a.q_start = P.d_start; a.q_len = P.d_len; a.kv_start = mp.X.d_start; a.kv_len = mp.X.d_len;
-    a.B = B; a.H = 1; a.D = H; a.max_qlen = P.maxlen; a.max_kvlen = mp.X.maxlen; a.scale = 1.0f / std::sqrt((float)H);
+    a.q_start = P.d_start; a.q_len = P.d_len;
+    a.kv_start = S > 1 ? ip2.dev(o_kvs) : mp.X.d_start; a.kv_len = S > 1 ? ip2.dev(o_kvl) : mp.X.d_len;
+    a.B = BS; a.H = 1; a.D = H; a.max_qlen = P.maxlen; a.max_kvlen = mp.X.maxlen; a.scale = 1.0f / std::sqrt((float)H);
     a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves; a.x6_min_qlen = c.m.opts.attn_x6_min;
     MT2_HIP(launch_attention(a, c.s));
     float* o = c.ws.get<float>((size_t)P.R * H);
@@ -729,6 +758,10 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
     float* tc = c.ws.get<float>((size_t)P.R * H);
     layernorm(c, o, H, m.x_ng, m.x_nb, P.R, H, tc, H, P.d_valid, 0, nullptr, 0, 0, 0, ACT_RELU);
     return {tc, P};
+}
+static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* phone_lens, int Np_max,
+                               const float* mel, const int* mel_lens, int Tp_max, int B) {
+    return tc_latent_rows(c, std::vector<PhoneSet>{{phone, phone_lens, Np_max}}, mel, mel_lens, Tp_max, B);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -793,6 +826,7 @@ struct ArPrefix {
     int P = 0;
     const void* data = nullptr;   // ADM: float [B, P] un-rounded predictions; PLM: int64 [B, P] prosody codes
     int max_steps = 0;
+    int stride = 0;               // PLM: row stride of `data` in elements (0: P)
 };
 
 // MegaADM.infer (models/megatts2.py:257-275).  tc: rows buffer (ld), utterance b's first row row0[b].
@@ -914,7 +948,7 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
         cofs += q.B;
         // BOS literal 1024 (models/megatts2.py:170), then the prompt's codes if any - on the device, no host staging
         MT2_HIP(launch_plm_init_hist(q.codes, cstride, 1024, static_cast<const int64_t*>(pre.data), pre.P,
-                                     ip.dev(q.o_slot), q.B, c.s));
+                                     pre.stride > 0 ? pre.stride : pre.P, ip.dev(q.o_slot), q.B, c.s));
         q.x = c.ws.get<float>((size_t)Mmax * d);
         q.logits = c.ws.get<float>((size_t)q.B * NB);
         q.sc = enc_scratch(c, e, std::max(Mmax, 2 * q.B));   // last layer: q | att rows of A sequences

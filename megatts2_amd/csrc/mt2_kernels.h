@@ -203,10 +203,10 @@ hipError_t launch_plm_finalize(const int64_t* codes, int cstride, const int* len
                                int ostride, int A, int nmax, int skip, hipStream_t s);
 // AR history initialisation (one launch instead of a host-staged copy):
 //   ADM  p[j*pstride + 0] = 0 (models/megatts2.py:262), p[j*pstride + 1 + i] = prefix[slot_b[j]*P + i], rest 0
-//   PLM  codes[j*cstride + 0] = bos (:170), codes[j*cstride + 1 + i] = prefix[slot_b[j]*P + i], rest 0
+//   PLM  codes[j*cstride + 0] = bos (:170), codes[j*cstride + 1 + i] = prefix[slot_b[j]*pstride + i], rest 0
 hipError_t launch_adm_init_hist(float* p, int pstride, const float* prefix, int P, const int* slot_b, int A,
                                 hipStream_t s);
-hipError_t launch_plm_init_hist(int64_t* codes, int cstride, int64_t bos, const int64_t* prefix, int P,
+hipError_t launch_plm_init_hist(int64_t* codes, int cstride, int64_t bos, const int64_t* prefix, int P, int pstride,
                                 const int* slot_b, int A, hipStream_t s);
 // flag |= bit when an id used by the call is outside [0, hi): ids[map[r]] for map[r] >= 0 (map == nullptr: ids[r])
 hipError_t launch_check_ids(const int64_t* ids, const int* map, int R, long long hi, int* flag, int bit,

@@ -653,21 +653,21 @@ hipError_t launch_adm_init_hist(float* p, int pstride, const float* prefix, int 
                        slot_b, A);
     return hipGetLastError();
 }
-__global__ void plm_init_hist_kernel(int64_t* codes, int cstride, int64_t bos, const int64_t* prefix, int P,
+__global__ void plm_init_hist_kernel(int64_t* codes, int cstride, int64_t bos, const int64_t* prefix, int P, int pstride,
                                      const int* slot_b, int A) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A * cstride) return;
     const int j = i / cstride, t = i % cstride;
     int64_t v = 0;
     if (t == 0) v = bos;
-    else if (t <= P) v = prefix[(long long)(slot_b ? slot_b[j] : j) * P + (t - 1)];
+    else if (t <= P) v = prefix[(long long)(slot_b ? slot_b[j] : j) * pstride + (t - 1)];
     codes[i] = v;
 }
-hipError_t launch_plm_init_hist(int64_t* codes, int cstride, int64_t bos, const int64_t* prefix, int P,
+hipError_t launch_plm_init_hist(int64_t* codes, int cstride, int64_t bos, const int64_t* prefix, int P, int pstride,
                                 const int* slot_b, int A, hipStream_t s) {
     if (A * cstride <= 0) return hipSuccess;
     hipLaunchKernelGGL(plm_init_hist_kernel, dim3((A * cstride + 255) / 256), dim3(256), 0, s, codes, cstride, bos,
-                       prefix, P, slot_b, A);
+                       prefix, P, pstride, slot_b, A);
     return hipGetLastError();
 }
 

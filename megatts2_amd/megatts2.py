@@ -350,8 +350,20 @@ class Megatts:
         on (reference modules/datamodule.py:161-177,196-212) at inference: the prompt's length-regulated, max-pooled
         tc_latents in front of the target's, the prompt's VQ-PE codes behind the BOS, greedy decoding from there.
         `prompt_phone_tokens` int64 [B, Npp] / `prompt_durations` int32 [B, Npp] are the prompt utterance's own phones and
-        alignment (sum = prompt frames).  One call here = the C-ABI stage calls tc_latent (prompt, target), vqpe_forward,
-        adm_infer, length_regulate, max_pool, plm_infer_prompted, then synthesize_batch with the decoded codes forced."""
+        alignment (sum = prompt frames).  ONE native call (mt2_synthesize_prompt_conditioned): the MRTE mel encoder runs once
+        for both phone sets, the prompt's VQ-PE beside the ADM on the handle's side stream, nothing leaves the device between
+        the stages but the durations.  `synthesize_prompt_conditioned_staged` is the same computation as ten C-ABI stage
+        calls (round 3's form; kept as the cross-check of the fused entry point)."""
+        out = self.native.synthesize_prompt_conditioned(phone_tokens, phone_lens, mels, mel_lens, prompt_phone_tokens,
+                                                        prompt_phone_lens, prompt_durations, forced_dur=forced_durations,
+                                                        vocoder=vocoder)
+        return out if return_aux else (out[0], out[1])
+
+    def synthesize_prompt_conditioned_staged(self, phone_tokens, mels, prompt_phone_tokens, prompt_durations, phone_lens=None,
+                                             mel_lens=None, prompt_phone_lens=None, forced_durations=None, vocoder: bool = False,
+                                             return_aux: bool = False):
+        """The stage-call composition of `synthesize_prompt_conditioned`: tc_latent (prompt, target), vqpe_forward, adm_infer,
+        length_regulate, max_pool, plm_infer_prompted, then synthesize_batch with the decoded codes forced."""
         import torch
         nat = self.native
         B = phone_tokens.shape[0]

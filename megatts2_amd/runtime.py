@@ -423,6 +423,47 @@ class NativeModel:
             return mel, mel_lens, {"dur": dur_out, "codes": codes_out, "wav": wav, "prompt_codes": pcodes}
         return mel, mel_lens
 
+    def synthesize_prompt_conditioned(self, phone, phone_lens, prompt_mel, prompt_lens, prompt_phone, prompt_phone_lens,
+                                      prompt_dur, forced_dur=None, vocoder=False, tm_cap: Optional[int] = None):
+        """mt2_synthesize_prompt_conditioned: prompt-conditioned synthesis (the PLM continued from the prompt's prosody codes,
+        modules/datamodule.py:161-177,196-212) as ONE native call -> (mel, mel_lens, aux) with aux["dur"] the ADM's own
+        durations, aux["codes"] the decoded target codes, aux["prompt_codes"] [B, P] the prompt's VQ-PE codes."""
+        import torch
+        B, Np = phone.shape
+        Tp, Npp = prompt_mel.shape[1], prompt_phone.shape[1]
+        phone = phone.contiguous().to(torch.int64)
+        prompt_phone = prompt_phone.contiguous().to(torch.int64)
+        prompt_mel = self._f32(prompt_mel)
+        pl, ml, ppl = self._lens(phone_lens, B, Np), self._lens(prompt_lens, B, Tp), self._lens(prompt_phone_lens, B, Npp)
+        pd = _i32(prompt_dur.detach().cpu().numpy() if hasattr(prompt_dur, "detach") else prompt_dur).reshape(B, Npp)
+        for b in range(B):
+            if int(pd[b, :ppl[b]].sum()) != int(ml[b]):
+                raise ValueError("prompt durations must sum to the prompt's mel frames")      # datamodule.py:198 assert
+        st = self.g_cfg.vqpe.stride
+        if len({-(-int(v) // st) for v in ml}) != 1:
+            raise ValueError("prompt-conditioned batches need prompts of one pooled length (pad-free prefix layout)")
+        fd = None
+        if forced_dur is not None:
+            fd = _i32(forced_dur.detach().cpu().numpy() if hasattr(forced_dur, "detach") else forced_dur).reshape(B, Np)
+            tm_cap = max(tm_cap or 0, int(max(int(fd[b, :pl[b]].sum()) for b in range(B))))
+        if tm_cap is None:
+            tm_cap = 128 * Np          # clamp(1, 128) bounds every duration (models/megatts2.py:275)
+        tq_cap = -(-tm_cap // st)
+        dev = prompt_mel.device
+        mel = torch.empty(B, tm_cap, self.g_cfg.mrte.mel_bins, device=dev, dtype=torch.float32)
+        mel_lens = np.zeros(B, np.int32)
+        dur_out = torch.empty(B, Np, device=dev, dtype=torch.int32)
+        codes_out = torch.empty(B, tq_cap, device=dev, dtype=torch.int64)
+        pad = int(getattr(self.hg_cfg, "inference_padding", 0))
+        wav = torch.empty(B, self.hg_cfg.hop * (tm_cap + 2 * pad), device=dev, dtype=torch.float32) if vocoder else None
+        pcodes = torch.empty(B, -(-Tp // st), device=dev, dtype=torch.int64)
+        _check(self.lib.mt2_synthesize_prompt_conditioned(
+            self.h, _stream(), _ptr(phone), _iptr(pl), Np, _ptr(prompt_mel), _iptr(ml), Tp, B, _ptr(prompt_phone), _iptr(ppl), Npp,
+            _iptr(pd), _iptr(fd), tq_cap, MT2_RUN_VOCODER if vocoder else 0, _ptr(mel), tm_cap, _iptr(mel_lens), _ptr(dur_out),
+            _ptr(codes_out), _ptr(wav), _ptr(pcodes)))
+        P = -(-int(ml[0]) // st)
+        return mel, mel_lens, {"dur": dur_out, "codes": codes_out, "wav": wav, "prompt_codes": pcodes[:, :P]}
+
     # ---- tuning / measurement (every switch lives in THIS handle; the library has no mutable globals)
     def set_option(self, name: str, value: int) -> None:
         _check(self.lib.mt2_set_option(self.h, name.encode(), int(value)))

@@ -1039,6 +1039,36 @@ def test_prompt_conditioned_synthesis_as_one_call(kind):
         assert O.rel_l2(mel2[b, :n].cpu().numpy(), z["mel"]) < NORTH_STAR
     with pytest.raises(ValueError, match="sum to the prompt"):
         tts.synthesize_prompt_conditioned(args[0], args[1], args[2], z["prompt_dur"][None] + 1)
+    # round 4: the call above is ONE native entry point (mt2_synthesize_prompt_conditioned: one mel-encoder pass for both phone
+    # sets, VQ-PE beside the ADM).  Against round 3's composition of ten stage calls: same discrete outputs, same mel; on a
+    # RAGGED pair too (the fixture's utterance beside one with fewer target phones and another split of the prompt alignment),
+    # with the vocoder.
+    st_mel, st_lens, st_aux = tts.synthesize_prompt_conditioned_staged(*args, forced_durations=z["forced_dur"][None], return_aux=True)
+    assert torch.equal(st_aux["codes"][0, :z["p_codes"].size], aux["codes"][0, :z["p_codes"].size])
+    assert torch.equal(st_aux["dur"], aux["dur"]) and torch.equal(st_aux["prompt_codes"], aux["prompt_codes"])
+    assert O.rel_l2(mel[0, :n].cpu().numpy(), st_mel[0, :n].cpu().numpy()) < TIGHT
+    ph2, pd2 = z["phone"][: max(1, z["phone"].size // 2)], z["prompt_dur"].copy()
+    pph2 = z["prompt_phone"][:-1] if z["prompt_phone"].size > 1 else z["prompt_phone"]
+    pd2 = pd2[:pph2.size].copy()
+    pd2[-1] += int(z["prompt_dur"].sum()) - int(pd2.sum())                      # same prompt frames, one phone fewer
+    fd2 = z["forced_dur"][:ph2.size]
+    phone_b, pl_b = pad_stack([z["phone"], ph2])
+    pph_b, ppl_b = pad_stack([z["prompt_phone"], pph2])
+    pd_b, _ = pad_stack([z["prompt_dur"], pd2])
+    fd_b, _ = pad_stack([z["forced_dur"], fd2])
+    mels_b = dev(np.stack([z["prompt_mel"], z["prompt_mel"]]))
+    kw = dict(phone_lens=pl_b, prompt_phone_lens=ppl_b, forced_durations=fd_b, vocoder=True, return_aux=True)
+    fm, fl, fa = tts.synthesize_prompt_conditioned(dev(phone_b), mels_b, dev(pph_b), pd_b, **kw)
+    sm, sl, sa = tts.synthesize_prompt_conditioned_staged(dev(phone_b), mels_b, dev(pph_b), pd_b, **kw)
+    assert fl.tolist() == sl.tolist() == [int(z["forced_dur"].sum()), int(fd2.sum())]
+    assert np.array_equal(fa["codes"][0, :z["p_codes"].size].cpu().numpy(), z["p_codes"])
+    for b in range(2):
+        nq = -(-int(fl[b]) // 8)
+        assert torch.equal(fa["codes"][b, :nq], sa["codes"][b, :nq]) and torch.equal(fa["dur"][b], sa["dur"][b])
+        assert O.rel_l2(fm[b, :fl[b]].cpu().numpy(), sm[b, :fl[b]].cpu().numpy()) < TIGHT
+        hop = tts.hifi_gan.cfg.hop
+        assert O.rel_l2(fa["wav"][b, :fl[b] * hop].cpu().numpy(), sa["wav"][b, :fl[b] * hop].cpu().numpy()) < 1e-4
+        assert not fm[b, fl[b]:].any()
 
 
 def test_hifigan_reflect_edge_mode():

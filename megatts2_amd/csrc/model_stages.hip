@@ -796,9 +796,9 @@ struct ArGroups {
     std::vector<std::vector<int>> slots;   // group -> positions in the length-sorted order
     std::vector<hipStream_t> stream;
 };
-static ArGroups ar_groups(mt2_model& m, hipStream_t main, const ArOrder& ord, int B) {
+static ArGroups ar_groups(mt2_model& m, hipStream_t main, const ArOrder& ord, int B, int stage_groups = 0) {
     ArGroups g;
-    g.G = std::max(1, std::min(m.ar_groups, B));
+    g.G = std::max(1, std::min(stage_groups > 0 ? stage_groups : m.ar_groups, B));
     g.slots.resize(g.G);
     for (int j = 0; j < B; ++j) g.slots[j % g.G].push_back(j);
     ensure_aux(m, g.G - 1);
@@ -840,7 +840,7 @@ static void adm_run(const Ctx& c, const float* tc, int ld_tc, int tc_rows, const
     ArOrder ord = ar_order(lens, B);
     MT2_REQUIRE(ord.nmax <= cfg.max_positions, "ADM sequence longer than the positional table");
     for (int b = 0; b < B; ++b) MT2_REQUIRE(lens[b] > pre.P, "forced history is not shorter than the sequence");
-    ArGroups grp = ar_groups(m, c.s, ord, B);
+    ArGroups grp = ar_groups(m, c.s, ord, B, m.adm_groups);
     struct Grp {
         int B, nmax, A; int o_tcrow, o_len, o_slot;
         std::vector<int> len;
@@ -882,19 +882,19 @@ static void adm_run(const Ctx& c, const float* tc, int ld_tc, int tc_rows, const
     }
     ar_fork(m, grp);
     const int t_end = pre.max_steps > 0 ? std::min(ord.nmax, pre.P + pre.max_steps) : ord.nmax;
-    for (int t = pre.P; t < t_end; ++t) {
+    auto step = [&](int g, int t) {
         const int n = t + 1;
-        for (int g = 0; g < grp.G; ++g) {
-            Grp& q = gs[g];
-            while (q.A > 0 && q.len[q.A - 1] <= t) --q.A;
-            if (q.A == 0) continue;
-            Ctx cg{m, grp.stream[g], c.ws};
-            MT2_HIP(launch_adm_step_input(tcemb, Dc, ip.dev(q.o_tcrow), m.adm_wdt, q.p, pstride, m.pe_adm, q.x, Dc, De,
-                                          n, q.A, cg.s));
-            const float* y = ar_step_layers(cg, e, q.x, n, q.A, q.qkv0, q.nmax, q.sc, q.ylast, t == pre.P && pre.P > 0);
-            MT2_HIP(launch_adm_predict(y, d, m.adm_wpred, q.p, pstride, n, 1, q.A, cg.s));
-        }
-    }
+        Grp& q = gs[g];
+        while (q.A > 0 && q.len[q.A - 1] <= t) --q.A;
+        if (q.A == 0) return;
+        Ctx cg{m, grp.stream[g], c.ws};
+        MT2_HIP(launch_adm_step_input(tcemb, Dc, ip.dev(q.o_tcrow), m.adm_wdt, q.p, pstride, m.pe_adm, q.x, Dc, De,
+                                      n, q.A, cg.s));
+        const float* y = ar_step_layers(cg, e, q.x, n, q.A, q.qkv0, q.nmax, q.sc, q.ylast, t == pre.P && pre.P > 0);
+        MT2_HIP(launch_adm_predict(y, d, m.adm_wpred, q.p, pstride, n, 1, q.A, cg.s));
+    };
+    for (int t = pre.P; t < t_end; ++t)        // interleaved: both chains' queues are fed step by step
+        for (int g = 0; g < grp.G; ++g) step(g, t);
     for (int g = 0; g < grp.G; ++g) {
         Grp& q = gs[g];
         MT2_HIP(launch_adm_finalize(q.p, pstride, ip.dev(q.o_len), ip.dev(q.o_slot), dur_out, flt_out, dstride, q.B,
@@ -916,7 +916,7 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
     MT2_REQUIRE(ord.nmax <= cfg.max_positions, "PLM sequence longer than the positional table");
     MT2_REQUIRE(1024 < cfg.plm_bins + 2, "pc_embedding too small for the BOS id 1024");
     for (int b = 0; b < B; ++b) MT2_REQUIRE(lens[b] > pre.P, "prompt prefix is not shorter than the sequence");
-    ArGroups grp = ar_groups(m, c.s, ord, B);
+    ArGroups grp = ar_groups(m, c.s, ord, B, m.plm_groups);
     struct Grp {
         int B, nmax, A; int o_crow, o_len, o_slot;
         std::vector<int> len, slot;
@@ -957,29 +957,29 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
     }
     ar_fork(m, grp);
     const int t_end = pre.max_steps > 0 ? std::min(ord.nmax, pre.P + pre.max_steps) : ord.nmax;
-    for (int t = pre.P; t < t_end; ++t) {
+    auto step = [&](int g, int t) {
         const int n = t + 1;
-        for (int g = 0; g < grp.G; ++g) {
-            Grp& q = gs[g];
-            while (q.A > 0 && q.len[q.A - 1] <= t) --q.A;
-            if (q.A == 0) continue;
-            Ctx cg{m, grp.stream[g], c.ws};
-            MT2_HIP(launch_plm_step_input(cond, ld_c, ip.dev(q.o_crow), m.plm_emb, q.codes, cstride, m.pe_plm, q.x, Dc,
-                                          De, n, q.A, NB + 2, cg.s));
-            const float* y = ar_step_layers(cg, e, q.x, n, q.A, q.qkv0, q.nmax, q.sc, q.ylast, t == pre.P && pre.P > 0);
-            // predict_layer on the last position of each sequence only (:178 takes [:, -1:]), then argmax
-            GemmP p{};
-            p.X = y; p.ldx = d; p.Rx = q.A; p.Cin = d; p.W = m.plm_wpred;
-            p.C = q.logits; p.ldc = NB; p.M = q.A; p.N = NB;
-            gemm(cg, p);
-            MT2_HIP(launch_argmax_rows(q.logits, NB, NB, q.codes, cstride, n, q.A, cg.s));
-            if (last_logits && t - pre.P < logit_tmax)
-                for (int j = 0; j < q.A; ++j)
-                    MT2_HIP(hipMemcpyAsync(last_logits + ((size_t)q.slot[j] * logit_tmax + (t - pre.P)) * NB,
-                                           q.logits + (size_t)j * NB, sizeof(float) * NB, hipMemcpyDeviceToDevice,
-                                           cg.s));
-        }
-    }
+        Grp& q = gs[g];
+        while (q.A > 0 && q.len[q.A - 1] <= t) --q.A;
+        if (q.A == 0) return;
+        Ctx cg{m, grp.stream[g], c.ws};
+        MT2_HIP(launch_plm_step_input(cond, ld_c, ip.dev(q.o_crow), m.plm_emb, q.codes, cstride, m.pe_plm, q.x, Dc,
+                                      De, n, q.A, NB + 2, cg.s));
+        const float* y = ar_step_layers(cg, e, q.x, n, q.A, q.qkv0, q.nmax, q.sc, q.ylast, t == pre.P && pre.P > 0);
+        // predict_layer on the last position of each sequence only (:178 takes [:, -1:]), then argmax
+        GemmP p{};
+        p.X = y; p.ldx = d; p.Rx = q.A; p.Cin = d; p.W = m.plm_wpred;
+        p.C = q.logits; p.ldc = NB; p.M = q.A; p.N = NB;
+        gemm(cg, p);
+        MT2_HIP(launch_argmax_rows(q.logits, NB, NB, q.codes, cstride, n, q.A, cg.s));
+        if (last_logits && t - pre.P < logit_tmax)
+            for (int j = 0; j < q.A; ++j)
+                MT2_HIP(hipMemcpyAsync(last_logits + ((size_t)q.slot[j] * logit_tmax + (t - pre.P)) * NB,
+                                       q.logits + (size_t)j * NB, sizeof(float) * NB, hipMemcpyDeviceToDevice,
+                                       cg.s));
+    };
+    for (int t = pre.P; t < t_end; ++t)
+        for (int g = 0; g < grp.G; ++g) step(g, t);
     for (int g = 0; g < grp.G; ++g) {
         Grp& q = gs[g];
         const int nt = q.nmax - pre.P;

@@ -172,6 +172,7 @@ struct mt2_model {
 
     // AR stream groups (model_stages.hip): sequences are split into `ar_groups` independent kernel chains
     int ar_groups = 2;
+    int adm_groups = 0, plm_groups = 0;     // per-stage override of ar_groups (0: ar_groups)
     std::vector<hipStream_t> aux_streams;
     hipEvent_t ev_fork = nullptr;
     std::vector<hipEvent_t> ev_join;

@@ -472,6 +472,11 @@ __device__ __forceinline__ void attn_x6(f32x16& acc, const au32x4 (&a)[3], const
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, a[PA[t]]), __builtin_bit_cast(abf16x8, b[PB[t]]), acc, 0, 0, 0);
 }
 
+// Round 4: a DOUBLE-BUFFERED plane stage (split of tile t+1 between the S products and the softmax of tile t, one barrier per
+// tile) was built and measured: parity-green, 0...-5 % on the isolated launch, +0.4 % on the C5 step (twice the LDS per
+// workgroup) - not kept (profiles/r04_attn_bench.txt, r04_experiment_attn_double_buffer.patch).  A tile's cost is its VALU work -
+// the softmax (16 expf per lane), two run-time splits of P and the rescale of O - not the barrier count: what WAS kept are
+// the exact savings there (no key mask on full tiles, no rescale when no query's running maximum moved).
 template <int D, int NWQ>     // D = 64 or 96; workgroup = NWQ waves = NWQ consecutive query tiles of one (utterance, head)
 __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) void attn_x6_kernel(AttnP p) {
     constexpr int NT = 64 * NWQ;
@@ -583,64 +588,82 @@ __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) v
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[t][e] = 0.0f;
 
-    prefetch(0);
-    for (int kv0 = 0; kv0 < kl; kv0 += 32) {
-        stage();
-        __syncthreads();
-        if (kv0 + 32 < kl) prefetch(kv0 + 32);                          // block-uniform; in flight during the MFMAs
-        if (active) {
-            f32x16 s;
+    f32x16 sc;
+    auto scores = [&]() {                 // S^T = K Q^T of the staged tile
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = 0.0f;
-            const char* krow = kp + l31 * RSK + half * 16;
+        for (int e = 0; e < 16; ++e) sc[e] = 0.0f;
+        const char* krow = kp + l31 * RSK + half * 16;
 #pragma unroll
-            for (int f = 0; f < NB; ++f) {
-                au32x4 ka[3];
+        for (int f = 0; f < NB; ++f) {
+            au32x4 ka[3];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) ka[pl] = *reinterpret_cast<const au32x4*>(krow + pl * KPL + f * 32);
-                attn_x6(s, ka, qp[f]);
+            for (int pl = 0; pl < 3; ++pl) ka[pl] = *reinterpret_cast<const au32x4*>(krow + pl * KPL + f * 32);
+            attn_x6(sc, ka, qp[f]);
+        }
+    };
+    auto softmax_pv = [&](int kv0) {
+        f32x16& s = sc;
+        // s[e] = S^T[kv0 + (e&3) + 8*(e>>2) + 4*half][q = l31]
+        float mloc = -INFINITY;
+        if (kv0 + 32 <= kl) {              // a full tile (block-uniform): no key mask
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[e] *= scale;
+                mloc = fmaxf(mloc, s[e]);
             }
-            // s[e] = S^T[kv0 + (e&3) + 8*(e>>2) + 4*half][q = l31]
-            float mloc = -INFINITY;
+        } else {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
                 s[e] = kvr < kl ? s[e] * scale : -INFINITY;
                 mloc = fmaxf(mloc, s[e]);
             }
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            const float m_new = fmaxf(m_run, mloc);
-            const float alpha = expf(m_run - m_new);
-            float lsum = 0.0f;
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = expf(m_run - m_new);
+        float lsum = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                s[e] = expf(s[e] - m_new);
-                lsum += s[e];
-            }
-            lsum += __shfl_xor(lsum, 32);
-            l_run = l_run * alpha + lsum;
-            m_run = m_new;
-#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[e] = expf(s[e] - m_new);
+            lsum += s[e];
+        }
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+        if (__any(alpha != 1.0f)) {        // the running maximum moved for some query of this wave (rare after the first tiles):
+#pragma unroll                             // x * 1.0f == x, so skipping the rescale changes no bit
             for (int t = 0; t < DT; ++t)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[t][e] *= alpha;
-            // P planes of key block kb: the lane's s[8 kb .. 8 kb + 7] (keys 16 kb + 4 half + {0..3, 8..11}: the permuted order
-            // in which stage() laid out V^T)
+        }
+        // P planes of key block kb: the lane's s[8 kb .. 8 kb + 7] (keys 16 kb + 4 half + {0..3, 8..11}: the permuted order
+        // in which stage() laid out V^T)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const af32x4 lo = {s[8 * kb], s[8 * kb + 1], s[8 * kb + 2], s[8 * kb + 3]};
-                const af32x4 hi = {s[8 * kb + 4], s[8 * kb + 5], s[8 * kb + 6], s[8 * kb + 7]};
-                au32x4 pp[3];
-                attn_split3(lo, hi, pp[0], pp[1], pp[2]);
+        for (int kb = 0; kb < 2; ++kb) {
+            const af32x4 lo = {s[8 * kb], s[8 * kb + 1], s[8 * kb + 2], s[8 * kb + 3]};
+            const af32x4 hi = {s[8 * kb + 4], s[8 * kb + 5], s[8 * kb + 6], s[8 * kb + 7]};
+            au32x4 pp[3];
+            attn_split3(lo, hi, pp[0], pp[1], pp[2]);
 #pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    const char* vrow = vp + (t * 32 + l31) * RSV + (2 * kb + half) * 16;
-                    au32x4 va[3];
+            for (int t = 0; t < DT; ++t) {
+                const char* vrow = vp + (t * 32 + l31) * RSV + (2 * kb + half) * 16;
+                au32x4 va[3];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) va[pl] = *reinterpret_cast<const au32x4*>(vrow + pl * VPL);
-                    attn_x6(o[t], va, pp);
-                }
+                for (int pl = 0; pl < 3; ++pl) va[pl] = *reinterpret_cast<const au32x4*>(vrow + pl * VPL);
+                attn_x6(o[t], va, pp);
             }
+        }
+    };
+
+    prefetch(0);
+    for (int kv0 = 0; kv0 < kl; kv0 += 32) {
+        stage();
+        __syncthreads();
+        if (kv0 + 32 < kl) prefetch(kv0 + 32);                          // block-uniform; in flight during the MFMAs
+        if (active) {
+            scores();
+            softmax_pv(kv0);
         }
         __syncthreads();               // every wave is done with this tile's planes before the next stage() overwrites them
     }

@@ -9,8 +9,8 @@ from megatts2_amd import runtime as rt
 rt.device_check()
 dev = torch.device("cuda")
 print("%-28s %10s %10s %10s %10s %10s   (us per launch; TF/s of the fastest)" % ("shape", "reg", "lds4", "lds8", "x6/4", "x6/8"))
-for name, B, H, D, ns in (("adm 8x96, 4 seq", 4, 8, 96, (64, 128, 256, 417, 834)), ("plm 16x64, 4 seq", 4, 16, 64, (64, 128, 323, 646)),
-                          ("adm 8x96, 16 seq", 16, 8, 96, (35, 70, 128)), ("plm 16x64, 16 seq", 16, 16, 64, (27, 54, 128))):
+for name, B, H, D, ns in (("adm 8x96, 4 seq", 4, 8, 96, (256, 417, 834)), ("plm 16x64, 4 seq", 4, 16, 64, (192, 323, 646)),
+                          ("adm 8x96, 16 seq", 16, 8, 96, (128, 256)), ("plm 16x64, 16 seq", 16, 16, 64, (128, 256))):
     for n in ns:
         d = H * D
         qkv = torch.randn(B * n, 3 * d, device=dev)
@@ -32,4 +32,4 @@ for name, B, H, D, ns in (("adm 8x96, 4 seq", 4, 8, 96, (64, 128, 256, 417, 834)
             torch.cuda.synchronize()
             row.append(e0.elapsed_time(e1) / 40 * 1e3)
         fl = 4.0 * n * n * d * B
-        print("%-18s n=%-6d %10.1f %10.1f %10.1f %10.1f %10.1f   %.1f" % (name, n, row[0], row[1], row[2], row[3], row[4], fl / min(row) / 1e6), flush=True)
+        print("%-18s n=%-6d %10.1f %10.1f %10.1f %10.1f %10.1f   %.1f" % ((name, n) + tuple(row) + (fl / min(row) / 1e6,)), flush=True)

@@ -13,7 +13,8 @@ greedy), VQ decode + concat, mel decoder, HiFi-GAN vocoder.  Durations are force
 count is exact (random weights predict arbitrary durations); nothing else is forced or
 skipped.  `--workload C2` = configs[1] (MRTE + ADM + decoder, prosody codes forced), C1 the single
 utterance, C5 the long prompt.  Weights are synthetic (no checkpoint ships with the reference), fp32
-throughout (`dtype: "f32"`: exact-f32 MFMA).
+storage and accumulation throughout (`dtype: "f32"`: products on the f32 MFMA or, f32-equivalent, as six bf16
+MFMAs of exactly split operands - DESIGN.md 4.2).
 
 N > 1: one process per GPU, utterances sharded by rank (weak scaling: 32 per GPU, C4 = 8 x 32), the
 only exchange is ONE fixed-capacity RCCL all-gather of the generated mels + lengths at the end of

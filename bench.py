@@ -449,10 +449,9 @@ def main() -> None:
         # engine throughput against the time of the TIMED steps (the engine is busy for at most the whole step)
         achieved = alg_gemm / (ms_per_step * 1e-3) / 1e12
         pm = None
-        pmc_path = os.path.join(ROOT, "profiles", f"r03_pmc_{args.workload.lower()}_latest.json")
-        if not os.path.exists(pmc_path):
-            pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload.lower()}_latest.json")
-        if os.path.exists(pmc_path):
+        pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r_:02d}_pmc_{args.workload.lower()}_latest.json")
+                                     for r_ in (4, 3, 2)) if os.path.exists(q)), None)     # the newest committed PMC summary
+        if pmc_path:
             pm = json.load(open(pmc_path))
         per_stage = {}
         for s in stages:
@@ -481,8 +480,8 @@ def main() -> None:
         result["roofline"] = {
             "bound": "mfma",
             "kernel": "gemm_x6_ldr_kernel / conv_win_x6_kernel (implicit-GEMM conv/linear engine on the bf16 matrix pipe, "
-                      "f32-equivalent, loader waves; gemm_x6_ks_kernel for the AR steps' K-split tiles) + gemm_skinny_f32_kernel / "
-                      "gemm_f32_dma_kernel (f32 MFMA) for launches of a handful of rows",
+                      "f32-equivalent, loader waves; gemm_x6_ks_kernel for the AR steps' K-split tiles) + gemm_skinny_tm_kernel "
+                      "(f32 MFMA 16x16x4 on tile-major weights, LayerNorm prologue) for launches of at most 64 rows",
             "achieved": round(achieved, 2), "peak": round(X6_EQUIV_PEAK_TFLOPS, 1), "unit": "TFLOP/s",
             "frac": round(achieved / X6_EQUIV_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_detail": traffic_detail,
             "method": "achieved = algorithmic GEMM FLOPs of the step (SURVEY 8d, reference semantics, f32 multiply-adds) / "
@@ -491,7 +490,7 @@ def main() -> None:
                       "416.7 TF/s of f32-equivalent work; the f32 MFMA pipe itself peaks at 157.3 TF/s (frac_of_f32_mfma_peak, "
                       "the basis of round 1's 0.45)",
             "frac_of_f32_mfma_peak": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-            "arithmetic": {"f32_mfma": "v_mfma_f32_32x32x2_f32 (exact f32 fma chain): launches of at most 64 rows (gemm_skinny_f32_kernel), shapes without weight planes",
+            "arithmetic": {"f32_mfma": "v_mfma_f32_16x16x4_f32 / 32x32x2_f32 (exact f32 fma chain): launches of at most 64 rows (gemm_skinny_tm_kernel), shapes without weight planes",
                            "x6": "f32-EQUIVALENT on the bf16 pipe: operands split exactly into 3 bf16 planes, 6 exact products, f32 "
                                  "accumulation (error vs float64 not above the f32-MFMA kernel's: tests/test_gpu_kernels.py::*x6*); "
                                  "configurations named x6*: conv stacks, vocoder, large AR GEMMs",

@@ -374,6 +374,28 @@ def test_gemm_skinny_tile_major_weights_and_layernorm_prologue(rt, M, N, K, a_mu
         assert rel(y, ref) <= 2.0 * rel(f32, ref) + 1e-7
 
 
+def test_skinny_prologues_treat_non_finite_inputs_like_the_tiled_engine(rt):
+    """the <= 64-row kernels' branch-free prologue once computed `v * 0` for ReLU (-inf -> NaN) where the tiled
+    engine's fmaxf(v, 0) gives 0.  Rows carrying -inf / +inf / NaN through ReLU and leaky ReLU: the row-major kernel (87), the
+    tile-major kernel and the tiled f32 engine (22) agree on which outputs are finite, and on their values."""
+    rng = np.random.default_rng(3)
+    M, N, K = 8, 64, 128
+    X = rng.standard_normal((M, K)).astype(np.float32)
+    X[1, 5], X[2, 7], X[3, 9] = -np.inf, np.inf, np.nan
+    W = (np.abs(rng.standard_normal((N, K))) / 16 + 0.01).astype(np.float32)          # positive weights: inf rows stay +inf, no inf - inf
+    Wt = rt.op_tile_major(dev(W))
+    for act, slope in ((rt.ACT_RELU, 0.0), (rt.ACT_LRELU, 0.1)):
+        tiled = rt.op_gemm(dev(X), dev(W), force_cfg=22, pro_act=act, pro_slope=slope).cpu().numpy()
+        rowm = rt.op_gemm(dev(X), dev(W), force_cfg=87, pro_act=act, pro_slope=slope).cpu().numpy()
+        tm = rt.op_gemm_tm(dev(X), Wt, K, N, K, pro_act=act, pro_slope=slope).cpu().numpy()
+        assert np.isfinite(tiled[0]).all() and np.isfinite(tiled[4:]).all()
+        assert np.isfinite(tiled[1]).all() == (act == rt.ACT_RELU)                   # ReLU(-inf) = 0; leaky: -inf * 0.1 = -inf
+        for got in (rowm, tm):
+            assert np.array_equal(np.isfinite(got), np.isfinite(tiled)) and np.array_equal(np.isnan(got), np.isnan(tiled))
+            fin = np.isfinite(tiled)
+            assert np.allclose(got[fin], tiled[fin], rtol=1e-5, atol=1e-6)
+
+
 def test_gemm_skinny_tile_major_sub_matrices_and_split_k_groups(rt):
     """The tile-major kernel addresses SUB-matrices of a whole matrix by block coordinates: the K | V rows of a [3d, d] QKV
     matrix (row offset), a K range (column offset) and split-K groups (slab g = columns [g K/S, (g+1) K/S) of both operands,

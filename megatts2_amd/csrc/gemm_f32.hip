@@ -411,6 +411,16 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned byte_addr) {
     return v;
 }
 
+// issue priority of a LOADER wave (GemmP::ldr_prio, 0..3; the immediate of s_setprio must be a constant).  Round 4
+// (tools/x6_prio.py, profiles/r04_x6_setprio.txt): a loader's few instructions per chunk - address update, LDS-DMA issue,
+// counted wait, barrier - compete for issue slots with two compute waves' MFMA / VALU streams on the same SIMD; at priority 3
+// the refill of a freed ring stage starts sooner: the AR shapes on the 128x128 loader tile -3.6 ... -5.5 % per launch.
+__device__ __forceinline__ void loader_priority(int prio) {
+    if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field on gfx9");
     __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));   // expcnt/lgkmcnt: no wait
@@ -1057,6 +1067,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x6_kernel(Gemm
     };
     const int nk_l = Kt / 32;
     if (NL > 0 && loader) {        // ---- loader wave: window pieces above, then nothing but the ring
+        loader_priority(p.ldr_prio);
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < nk_l) issue(st, st);
@@ -1653,6 +1664,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
 
     if (wave_all >= NW) {
         // ------------------------------------------------------------------ loader wave lw: pieces lw, lw + NL, ...
+        loader_priority(p.ldr_prio);
         const int lw = wave_all - NW;
         const float* __restrict__ X = p.X + (long long)g * p.strideX;
         const unsigned short* __restrict__ W3 = reinterpret_cast<const unsigned short*>(p.W3) + (long long)g * p.strideW;
@@ -2061,6 +2073,9 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
             MT2_T(5);                               // MFMA steps of the previous chunk
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+#if defined(MT2_SETPRIO_HEAD)                // measurement builds: issue priority of a compute wave in the head of a chunk
+            __builtin_amdgcn_s_setprio(MT2_SETPRIO_HEAD);      // (fetch + first split) and in its product phase
+#endif
             MT2_T(1);                               // barrier (loaders' landing wait included)
             fetch(0, sa, sb);
             __builtin_amdgcn_sched_barrier(0);
@@ -2070,6 +2085,9 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
             fetch(1, sa, sb);
             split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
             __builtin_amdgcn_sched_barrier(0);
+#if defined(MT2_SETPRIO_HEAD)
+            __builtin_amdgcn_s_setprio(MT2_SETPRIO_BODY);
+#endif
             MT2_T(4);                               // second fetch + first split
         } else {
             fetch(1, sa, sb);
@@ -2194,6 +2212,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x6_ks_kernel(
 
     if (wave_all >= NWC) {
         // ------------------------------------------------------------------ loader wave lw: pieces lw, lw + NL, ... of a round
+        loader_priority(p.ldr_prio);
         const int lw = wave_all - NWC;
         const char* __restrict__ Xb = reinterpret_cast<const char*>(p.X + (long long)g * p.strideX);
         const char* __restrict__ Wb = reinterpret_cast<const char*>(reinterpret_cast<const unsigned short*>(p.W3) + (long long)g * p.strideW);
@@ -2804,6 +2823,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     const int tiles = ((p.M + c->bm - 1) / c->bm) * ((p.N + c->bn - 1) / c->bn);
     p.w_nt = (o.nt_weights && (p.M + c->bm - 1) / c->bm <= o.nt_row_tiles) ? 1 : 0;
     p.epi_t4 = o.epi_t4 ? 1 : 0;
+    p.ldr_prio = o.ldr_prio;
     dim3 grid(tiles, 1, p.groups), block(c->threads);
     if (opts) opts->last_cfg = c->name;
     if (opts && opts->trace_on) {

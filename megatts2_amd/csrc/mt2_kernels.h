@@ -32,6 +32,7 @@ struct GemmP {
     unsigned long long* dbg = nullptr;   // MT2_PHASE_TIMING builds only: per-phase cycle sums of one wave (tools/x6_phase_timing.py)
     int w_nt = 0;               // weight loads with the non-temporal cache policy (set by launch_gemm: weights streamed ~once per launch)
     int epi_t4 = 1;             // 16-byte-store epilogue where the layout allows it (set by launch_gemm from EngineOpts::epi_t4)
+    int ldr_prio = 0;           // s_setprio of the loader waves of the loader-wave kernels (set by launch_gemm from EngineOpts::ldr_prio)
     const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like
     long long w3_plane = 0;     // W (same ldw / strideW, in bf16 elements), planes w3_plane elements apart (0: N * ldw) -
                                 // lets launch_gemm run on the bf16 matrix pipe in the f32-equivalent 6-product form
@@ -79,6 +80,7 @@ struct EngineOpts {
                                  // (profiles/r03_gemm_sweep_x6k.txt), C3 step -1.6 % (profiles/r03_ab_interleaved_v1.txt)
     int t_x6_ks_over128 = 0;     // with x6_ks: up to this many 64x64 tiles the K-split x6 tile replaces the 128x128 loader tile
     bool epi_t4 = true;          // DPP-transposed 16-byte-store epilogue for wave tiles without epilogue prefetch
+    int ldr_prio = 3;            // issue priority (s_setprio 0..3) of the loader waves (gemm_x6_ldr / gemm_x6_ks / conv_win_x6 kernels)
     bool x6_mp256 = false;       // MP form (config 68) wherever the 256x128 loader tile (51) would run
     int x6_mp = 0;               // 1: MP form (gemm_x6_ldr_kernel<..., MP>) of the 128x128 and small loader tiles, 2: of 256x128 too
     int skinny_rows = 64;        // linear layers with at most this many rows (<= 64) run on the weight-streaming kernel of

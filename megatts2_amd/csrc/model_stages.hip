@@ -406,7 +406,21 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
     float* kv = s.qkv;                                   // [M, 2d]: K | V
     float* q = s.att;                                    // [A, d]
     float* att = s.att + (size_t)A * d;                  // [A, d]
-    if (in.S) {
+    AttnP a{};
+    if (c.m.opts.skinny_tm && M <= c.m.opts.skinny_rows && M <= 64 && c.m.opts.force_cfg < 0) {
+        // a handful of rows (one utterance's steps): Q | K | V of ALL rows in ONE weight-streaming launch - the Q rows that
+        // are not the last of their sequence cost nothing measurable at M <= 64, a second launch costs ~8 us
+        float* qkv = s.qkv;                              // [M, 3d]
+        if (in.S) {
+            ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
+            linear(c, s.h, d, M, w.wqkv, w.bqkv, 3 * d, d, qkv, 3 * d);
+        } else {
+            ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d), 3 * d, d, qkv, 3 * d, s.h);
+        }
+        a.Q = qkv + (size_t)(n - 1) * 3 * d; a.ldq = 3 * d; a.u_qstride = n;      // query of sequence j = row j * n + n - 1
+        a.K = qkv + d; a.ldk = 3 * d; a.V = qkv + 2 * d; a.ldv = 3 * d;
+        a.u_ostride = 1;
+    } else if (in.S) {
         ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
         linear(c, s.h, d, M, w.wqkv + (size_t)d * d, w.bqkv + d, 2 * d, d, kv, 2 * d);
         GemmP p{};
@@ -417,9 +431,12 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
         ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d, d), 2 * d, d, kv, 2 * d, s.h);
         ln_linear(c, x, d, M, n, n - 1, A, ln1_qkv(w, d), d, d, q, d, s.f);
     }
-    AttnP a{};
-    a.Q = q; a.ldq = d; a.K = kv; a.ldk = 2 * d; a.V = kv + d; a.ldv = 2 * d; a.O = att; a.ldo = d;
-    a.u_qstride = 1; a.u_qlen = 1; a.u_kvstride = n; a.u_kvlen = n; a.B = A; a.H = e.heads; a.D = D; a.max_qlen = 1;
+    if (!a.Q) {
+        a.Q = q; a.ldq = d; a.K = kv; a.ldk = 2 * d; a.V = kv + d; a.ldv = 2 * d;
+        a.u_qstride = 1;
+    }
+    a.O = att; a.ldo = d;
+    a.u_qlen = 1; a.u_kvstride = n; a.u_kvlen = n; a.B = A; a.H = e.heads; a.D = D; a.max_qlen = 1;
     a.scale = 1.0f / std::sqrt((float)D);
     a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves; a.x6_min_qlen = c.m.opts.attn_x6_min;
     MT2_HIP(launch_attention(a, c.s));

@@ -229,7 +229,9 @@ int mt2_synthesize_prompt_conditioned(mt2_model* m, void* stream, const int64_t*
  * the implicit-GEMM launches with enough big tiles), "x6_splitk" (1), "t_x6_256" (160), "t_x6_128" (72), "t_x6_64" (0: tile-count thresholds of
  * the two x6 tile shapes), "nt_weights" (0) / "nt_row_tiles" (2: non-temporal weight loads for launches with at most that many
  * row tiles), "win_conv" (1), "stage_markers" (0), "force_gemm_config" (-1), "lnalg_rows" (4),
- * "t_ks4", "t_ks2", "t32", "t32x32" (tile-choice thresholds).  Unknown names are an error. */
+ * "t_ks4", "t_ks2", "t32", "t32x32" (tile-choice thresholds); round 4: "skinny_tm" (1: launches of at most "skinny_rows" = 64 rows on the
+ * tile-major weight-streaming kernel incl. its LayerNorm prologue), "ldr_prio" (3: s_setprio of the loader waves), "adm_groups" /
+ * "plm_groups" (0: per-stage override of "ar_groups").  Unknown names are an error. */
 int mt2_set_option(mt2_model* m, const char* name, int value);
 int mt2_get_option(mt2_model* m, const char* name, int* value);
 int mt2_set_ar_groups(mt2_model* m, int groups);

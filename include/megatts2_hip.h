@@ -281,11 +281,12 @@ int mt2_op_attention(void* stream, const float* Q, int ldq, const float* K, int 
                      const int32_t* kv_len, int B, int H, int D, int max_qlen, float scale);
 /* ... with the kernel choice exposed: lds_min_qlen = first query count served by the LDS-tiled kernel (0 never, < 0 default),
  * lds_waves = its query tiles per workgroup (8, otherwise 4); x6_min_qlen = first query count served by the bf16-pipe
- * kernel (f32-equivalent six-product form, head dims 64 / 96; 0 never, < 0 default). */
+ * kernel (f32-equivalent six-product form, head dims 64 / 96; 0 never, < 0 default); lds_waves + 32: the register kernel instead of the
+ * head-dim-split kernel that serves D = 64 / 96 with at most 128 keys; max_kvlen: longest key range of the launch (0 = unknown). */
 int mt2_op_attention_tuned(void* stream, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                            float* O, int ldo, const int32_t* q_start, const int32_t* q_len, const int32_t* kv_start,
                            const int32_t* kv_len, int B, int H, int D, int max_qlen, float scale, int lds_min_qlen,
-                           int lds_waves, int x6_min_qlen);
+                           int lds_waves, int x6_min_qlen, int max_kvlen);
 /* Launch trace of the GEMM/conv engine (measurement only): between begin and end every launch is
  * bracketed by HIP events on its own stream.  end() reports, per tile configuration, the number of
  * launches, the executed FLOPs (2*M*N*K*groups) and the summed kernel time in ms, plus a last entry named

@@ -269,6 +269,148 @@ __global__ __launch_bounds__(256) void attn_f32_reg_kernel(AttnP p) {
         }
 }
 
+// Short sequences on the AR heads (D = 64 / 96, at most 128 keys: every step of C1 - C3), round 4: the head dim is SPLIT over
+// the waves as well.  In the register kernel above a wave multiplies its key tile against the whole head dim: D/2 + D/2
+// v_mfma_f32_32x32x2_f32 of 64 cycles - 2.0 / 3.1 us of matrix time per launch, most of a 6.4 / 7.9-us launch that is
+// otherwise one memory round trip (profiles/r04_c1_kernel_stats_tm16.csv: attention = 27 % of the one-utterance path).  Here a
+// workgroup = (key tiles) x (D / 32 slices of 32 channels) waves: wave (kt, ds) computes the partial S^T of its tile over
+// its 32 channels (16 MFMAs), the D/32 partials of a tile meet in LDS and are summed in slice order by each of the tile's
+// waves, which then runs the tile's softmax (redundantly: it is 32 x 32) and P V for ITS 32 output channels (16 MFMAs); the
+// tiles' (m, l, O-slice) states are merged by the waves of tile 0 with the log-sum-exp rescale, in tile order.  32 MFMAs per
+// wave instead of 64 / 96.  f32 throughout, fixed summation order (slices ascending, keys ascending, tiles ascending).
+template <int D>
+__global__ __launch_bounds__(768) void attn_f32_ds_kernel(AttnP p) {
+    constexpr int NS = D / 32;
+    extern __shared__ __attribute__((aligned(16))) float amem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nkv = (blockDim.x >> 6) / NS;
+    const int kt = wave / NS, ds = wave - kt * NS;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y, qt = blockIdx.x;
+    int qs, ql, ks, kl;
+    if (p.q_start) {
+        qs = p.q_start[b]; ql = p.q_len[b]; ks = p.kv_start[b]; kl = p.kv_len[b];
+    } else {
+        qs = b * p.u_qstride; ql = p.u_qlen; ks = b * p.u_kvstride; kl = p.u_kvlen;
+    }
+    if (qt * 32 >= ql || kl <= 0) return;          // block-uniform
+    const int os = p.o_start ? p.o_start[b] : (p.q_start ? qs : b * (p.u_ostride ? p.u_ostride : p.u_qstride));
+    const int qrow = qt * 32 + l31;
+    const bool qok = qrow < ql;
+    const int kv0 = kt * 32;
+    const bool tile_ok = kv0 < kl;                 // wave-uniform (a ragged launch is sized by its longest key range)
+    float* sp = amem;                              // [nkv * NS][16][64] partial scores
+    float* st = amem + nkv * NS * 16 * 64;         // [nkv * NS][18][64]: O^T slice (16), m, l
+
+    f32x16 sc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sc[e] = 0.0f;
+    float vr[16];
+    if (tile_ok) {
+        // every load of this wave goes out before its first MFMA: Q and K fragments of its 32 channels, its V column
+        float4 qf[4], kf[4];
+        const float* __restrict__ qptr = p.Q + (long long)(qs + (qok ? qrow : qt * 32)) * p.ldq + h * D + ds * 32 + 4 * half;
+        const int kvrow = kv0 + l31;
+        const float* __restrict__ kptr = p.K + (long long)(ks + (kvrow < kl ? kvrow : kv0)) * p.ldk + h * D + ds * 32 + 4 * half;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            qf[f] = *reinterpret_cast<const float4*>(qptr + 8 * f);
+            kf[f] = *reinterpret_cast<const float4*>(kptr + 8 * f);
+        }
+        const float* __restrict__ vcol = p.V + h * D + ds * 32 + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            vr[e] = kvr < kl ? vcol[(long long)(ks + kvr) * p.ldv] : 0.0f;
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].x, qf[f].x, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].y, qf[f].y, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].z, qf[f].z, sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[f].w, qf[f].w, sc, 0, 0, 0);
+        }
+    }
+    {
+        float* mine = sp + (size_t)wave * 16 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mine[e * 64] = sc[e];
+    }
+    __syncthreads();
+    float m_run = -INFINITY, l_run = 0.0f;
+    f32x16 o;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = 0.0f;
+    if (tile_ok) {
+        // the tile's scores: its NS partials in slice order; sc[e] = S^T[kv0 + (e&3) + 8*(e>>2) + 4*half][q = l31]
+        const float* part = sp + (size_t)(kt * NS) * 16 * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float v = part[e * 64];
+#pragma unroll
+            for (int x = 1; x < NS; ++x) v += part[(x * 16 + e) * 64];
+            const int kvr = kv0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            sc[e] = kvr < kl ? v * p.scale : -INFINITY;
+            m_run = fmaxf(m_run, sc[e]);
+        }
+        m_run = fmaxf(m_run, __shfl_xor(m_run, 32));      // finite: key kv0 is in range
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            sc[e] = expf(sc[e] - m_run);
+            l_run += sc[e];
+        }
+        l_run += __shfl_xor(l_run, 32);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[e], sc[e], o, 0, 0, 0);
+    }
+    if (nkv > 1) {                                  // block-uniform
+        if (kt > 0) {
+            float* mine = st + (size_t)wave * 18 * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mine[e * 64] = o[e];
+            mine[16 * 64] = m_run;
+            mine[17 * 64] = l_run;
+        }
+        __syncthreads();
+        if (kt > 0) return;
+        for (int t = 1; t < nkv; ++t) {             // tile 0 always holds key 0: m_run is finite
+            const float* oth = st + (size_t)(t * NS + ds) * 18 * 64 + lane;
+            const float m_o = oth[16 * 64], l_o = oth[17 * 64];
+            const float m_new = fmaxf(m_run, m_o);
+            const float a0 = expf(m_run - m_new), a1 = expf(m_o - m_new);       // exp(-inf) = 0 for an empty tile
+            l_run = l_run * a0 + l_o * a1;
+            m_run = m_new;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] = o[e] * a0 + oth[e * 64] * a1;
+        }
+    }
+    if (!qok) return;
+    const float inv = 1.0f / l_run;
+    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo + h * D + ds * 32 + 4 * half;
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+        float4 v;
+        v.x = o[4 * e4 + 0] * inv;
+        v.y = o[4 * e4 + 1] * inv;
+        v.z = o[4 * e4 + 2] * inv;
+        v.w = o[4 * e4 + 3] * inv;
+        *reinterpret_cast<float4*>(orow + 8 * e4) = v;
+    }
+}
+template <int D>
+static hipError_t launch_attn_ds(const AttnP& p, int nkv, hipStream_t s) {
+    static bool attr_done = false;
+    constexpr int NS = D / 32;
+    const size_t lds = (size_t)nkv * NS * (16 + 18) * 64 * sizeof(float);
+    if (!attr_done) {       // up to 4 x 3 waves: 102 KiB
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_ds_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((size_t)4 * NS * (16 + 18) * 64 * sizeof(float)));
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(attn_f32_ds_kernel<D>, dim3((p.max_qlen + 31) / 32, p.H, p.B), dim3(64 * nkv * NS), lds, s, p);
+    return hipGetLastError();
+}
+
 // Very long sequences (default: >= 640 queries, AttnP::lds_min_qlen): the LDS-tiled form.  The register kernel above gives every 32-query tile its own
 // workgroup and lets each of its waves fetch "its" K / V tiles from memory - right for the <= 3 key tiles of a 70-position
 // step (one round trip per launch), wrong for 834 positions: 27 query tiles re-read the whole K / V of the head, a wave
@@ -720,6 +862,11 @@ hipError_t launch_attention(const AttnP& p, hipStream_t s) {
         // split-KV width: the longest key range of the launch (uniform geometry knows it exactly; ragged
         // launches pass max_kvlen, 0 = unknown -> assume as long as the queries)
         int kvmax = p.q_start ? (p.max_kvlen > 0 ? p.max_kvlen : p.max_qlen) : p.u_kvlen;
+        if (p.ds_short && (p.D == 64 || p.D == 96) && kvmax <= 128 && (!p.q_start || p.max_kvlen > 0)) {      // kvmax must be a true bound
+            // the AR steps' short sequences: key tiles x head-dim slices (attn_f32_ds_kernel)
+            const int nkv = (kvmax + 31) / 32;
+            return p.D == 64 ? launch_attn_ds<64>(p, nkv < 1 ? 1 : nkv, s) : launch_attn_ds<96>(p, nkv < 1 ? 1 : nkv, s);
+        }
         int nwv = (kvmax + 31) / 32;
         nwv = nwv < 1 ? 1 : (nwv > 4 ? 4 : nwv);
         const int DT = p.D / 32;

@@ -88,6 +88,7 @@ struct EngineOpts {
     int attn_x6_min = 192;       // attention on the bf16 pipe (f32-equivalent, AttnP::x6_min_qlen) from this many queries on; 0: never
                                  // (C5 step 5525 -> 5314 ms at 192, 5376 at 448: profiles/r03_opts_ab.txt)
     int attn_lds_waves = 0;      // ... its query tiles per workgroup (AttnP::lds_waves)
+    int attn_ds = 1;             // short sequences on the AR heads: head dim split over the waves as well (AttnP::ds_short)
     bool skinny_tm = true;       // ... on the tile-major weight copy where one exists (gemm_skinny_tm_kernel; LayerNorm prologue included)
     int skinny_groups = 1;       // ... only for launches with at least this many GemmP groups (split-K slabs)
     int skinny_nt = 0;           // gemm_skinny.hip (0: off); skinny_nt: non-temporal weight loads (measured: C1 65.2 ms with, 56.8 without)
@@ -157,6 +158,7 @@ struct AttnP {
                               // tiles of a workgroup (attn_f32_lds_kernel); 0: never
     int x6_min_qlen = 0;      // from this many queries on (D = 64 / 96) the f32-equivalent bf16-pipe kernel (attn_x6_kernel); 0: never
     int lds_waves = 0;        // query tiles per workgroup of that kernel: 8, otherwise 4
+    int ds_short = 1;         // D = 64 / 96 and at most 128 keys: key tiles x head-dim slices per workgroup (attn_f32_ds_kernel)
 };
 hipError_t launch_attention(const AttnP& p, hipStream_t s);
 

@@ -683,7 +683,8 @@ def op_attention(Q, K, V, q_start, q_len, kv_start, kv_len, H, D, scale, lds_min
     B = q_start.shape[0]
     _check(lib.mt2_op_attention_tuned(_stream(), _ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(V), V.stride(0), _ptr(O),
                                       O.stride(0), _ptr(q_start), _ptr(q_len), _ptr(kv_start), _ptr(kv_len), B, H, D,
-                                      int(q_len.max().item()), C.c_float(scale), lds_min_qlen, lds_waves, x6_min_qlen))
+                                      int(q_len.max().item()), C.c_float(scale), lds_min_qlen, lds_waves, x6_min_qlen,
+                                      int(kv_len.max().item())))
     return O
 
 

@@ -620,6 +620,40 @@ def test_attention_long_sequences_lds_tiled(rt, H, D, waves):
     assert not out[:3].any() and not out[qs[-1] + qlens[-1]:].any()
 
 
+@pytest.mark.parametrize("H,D", [(16, 64), (8, 96)])
+def test_attention_short_sequences_head_dim_split(rt, H, D):
+    """Round 4: attn_f32_ds_kernel - D = 64 / 96 with at most 128 keys (every AR step of C1 - C3): a workgroup = key tiles x 32-channel
+    slices of the head dim, partial scores summed through LDS, tile states merged by log-sum-exp.  Ragged batch around every tile
+    boundary (1, 31, 32, 33, 64, 65, 96, 128 keys; launches sized by the longest range, so short utterances have EMPTY tiles), a
+    late score spike (merge with a larger maximum), queries in two tiles - against float64 and against the register kernel."""
+    rng = np.random.default_rng(H + D)
+    qlens = [1, 33, 32, 64, 5, 40, 17, 64]
+    kvlens = [1, 31, 32, 33, 64, 65, 96, 128]
+    d = H * D
+    qs = np.cumsum([0] + qlens[:-1]).astype(np.int32) + 3
+    ks = np.cumsum([0] + kvlens[:-1]).astype(np.int32) + 5
+    Q = rng.standard_normal((qs[-1] + qlens[-1] + 2, d)).astype(np.float32)
+    KV = rng.standard_normal((ks[-1] + kvlens[-1] + 2, 2 * d)).astype(np.float32)
+    KV[ks[7] + 100, :D] = Q[qs[7] + 5, :D] * 4.0            # spike in the 4th key tile of the last utterance, head 0
+    kv = dev(KV)
+    args = (dev(Q), kv[:, :d], kv[:, d:], dev(qs), dev(np.asarray(qlens, np.int32)), dev(ks), dev(np.asarray(kvlens, np.int32)), H, D,
+            1.0 / math.sqrt(D))
+    out = rt.op_attention(*args).cpu().numpy()
+    reg = rt.op_attention(*args, lds_waves=32).cpu().numpy()                      # + 32: the register kernel
+    for b in range(len(qlens)):
+        q = Q[qs[b]:qs[b] + qlens[b]].astype(np.float64)
+        k = KV[ks[b]:ks[b] + kvlens[b], :d].astype(np.float64)
+        v = KV[ks[b]:ks[b] + kvlens[b], d:].astype(np.float64)
+        for h in range(H):
+            sl = slice(h * D, (h + 1) * D)
+            sc = q[:, sl] @ k[:, sl].T / math.sqrt(D)
+            pr = np.exp(sc - sc.max(1, keepdims=True))
+            ref = (pr / pr.sum(1, keepdims=True)) @ v[:, sl]
+            assert rel(out[qs[b]:qs[b] + qlens[b], sl], ref) < 3e-6, (b, h)
+            assert rel(out[qs[b]:qs[b] + qlens[b], sl], ref) <= 2.0 * rel(reg[qs[b]:qs[b] + qlens[b], sl], ref) + 1e-7, (b, h)
+    assert not out[:3].any() and not out[qs[-1] + qlens[-1]:].any()
+
+
 def test_attention_forces_online_softmax_rescale(rt):
     """A key tile whose scores dwarf the previous tiles' maximum exercises the rescale branch."""
     rng = np.random.default_rng(9)

@@ -233,14 +233,16 @@ def main() -> None:
 
     from megatts2_amd import config as C
     from megatts2_amd import synth, weights
-    from megatts2_amd.dist import gather_mels, shard_imbalance, utterance_cost
+    from megatts2_amd.dist import MelExchange, gather_mels, shard_imbalance, utterance_cost
 
     g, p, a, h = C.production_g(), C.production_plm(), C.production_adm(), C.production_hifigan()
     full = args.workload in ("C1", "C3", "C5")     # C1 = infer.py's single utterance: the whole path incl. PLM + vocoder
     if dry:
         class _StandIn:                                                  # shapes only; never used for a measurement
-            def synthesize_batch(self, phone, pl, mel_in, ml, forced_dur=None, tm_cap=None, **_):
+            def synthesize_batch(self, phone, pl, mel_in, ml, forced_dur=None, tm_cap=None, mel_out=None, **_):
                 lens = forced_dur.sum(axis=1).astype(np.int32)
+                if mel_out is not None:       # in place, like the native call: zero-fill the caller's block
+                    return mel_out.zero_(), lens
                 return torch.zeros(phone.shape[0], tm_cap, g.mrte.mel_bins), lens
 
             def vqpe_forward(self, mel, lens=None):
@@ -311,14 +313,17 @@ def main() -> None:
     ev = None if dry else [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 
     lanes = None if dry or args.inflight <= 1 else [torch.cuda.Stream() for _ in models]
+    # N > 1: the exchange buffers are allocated ONCE; the synthesis call writes its mels straight into the send block
+    # (Tm_cap stride), so the timed multi-GPU step has no allocation, memset or copy in front of the collective
+    exchange = MelExchange(b_cap, shape.Tm, g.mrte.mel_bins, dev, world) if world > 1 else None
 
-    def step(time_vqpe=False, exchange=True, i=0):
+    def step(time_vqpe=False, do_exchange=True, i=0):
         if lanes is not None:         # batch i on handle / stream i % N; joined by the synchronisation that ends the timed region
             with torch.cuda.stream(lanes[i % len(lanes)]):
-                return step_on(models[i % len(models)], time_vqpe, exchange)
-        return step_on(model, time_vqpe, exchange)
+                return step_on(models[i % len(models)], time_vqpe, do_exchange)
+        return step_on(model, time_vqpe, do_exchange)
 
-    def step_on(model, time_vqpe=False, exchange=True):
+    def step_on(model, time_vqpe=False, do_exchange=True):
         # configs[2] "full VQ-PE -> ...": VQProsodyEncoder.forward (conv stacks + codebook L2-argmin) on the 431-frame
         # prompt mel - the prosody codes a prompt-conditioned PLM / stage-2 extraction consume.  Same work either way:
         # "overlap" runs it inside the synthesis call on an internal stream beside the ADM, "separate" in front.
@@ -329,11 +334,12 @@ def main() -> None:
             model.vqpe_forward(mel_in, ml)
             if time_vqpe:
                 ev[1].record()
+        into = exchange.mel_view(B) if (exchange is not None and do_exchange and B) else None
         out = model.synthesize_batch(phone, pl, mel_in, ml, forced_dur=dur, forced_codes=codes, run_plm=full,
-                                     vocoder=full, tm_cap=shape.Tm, skip_adm=args.skip_adm, prompt_vqpe=side)
+                                     vocoder=full, tm_cap=shape.Tm, skip_adm=args.skip_adm, prompt_vqpe=side, mel_out=into)
         mel, lens = out[0], out[1]
-        if world > 1 and exchange:   # the path's only exchange: ONE fixed-capacity RCCL all-gather over xGMI, lengths stay on the device
-            mel, lens = gather_mels(mel, lens, b_cap=b_cap, t_cap=shape.Tm, host_lens=False)
+        if world > 1 and do_exchange:   # the path's only exchange: ONE fixed-capacity RCCL all-gather over xGMI, lengths stay on the device
+            mel, lens = gather_mels(mel, lens, host_lens=False, exchange=exchange)
         return mel, lens
 
     if args.ab and not dry and world == 1:
@@ -423,7 +429,7 @@ def main() -> None:
         # (1) one PROFILED step (events at the stage boundaries only - no per-launch instrumentation)
         # (rank 0 only: these extra steps must not enter the collective the other ranks have already left)
         model.set_profiling(True)
-        step(time_vqpe=True, exchange=False)
+        step(time_vqpe=True, do_exchange=False)
         torch.cuda.synchronize()
         stage_ms = {k: v for k, v in model.last_stage_ms().items()}
         if full and args.vqpe == "separate" and args.workload != "C1":
@@ -435,7 +441,7 @@ def main() -> None:
         # (2) one TRACED step: HIP events around every GEMM/conv launch -> per tile configuration breakdown.  The
         # traced step is slower than the timed ones (10k event pairs); it only apportions, it is never the denominator.
         model.gemm_trace_begin()
-        step(exchange=False)
+        step(do_exchange=False)
         torch.cuda.synchronize()
         shapes = model.gemm_trace_shapes(14)
         tr = model.gemm_trace_end()

@@ -398,14 +398,13 @@ __global__ __launch_bounds__(768) void attn_f32_ds_kernel(AttnP p) {
 }
 template <int D>
 static hipError_t launch_attn_ds(const AttnP& p, int nkv, hipStream_t s) {
-    static bool attr_done = false;
+    static std::atomic<unsigned long long> attr_done{0};      // per device (dyn_lds_once)
     constexpr int NS = D / 32;
     const size_t lds = (size_t)nkv * NS * (16 + 18) * 64 * sizeof(float);
-    if (!attr_done) {       // up to 4 x 3 waves: 102 KiB
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_ds_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)((size_t)4 * NS * (16 + 18) * 64 * sizeof(float)));
+    {                       // up to 4 x 3 waves: 102 KiB
+        hipError_t e = dyn_lds_once(attr_done, reinterpret_cast<const void*>(attn_f32_ds_kernel<D>),
+                                    (size_t)4 * NS * (16 + 18) * 64 * sizeof(float));
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(attn_f32_ds_kernel<D>, dim3((p.max_qlen + 31) / 32, p.H, p.B), dim3(64 * nkv * NS), lds, s, p);
     return hipGetLastError();
@@ -557,13 +556,12 @@ __global__ __launch_bounds__(64 * NWQ) void attn_f32_lds_kernel(AttnP p) {
 
 template <int D, int NWQ>
 static hipError_t launch_attn_lds(const AttnP& p, hipStream_t s) {
-    static bool attr_done = false;
+    static std::atomic<unsigned long long> attr_done{0};      // per device (dyn_lds_once)
     void (*fn)(AttnP) = attn_f32_lds_kernel<D, NWQ>;
     const size_t lds = (size_t)4 * 32 * (D + 4) * sizeof(float);
-    if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) {
+        hipError_t e = dyn_lds_once(attr_done, reinterpret_cast<const void*>(fn), lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(fn, dim3((p.max_qlen + 32 * NWQ - 1) / (32 * NWQ), p.H, p.B), dim3(64 * NWQ), lds, s, p);
     return hipGetLastError();
@@ -827,13 +825,12 @@ __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) v
 
 template <int D, int NWQ>
 static hipError_t launch_attn_x6(const AttnP& p, hipStream_t s) {
-    static bool attr_done = false;
+    static std::atomic<unsigned long long> attr_done{0};      // per device (dyn_lds_once)
     void (*fn)(AttnP) = attn_x6_kernel<D, NWQ>;
     const size_t lds = (size_t)3 * 32 * (D * 2 + 16) + (size_t)3 * D * 80;
-    if (!attr_done && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) {
+        hipError_t e = dyn_lds_once(attr_done, reinterpret_cast<const void*>(fn), lds);
         if (e != hipSuccess) return e;
-        attr_done = true;
     }
     hipLaunchKernelGGL(fn, dim3((p.max_qlen + 32 * NWQ - 1) / (32 * NWQ), p.H, p.B), dim3(64 * NWQ), lds, s, p);
     return hipGetLastError();

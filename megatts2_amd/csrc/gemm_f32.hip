@@ -2593,9 +2593,9 @@ int gemm_trace_shapes(EngineOpts& o, char* buf, int cap, int top) {
 int gemm_num_configs() { return kNumCfgs; }
 const char* gemm_config_name(int idx) { return idx >= 0 && idx < kNumCfgs ? kCfgs[idx].name : ""; }
 
-// hipFuncSetAttribute is process-wide state of the code object: a "done" cache per (configuration, prologue) only
-// saves the call; the benign race (two threads both setting the same value) is harmless.
-static std::atomic<bool> g_attr_done[kNumCfgs][5];
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per-DEVICE state of the code object: a "done" mask per (configuration,
+// prologue) with one bit per device only saves the call; the benign race (two threads setting the same value) is harmless.
+static std::atomic<unsigned long long> g_attr_done[kNumCfgs][5];   // bit per device (dyn_lds_once)
 
 // ---- launch trace (measurement only): HIP events around every GEMM launch, on the launch stream; the records
 // live in the EngineOpts of whoever asked for the trace (the model handle).
@@ -2811,14 +2811,10 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     }
     void (*fn)(GemmP) = c->fn[p.pro_act];
     if (!fn) return hipErrorNotSupported;           // retired configuration / no variant for this prologue
-    if (!g_attr_done[idx][p.pro_act] || c->win_qs) {
+    {
         if (c->win_qs) lds_attr = c->lds + (size_t)c->win_qs * ((c->bm + 64 + 7) & ~7) * BK * sizeof(float);
-        if (!g_attr_done[idx][p.pro_act]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(c->win_qs ? lds_attr : lds));
-            if (e != hipSuccess) return e;
-            g_attr_done[idx][p.pro_act] = true;
-        }
+        hipError_t e = dyn_lds_once(g_attr_done[idx][p.pro_act], reinterpret_cast<const void*>(fn), c->win_qs ? lds_attr : lds);
+        if (e != hipSuccess) return e;
     }
     const int tiles = ((p.M + c->bm - 1) / c->bm) * ((p.N + c->bn - 1) / c->bn);
     p.w_nt = (o.nt_weights && (p.M + c->bm - 1) / c->bm <= o.nt_row_tiles) ? 1 : 0;

@@ -149,16 +149,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(GemmP p) {
 
 template <int RT, int NW, int U>
 hipError_t sk_launch(const GemmP& p, hipStream_t s) {
-    static bool attr_done = false;      // idempotent: a race only repeats the call
+    static std::atomic<unsigned long long> attr_done[2];      // per device and variant (dyn_lds_once; zero-initialised)
     void (*fn)(GemmP) = p.w_nt ? gemm_skinny_f32_kernel<RT, NW, U, true> : gemm_skinny_f32_kernel<RT, NW, U, false>;
     const size_t lds = NW > 1 ? (size_t)NW * RT * 16 * 64 * sizeof(float) : 0;
-    if (!attr_done && lds > 48 * 1024) {
-        for (int v = 0; v < 2; ++v) {
-            void (*f2)(GemmP) = v ? gemm_skinny_f32_kernel<RT, NW, U, true> : gemm_skinny_f32_kernel<RT, NW, U, false>;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(f2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-        }
-        attr_done = true;
+    if (lds > 48 * 1024) {
+        hipError_t e = dyn_lds_once(attr_done[p.w_nt ? 1 : 0], reinterpret_cast<const void*>(fn), lds);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(fn, dim3((p.N + 31) / 32, 1, p.groups), dim3(NW * 64), lds, s, p);
     return hipGetLastError();

@@ -145,8 +145,11 @@ static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, 
         q.pro_act = 3; q.ln_g = w.g; q.ln_b = w.b;
         attach_tm(c.m, q);
         if (q.Wtm && gemm_skinny_tm_eligible(q, c.m.opts.skinny_rows)) {
-            MT2_HIP(launch_gemm(q, c.s, &c.m.opts));
-            return;
+            // launch_gemm routes to the tile-major kernel only when its own conditions hold too (skinny_groups); with another
+            // routing the LayerNorm-prologue form may not exist for the tile it picks: fall through like the branches below
+            const hipError_t e = launch_gemm(q, c.s, &c.m.opts);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotSupported) MT2_HIP(e);
         }
     }
     if (c.m.opts.lnalg && w.Wl && K <= 1024) {

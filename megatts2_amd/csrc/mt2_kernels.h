@@ -10,9 +10,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <vector>
 
 namespace mt2 {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a launcher that needs more than the
+// default dynamic LDS sets it once per (kernel, device).  `done` is the launcher's own bit mask of devices already served
+// (device ordinal mod 64; a race between two host threads only repeats the idempotent call).
+inline hipError_t dyn_lds_once(std::atomic<unsigned long long>& done, const void* fn, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return e;
+    done.fetch_or(bit, std::memory_order_release);
+    return hipSuccess;
+}
 
 constexpr int kInvalidRow = -(1 << 30);   // rowbase sentinel: "this A row is all zeros"
 

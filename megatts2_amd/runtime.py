@@ -381,8 +381,10 @@ class NativeModel:
 
     def synthesize_batch(self, phone, phone_lens, prompt_mel, prompt_lens, forced_dur=None, forced_codes=None,
                          run_plm=True, vocoder=False, skip_adm=False, tm_cap: Optional[int] = None,
-                         return_aux=False, prompt_vqpe=False):
-        """Megatts.forward's no_grad block for a batch; returns (mel [B, Tm_cap, 80], mel_lens[, aux])."""
+                         return_aux=False, prompt_vqpe=False, mel_out=None):
+        """Megatts.forward's no_grad block for a batch; returns (mel [B, Tm_cap, 80], mel_lens[, aux]).
+        `mel_out`: a caller-owned contiguous f32 [B, tm_cap, mel_bins] device tensor the mels are written into (the native call
+        zero-fills it first) - e.g. `dist.MelExchange.mel_view(B)`, so that a multi-GPU step gathers without a copy."""
         import torch
         B, Np = phone.shape
         Tp = prompt_mel.shape[1]
@@ -407,7 +409,13 @@ class NativeModel:
                 fc[:, :n] = forced_codes[:, :n]
                 forced_codes = fc
         dev = prompt_mel.device
-        mel = torch.empty(B, tm_cap, self.g_cfg.mrte.mel_bins, device=dev, dtype=torch.float32)
+        if mel_out is not None:
+            if (tuple(mel_out.shape) != (B, tm_cap, self.g_cfg.mrte.mel_bins) or mel_out.dtype != torch.float32
+                    or not mel_out.is_contiguous() or mel_out.device != dev):
+                raise ValueError(f"mel_out must be a contiguous f32 [{B}, {tm_cap}, {self.g_cfg.mrte.mel_bins}] tensor on {dev}")
+            mel = mel_out
+        else:
+            mel = torch.empty(B, tm_cap, self.g_cfg.mrte.mel_bins, device=dev, dtype=torch.float32)
         mel_lens = np.zeros(B, np.int32)
         dur_out = torch.empty(B, Np, device=dev, dtype=torch.int32)
         codes_out = torch.empty(B, tq_cap, device=dev, dtype=torch.int64)

@@ -62,8 +62,9 @@ class SymbolTable:
         self._by_id: Dict[int, str] = {i: s for s, i in pairs}
         null_in_file = self._by_id.get(0)
         if null_in_file is None:                # the null symbol joins the table (and therefore the ranking)
-            if eps in self._by_sym:
-                raise SymbolTableError(f"symbol table: {eps!r} is listed with a non-zero id")
+            # a file that lists the null symbol with a NON-zero id and has no id 0 is accepted as the reference accepts it
+            # (utils/symbol_table.py:66-68): the symbol is re-mapped to 0, its old id keeps pointing at it, and the
+            # string-sorted ranking phone2token uses is unchanged
             self._by_sym[eps], self._by_id[0] = 0, eps
             null_in_file = eps
         self.eps = null_in_file

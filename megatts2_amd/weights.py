@@ -227,6 +227,23 @@ def synth_state_dict(inv, seed: int = 0, prefix: str = "") -> Dict[str, np.ndarr
     return sd
 
 
+def _benign_checkpoint_types():
+    """Value types a Lightning checkpoint commonly pickles outside its state_dict (hyper_parameters, callbacks, lr_schedulers):
+    plain data holders only - allow-listing them for the weights_only unpickler executes no code from the file."""
+    import argparse
+    import pathlib
+    types = [argparse.Namespace, pathlib.PosixPath, pathlib.PurePosixPath, np.dtype]
+    for mod, name in (("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                      ("lightning_fabric.utilities.data", "AttributeDict"), ("pytorch_lightning.utilities.parsing", "AttributeDict"),
+                      ("lightning.fabric.utilities.data", "AttributeDict")):
+        try:
+            types.append(getattr(__import__(mod, fromlist=[name]), name))
+        except Exception:      # not installed / renamed in this version: nothing to allow-list
+            pass
+    types += [type(np.dtype(t)) for t in ("float32", "float64", "int64", "int32", "bool")]
+    return list(dict.fromkeys(types))
+
+
 def load_lightning_state_dict(ckpt_path: str, prefix: str) -> Dict[str, np.ndarray]:
     """`torch.load(ckpt)['state_dict']`, keep keys under `prefix`, strip it
     (reference models/megatts2.py:111-116,192-197,287-291)."""
@@ -239,13 +256,24 @@ def load_lightning_state_dict(ckpt_path: str, prefix: str) -> Dict[str, np.ndarr
     # classes is refused unless the caller opts in (the same switch as the speechbrain loader below) - never unpickle
     # arbitrary objects from a path the caller, the CWD or an environment variable points at
     unsafe = os.environ.get("MEGATTS2_UNSAFE_PICKLE", "") == "1"
-    try:
-        raw = torch.load(ckpt_path, map_location="cpu", weights_only=not unsafe)
-    except Exception as e:       # pickle.UnpicklingError from the weights_only unpickler
-        if unsafe or "weights_only" not in str(e).lower() and "unsupported" not in str(e).lower():
-            raise
-        raise RuntimeError(f"{ckpt_path}: the checkpoint pickles objects beyond tensors and plain containers ({str(e)[:160]}...); "
-                           "re-save its ['state_dict'] alone, or set MEGATTS2_UNSAFE_PICKLE=1 if you trust the file") from None
+    if unsafe:
+        raw = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+    else:
+        import pickle
+        try:
+            raw = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as first:      # what the weights_only unpickler raises for a class it does not know
+            # Real Lightning checkpoints pickle a few harmless value types beside the tensors (hyper_parameters, callback
+            # and scheduler states): retry with exactly those allow-listed - still no arbitrary code - before refusing
+            try:
+                with torch.serialization.safe_globals(_benign_checkpoint_types()):
+                    raw = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+            except pickle.UnpicklingError:
+                raise RuntimeError(
+                    f"{ckpt_path}: the checkpoint pickles objects beyond tensors, plain containers and the allow-listed value "
+                    f"types ({str(first)[:160]}...); re-save its weights alone - torch.save({{'state_dict': "
+                    "torch.load(path, weights_only=False)['state_dict']}, new_path) in an environment you trust - or set "
+                    "MEGATTS2_UNSAFE_PICKLE=1 if you trust the file") from None
     raw = raw["state_dict"]
     out = OrderedDict()
     for k, v in raw.items():

@@ -314,6 +314,13 @@ def test_lightning_checkpoints_are_read_weights_only(tmp_path, monkeypatch):
     assert list(out) == ["a.weight"] and out["a.weight"].dtype == np.float32 and out["a.weight"].shape == (2, 3)
     with pytest.raises(RuntimeError, match="MEGATTS2_UNSAFE_PICKLE"):
         weights.load_lightning_state_dict(bad, "plm.")
+    # value types real Lightning checkpoints carry beside the tensors are allow-listed, not refused
+    import argparse
+    import pathlib
+    benign = str(tmp_path / "benign.ckpt")
+    torch.save({"state_dict": sd, "hyper_parameters": argparse.Namespace(lr=1e-4, root=pathlib.PosixPath("/data")),
+                "lr_schedulers": [{"last_lr": np.float64(1e-4)}]}, benign)
+    assert list(weights.load_lightning_state_dict(benign, "plm.")) == ["a.weight"]
     monkeypatch.setenv("MEGATTS2_UNSAFE_PICKLE", "1")
     assert list(weights.load_lightning_state_dict(bad, "plm.")) == ["a.weight"]
 
@@ -343,6 +350,10 @@ def test_symbol_table_and_phone2token_match_the_reference(tmp_path):
         assert isinstance(ei.value, ValueError)
     named0 = SymbolTable.from_str("<blk> 0\nx 5\n")                              # a file that names id 0 itself
     assert named0.eps == "<blk>" and named0.symbols == ["<blk>", "x"]
+    # the null symbol listed with a NON-zero id and no id 0 in the file: accepted, re-mapped to 0, ranking unchanged - as
+    # the reference's __post_init__ does (utils/symbol_table.py:66-68)
+    moved = SymbolTable.from_str("<eps> 4\na 1\nb 2\n")
+    assert moved["<eps>"] == 0 and moved[0] == "<eps>" and moved[4] == "<eps>" and moved.symbols == ["<eps>", "a", "b"]
     if os.path.isdir("/root/reference/utils"):
         sys.path.insert(0, "/root/reference")
         try:
@@ -353,6 +364,8 @@ def test_symbol_table_and_phone2token_match_the_reference(tmp_path):
             f = tmp_path / "t.k2symbols"
             f.write_text("".join(f"{s} {i}\n" for s, i in zip(syms, ids)), encoding="utf-8")
             assert SymbolTable.from_file(str(f)).symbols == Ref.from_file(str(f)).symbols
+            ref_moved = Ref.from_str("<eps> 4\na 1\nb 2\n")
+            assert ref_moved["<eps>"] == moved["<eps>"] and ref_moved[0] == moved[0] and ref_moved.symbols == moved.symbols
         finally:
             sys.path.remove("/root/reference")
 

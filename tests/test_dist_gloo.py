@@ -46,6 +46,23 @@ def _worker(rank, world, port, q):
     mel_cap, lens_cap = D.gather_mels(local, np.arange(1, rank + 2, dtype=np.int32), b_cap=3, t_cap=8, host_lens=False)
     ok = ok and tuple(mel_cap.shape) == (6, 8, 80) and lens_cap.tolist() == [1, 0, 0, 1, 2, 0]
     ok = ok and float(mel_cap[3, :6].min()) == 1.0 and float(mel_cap[3, 6:].abs().max()) == 0.0
+    # the preallocated exchange of a serving loop (bench.py --gpus N): the "synthesis" writes straight into the send block,
+    # nothing is allocated between the steps; a second step with a smaller batch leaves no stale rows behind
+    ex = D.MelExchange(3, 8, 80, "cpu", world)
+    ptrs = (ex.buf.data_ptr(), ex.out.data_ptr())
+    for stepno, nb in enumerate((rank + 1, 1)):
+        view = ex.mel_view(nb)
+        view.zero_()
+        view[:, :5 + rank] = float(rank + 10 * stepno)
+        m2, l2 = D.gather_mels(view, np.arange(1, nb + 1, dtype=np.int32), host_lens=False, exchange=ex)
+        want = [1, 0, 0, 1, 2, 0] if stepno == 0 else [1, 0, 0, 1, 0, 0]
+        ok = ok and tuple(m2.shape) == (6, 8, 80) and l2.tolist() == want
+        ok = ok and float(m2[3, :6].min()) == 1.0 + 10 * stepno and float(m2[3, 6:].abs().max()) == 0.0
+        ok = ok and float(m2[4].abs().max()) == (0.0 if stepno else 1.0) and float(m2[5].abs().max()) == 0.0
+        ok = ok and (ex.buf.data_ptr(), ex.out.data_ptr()) == ptrs
+    # a block that was NOT written in place (shorter T) is copied in, its tail zeroed
+    m3, l3 = D.gather_mels(torch.full((1, 4, 80), 7.0), np.asarray([4], np.int32), host_lens=True, exchange=ex)
+    ok = ok and tuple(m3.shape) == (2, 8, 80) and l3.tolist() == [4, 4] and float(m3[:, :4].min()) == 7.0 and float(m3[:, 4:].abs().max()) == 0.0
     # fewer utterances than ranks: the rank with an empty shard still takes part in the collective (no hang)
     one = D.synthesize_sharded(FakeTTS(), utts[:1])
     ok = ok and len(one) == 1 and torch.equal(one[0], fake_mel(utts[0]))
@@ -119,3 +136,24 @@ def test_bench_strong_scaling_contract_world2_gloo():
         assert ss["lpt_cost_imbalance"] >= 1.0
         totals[n] = d["config"]["frames_per_step"]
     assert totals[1] == totals[2] and 9 * 431 * 0.7 <= totals[1] <= 9 * 431       # ragged: U(0.7, 1) x 431 frames each
+
+
+def test_lpt_balance_of_the_c4_set_with_the_vocoder_in_the_cost_model():
+    """BASELINE configs[3]: the 256 ragged utterances bench.py --scaling strong shards (C4 geometry, lengths U(0.7, 1), seed
+    1004).  The cost model now carries the vocoder (614.1 MFLOP / frame, the largest linear term) and the prompt's VQ-PE (50.0
+    MFLOP / prompt frame) - SURVEY 8d; the modelled imbalance of the LPT shards stays <= 1.03 for 2, 4 and 8 ranks, and the
+    linear terms are what the per-unit figures say."""
+    from megatts2_amd import dist as D
+    from megatts2_amd import synth
+    base = D.utterance_cost(70, 431, 431, vocoder=False, prompt_vqpe=False)
+    assert abs(D.utterance_cost(70, 431, 431, vocoder=True, prompt_vqpe=False) - base - 614.1 * 431) < 1e-6
+    assert abs(D.utterance_cost(70, 431, 431, vocoder=False, prompt_vqpe=True) - base - 50.0 * 431) < 1e-6
+    assert D.utterance_cost(70, 431, 431) == D.utterance_cost(70, 431, 431, vocoder=True, prompt_vqpe=True)
+    shape = synth.SHAPES["C4"]
+    utts = synth.make_batch(shape, seed=1004, jitter=0.3, batch=shape.B)
+    assert len(utts) == 256
+    costs = [D.utterance_cost(u.phone.size, u.prompt_mel.shape[0], int(u.durations.sum())) for u in utts]
+    for world in (2, 4, 8):
+        shards = D.shard_utterances(costs, world)
+        assert sorted(i for s_ in shards for i in s_) == list(range(256)) and {len(s_) for s_ in shards} == {256 // world}
+        assert D.shard_imbalance(costs, shards) <= 1.03, (world, D.shard_imbalance(costs, shards))

@@ -50,6 +50,9 @@ F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 # the same f32 product from six bf16 MFMAs (3-way exact split, gemm_f32.hip "x6"): 2500 TF/s dense bf16 / 6 products
 X6_EQUIV_PEAK_TFLOPS = 2500.0 / 6.0
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s achievable)
+N_SIMD = 1024                     # 256 CUs x 4 SIMDs
+MFMA_BUSY_GHZ = 1.9               # clock the matrix-pipe busy fraction is priced at: between the 1.4 GHz a long x6 stage sustains
+                                  # and the 2.0-2.3 GHz of the AR stages' short launches (roofline.clock_probe measures both live)
 STAGES_FULL = ["vqpe", "mrte", "adm", "plm", "decoder", "vocoder"]
 
 
@@ -171,6 +174,137 @@ def sub_workload(model, cfgs, name, steps, warmup, dev):
             "frac_of_f32_mfma_peak": round(alg / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
 
 
+def _timed(step, steps, warmup):
+    import torch
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def _stack(arrs, dtype):
+    n = max(a.shape[0] for a in arrs)
+    out = np.zeros((len(arrs), n) + arrs[0].shape[1:], dtype)
+    for i, a in enumerate(arrs):
+        out[i, :a.shape[0]] = a
+    return out
+
+
+def sub_c4_strong_n1(model, cfgs, steps, warmup, dev):
+    """BASELINE configs[3] on ONE rank, exactly what `bench.py --gpus 1 --scaling strong` times (the N = 1 anchor of a
+    strong-scaling curve): the 256 ragged utterances of C4 (lengths U(0.7, 1), seed 1004) in ONE synthesize_batch call, the
+    whole path incl. prompt VQ-PE and vocoder.  Parity of this very call: tests/test_gpu_stages.py::
+    test_prod_strong_scaling_the_exact_256_utterance_call."""
+    import torch
+    from megatts2_amd import synth
+    g, p, a, h = cfgs
+    shape = synth.SHAPES["C4"]
+    utts = synth.make_batch(shape, seed=1004, jitter=0.3, batch=shape.B)
+    phone = torch.from_numpy(_stack([u.phone for u in utts], np.int64)).to(dev)
+    mel_in = torch.from_numpy(_stack([u.prompt_mel for u in utts], np.float32)).to(dev)
+    dur = _stack([u.durations for u in utts], np.int32)
+    pl = np.asarray([u.phone.size for u in utts], np.int32)
+    ml = np.asarray([u.prompt_mel.shape[0] for u in utts], np.int32)
+    model.workspace_reserve(model.workspace_query(len(utts), int(pl.max()), int(ml.max()), shape.Tm, run_plm=True, vocoder=True,
+                                                  prompt_vqpe=True))
+
+    def step():
+        return model.synthesize_batch(phone, pl, mel_in, ml, forced_dur=dur, run_plm=True, vocoder=True, tm_cap=shape.Tm,
+                                      prompt_vqpe=True)
+    ms = _timed(step, steps, warmup)
+    model.set_profiling(True)
+    step()
+    torch.cuda.synchronize()
+    stage_ms = dict(model.last_stage_ms())
+    model.set_profiling(False)
+    if "vqpe_side" in stage_ms:
+        stage_ms["vqpe"] = stage_ms.pop("vqpe_side")
+    frames = int(dur.sum())
+    alg = sum(stage_flops_model(g, a, p, h, utts, STAGES_FULL)[0].values())
+    return {"workload": f"C4 on ONE rank (`--scaling strong`, N = 1): {len(utts)} utterances, lengths U(0.70, 1) x (Np={shape.Np}, "
+                        f"Tp={shape.Tp}, Tm={shape.Tm}), one synthesize_batch call; stages " + "+".join(STAGES_FULL) + "; forced durations",
+            "value": round(frames / (ms * 1e-3), 1), "unit": "mel-frames/s", "ms_per_step": round(ms, 3), "steps": steps,
+            "warmup": warmup, "frames_per_step": frames, "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "algorithmic_gflop_per_step": round(alg / 1e9, 1), "tflops": round(alg / (ms * 1e-3) / 1e12, 2),
+            "frac": round(alg / (ms * 1e-3) / 1e12 / X6_EQUIV_PEAK_TFLOPS, 4)}
+
+
+def sub_c3_inflight(make_model, model, inputs, frames, n, steps, warmup):
+    """The throughput mode (`bench.py --inflight 3`): batch i on handle i % n and HIP stream i % n (n handles, each with its own
+    weights and arena), the timed region ends with a device-wide synchronisation.  Same C3 batch, same arithmetic; a step is
+    still one batch.  Parity: test_prod_three_batches_in_flight_equal_three_sequential_calls."""
+    import torch
+    models = [model] + [make_model() for _ in range(n - 1)]
+    try:
+        lanes = [torch.cuda.Stream() for _ in models]
+        phone, pl, mel_in, ml, dur, tm = inputs
+        for m_ in models[1:]:
+            m_.workspace_reserve(m_.workspace_query(phone.shape[0], phone.shape[1], mel_in.shape[1], tm, run_plm=True, vocoder=True,
+                                                    prompt_vqpe=True))
+        cnt = [0]
+
+        def step():
+            i = cnt[0]
+            cnt[0] += 1
+            with torch.cuda.stream(lanes[i % n]):
+                return models[i % n].synthesize_batch(phone, pl, mel_in, ml, forced_dur=dur, run_plm=True, vocoder=True,
+                                                      tm_cap=tm, prompt_vqpe=True)
+        ms = _timed(step, steps, warmup)
+    finally:
+        for m_ in models[1:]:
+            m_.close()
+    return {"workload": f"C3 with {n} batches in flight ({n} handles x {n} streams); stages " + "+".join(STAGES_FULL) + "; forced durations",
+            "value": round(frames / (ms * 1e-3), 1), "unit": "mel-frames/s", "ms_per_step": round(ms, 3), "steps": steps,
+            "warmup": warmup, "batches_in_flight": n}
+
+
+def sub_c3_own_durations(model, cfgs, inputs, steps, warmup):
+    """The REAL control flow at production size: nothing forced - the ADM's own durations leave the device (one D2H +
+    hipStreamSynchronize, capi.inc `if (!dur)`; the reference's modules/mrte.py:51-56 round trip), the host re-plans the frame
+    rows, the PLM / decoder / vocoder run on the lengths the ADM chose (name-seeded weights: 4-6 frames per phone, so fewer
+    frames than the forced 431 - `frames_per_step` says how many).  Parity: test_prod_c3_batch_own_durations_end_to_end."""
+    import torch
+    g, p, a, h = cfgs
+    phone, pl, mel_in, ml, _, _ = inputs
+    B, Np = phone.shape
+    _, lens, aux = model.synthesize_batch(phone, pl, mel_in, ml, forced_dur=None, run_plm=True, vocoder=True, tm_cap=24 * Np,
+                                          prompt_vqpe=True, return_aux=True)
+    torch.cuda.synchronize()
+    tm = int((int(lens.max()) + 7) // 8 * 8)          # deterministic weights, deterministic durations: the cap a server would set
+    durs = aux["dur"].cpu().numpy()
+    model.workspace_reserve(model.workspace_query(B, Np, mel_in.shape[1], tm, run_plm=True, vocoder=True, prompt_vqpe=True))
+
+    def step():
+        return model.synthesize_batch(phone, pl, mel_in, ml, forced_dur=None, run_plm=True, vocoder=True, tm_cap=tm, prompt_vqpe=True)
+    ms = _timed(step, steps, warmup)
+    model.set_profiling(True)
+    step()
+    torch.cuda.synchronize()
+    stage_ms = dict(model.last_stage_ms())
+    model.set_profiling(False)
+    if "vqpe_side" in stage_ms:
+        stage_ms["vqpe"] = stage_ms.pop("vqpe_side")
+    frames = int(lens.sum())
+
+    class _U:          # the flop model reads sizes only
+        def __init__(self, i):
+            self.phone = np.zeros(int(pl[i]), np.int64)
+            self.prompt_mel = np.zeros((int(ml[i]), 1), np.float32)
+            self.durations = durs[i, :int(pl[i])]
+    alg = sum(stage_flops_model(g, a, p, h, [_U(i) for i in range(B)], STAGES_FULL)[0].values())
+    return {"workload": f"C3 with the ADM's OWN durations (nothing forced): B={B}, Np={Np}, Tp={mel_in.shape[1]}; D2H of the durations "
+                        "+ stream synchronisation + host re-planning inside the timed region; stages " + "+".join(STAGES_FULL),
+            "value": round(frames / (ms * 1e-3), 1), "unit": "mel-frames/s", "ms_per_step": round(ms, 3), "steps": steps,
+            "warmup": warmup, "frames_per_step": frames, "frames_per_utterance_min_max": [int(lens.min()), int(lens.max())],
+            "tm_cap": tm, "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
+            "algorithmic_gflop_per_step": round(alg / 1e9, 1), "tflops": round(alg / (ms * 1e-3) / 1e12, 2),
+            "frac": round(alg / (ms * 1e-3) / 1e12 / X6_EQUIV_PEAK_TFLOPS, 4)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,14 +392,16 @@ def main() -> None:
         sd_a = weights.synth_state_dict(weights.inventory_adm(a), 0, "adm.")
         sd_p = weights.synth_state_dict(weights.inventory_plm(p), 0, "plm.") if full else None
         sd_h = weights.synth_state_dict(weights.inventory_hifigan(h), 0, "hifigan.") if full else None
-        models = [NativeModel(g, p, a, h, sd_g, sd_p, sd_a, sd_h) for _ in range(max(1, args.inflight))]
-        model = models[0]
-        for m_ in models:
+        def make_model():
+            m_ = NativeModel(g, p, a, h, sd_g, sd_p, sd_a, sd_h)
             for kv in args.opt:
                 k, v = kv.split("=")
                 m_.set_option(k, int(v))
             if args.stage_markers:
                 m_.set_option("stage_markers", 1)
+            return m_
+        models = [make_model() for _ in range(max(1, args.inflight))]
+        model = models[0]
 
     shape = synth.SHAPES[args.workload]
     strong = args.scaling == "strong"
@@ -456,10 +592,11 @@ def main() -> None:
         achieved = alg_gemm / (ms_per_step * 1e-3) / 1e12
         pm = None
         pmc_path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r_:02d}_pmc_{args.workload.lower()}_latest.json")
-                                     for r_ in (4, 3, 2)) if os.path.exists(q)), None)     # the newest committed PMC summary
+                                     for r_ in (5, 4, 3, 2)) if os.path.exists(q)), None)     # the newest committed PMC summary
         if pmc_path:
             pm = json.load(open(pmc_path))
         per_stage = {}
+        mfma_cycles_total = [0.0]
         for s in stages:
             ms = stage_ms.get(s)
             if not ms:
@@ -474,6 +611,13 @@ def main() -> None:
                 e["hbm_gb"] = round(gb, 3)
                 e["hbm_gb_s"] = round(gb / (ms * 1e-3), 1)
                 e["hbm_frac_of_8tbs"] = round(gb / (ms * 1e-3) / HBM_PEAK_GBS, 4)
+                if by.get("mfma_busy_cycles"):
+                    # matrix-pipe utilisation (north_star: "MFMA utilisation against gfx950 peak"): SQ_VALU_MFMA_BUSY_CYCLES of
+                    # the stage's launches (summed over the 1024 SIMDs, from the committed --pmc pass) over the SIMD cycles the
+                    # stage's wall time offers at MFMA_BUSY_GHZ - the PMC pass serialises the streams, so its own wall time is
+                    # not used; the stage time is this run's
+                    e["mfma_busy_frac"] = round(by["mfma_busy_cycles"] / (N_SIMD * ms * 1e-3 * MFMA_BUSY_GHZ * 1e9), 4)
+                    mfma_cycles_total[0] += by["mfma_busy_cycles"]
             per_stage[s] = e
         traffic, traffic_detail = None, None      # bytes per launch, from the committed rocprofv3 --pmc passes
         if pm and "gemm_engine" in pm:
@@ -508,6 +652,12 @@ def main() -> None:
             "launches_per_step": n_launch, "avg_launch_us": round(sum_ms * 1e3 / max(n_launch, 1), 2),
             "traced_gemm_ms_sum_of_launches": round(sum_ms, 3),
             "stages": per_stage,
+            "mfma_busy_frac": (round(mfma_cycles_total[0] / (N_SIMD * ms_per_step * 1e-3 * MFMA_BUSY_GHZ * 1e9), 4)
+                               if mfma_cycles_total[0] else None),
+            "mfma_busy_detail": (f"SQ_VALU_MFMA_BUSY_CYCLES (all {N_SIMD} SIMDs, committed rocprofv3 --pmc pass) / (SIMDs x this run's "
+                                 f"stage or step time x {MFMA_BUSY_GHZ} GHz); per stage in `stages`"),
+            "hbm_frac_of_8tbs": (round(sum(e_.get("hbm_gb", 0.0) for e_ in per_stage.values()) / (ms_per_step * 1e-3) / HBM_PEAK_GBS, 4)
+                                 if any("hbm_gb" in e_ for e_ in per_stage.values()) else None),
             "slowest_shapes_traced": shapes,
             "per_config": [{"config": r["config"], "launches": r["launches"], "ms": round(r["ms"], 3),
                             "tflops": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2)} for r in tr],
@@ -544,6 +694,16 @@ def main() -> None:
         for nm, k_, w_ in (("C2", 3, 1), ("C1", 5, 2), ("C5", 2, 1)):
             try:
                 subs[nm] = sub_workload(model, (g, p, a, h), nm, k_, w_, dev)
+            except Exception as e:
+                subs[nm] = {"error": str(e)[:200]}
+        # what else this repo publishes, timed by the same command: the C4 anchor on one rank, the
+        # throughput mode with three batches in flight, and the path with NOTHING forced (the ADM's own durations)
+        c3_inputs = (phone, pl, mel_in, ml, dur, shape.Tm)
+        for nm, fn_ in (("C4_strong_n1", lambda: sub_c4_strong_n1(model, (g, p, a, h), 2, 1, dev)),
+                        ("C3_own_durations", lambda: sub_c3_own_durations(model, (g, p, a, h), c3_inputs, 5, 2)),
+                        ("C3_inflight3", lambda: sub_c3_inflight(make_model, model, c3_inputs, frames_per_step, 3, 9, 3))):
+            try:
+                subs[nm] = fn_()
             except Exception as e:
                 subs[nm] = {"error": str(e)[:200]}
         result["workloads"] = subs

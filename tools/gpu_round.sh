@@ -13,6 +13,7 @@
 #   sweep sweep_ar sweep_voc sweep_vocx   GEMM engine sweeps (all / AR shapes / vocoder shapes / vocoder launch variants)
 #   sweep_x6 sweep_x6s sweep_x6k sweep_skinny   x6 tile forms / under-filled AR launches / K-split x6 tiles / M <= 64 kernel
 #   frontend s2                      rows f3 / f2 measurements
+#   graph newtests                   hipGraph replay vs stream launches (boundary ubench); this round's new parity tests (TEST_K)
 #   gridsync cpuinfo                 phase-boundary ubench (launch chain vs in-kernel grid barrier); host CPU limits of the box
 #   strong                           bench.py --scaling strong on one rank (C4: 256 ragged utterances in one call)
 # everything is written under gpurun_out/ (scratch); summaries worth keeping are copied to profiles/ by hand.
@@ -33,6 +34,14 @@ prof1)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof1${PROF_TAG} -o bench -- python $GRAFT_REPO_ROOT/bench.py --workload C1 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-sub-workloads ${PROF_OPT}) > gpurun_out/prof1${PROF_TAG}.log 2>&1
   echo "prof1 rc=$?"; f=$(find gpurun_out/prof1${PROF_TAG} -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/prof1${PROF_TAG}_kernel_stats.csv && head -14 "$f" | cut -c1-200
   find gpurun_out/prof1${PROF_TAG} -name "*kernel_trace.csv" -size +8M -delete ;;
+graph)
+  # dependent-launch boundary replayed from a hipGraph vs launch by launch on a stream (tools/ubench/graph_chain.hip)
+  timeout 120 variants/ubench/graph_chain > gpurun_out/ubench_graph.txt 2>&1
+  echo "graph rc=$?"; cat gpurun_out/ubench_graph.txt ;;
+newtests)
+  # this round's added parity tests only (TEST_K selects), before the whole suite is spent on them
+  timeout 1500 python -m pytest tests/test_gpu_stages.py tests/test_gpu_kernels.py -m gpu -q --no-header -p no:cacheprovider --maxfail=10 -rf -k "${TEST_K:-exact_256 or in_flight or own_durations_end}" > gpurun_out/newtests.log 2>&1
+  echo "newtests rc=$?"; tail -12 gpurun_out/newtests.log ;;
 gridsync)
   # phase-boundary price list on THIS box: dependent launches vs grid barriers inside one launch (tools/ubench/grid_sync.hip)
   timeout 120 variants/ubench/grid_sync > gpurun_out/ubench_grid_sync.txt 2>&1

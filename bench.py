@@ -691,17 +691,17 @@ def main() -> None:
     if (rank == 0 and world == 1 and not dry and args.workload == "C3" and not args.no_sub_workloads and not args.batch
             and not args.skip_adm and not args.opt):
         subs = {}
-        for nm, k_, w_ in (("C2", 3, 1), ("C1", 5, 2), ("C5", 2, 1)):
-            try:
-                subs[nm] = sub_workload(model, (g, p, a, h), nm, k_, w_, dev)
-            except Exception as e:
-                subs[nm] = {"error": str(e)[:200]}
-        # what else this repo publishes, timed by the same command: the C4 anchor on one rank, the
-        # throughput mode with three batches in flight, and the path with NOTHING forced (the ADM's own durations)
+        # what else this repo publishes, timed by the same command: the throughput mode with three
+        # batches in flight (FIRST: its two extra handles need ~6 GB each, before the big sub-workloads grow this handle's
+        # arena), the path with NOTHING forced (the ADM's own durations), then the other BASELINE configurations and the
+        # C4 anchor on one rank
         c3_inputs = (phone, pl, mel_in, ml, dur, shape.Tm)
-        for nm, fn_ in (("C4_strong_n1", lambda: sub_c4_strong_n1(model, (g, p, a, h), 2, 1, dev)),
-                        ("C3_own_durations", lambda: sub_c3_own_durations(model, (g, p, a, h), c3_inputs, 5, 2)),
-                        ("C3_inflight3", lambda: sub_c3_inflight(make_model, model, c3_inputs, frames_per_step, 3, 9, 3))):
+        jobs = [("C3_inflight3", lambda: sub_c3_inflight(make_model, model, c3_inputs, frames_per_step, 3, 9, 3)),
+                ("C3_own_durations", lambda: sub_c3_own_durations(model, (g, p, a, h), c3_inputs, 5, 2))]
+        jobs += [(nm, (lambda nm=nm, k_=k_, w_=w_: sub_workload(model, (g, p, a, h), nm, k_, w_, dev)))
+                 for nm, k_, w_ in (("C2", 3, 1), ("C1", 5, 2), ("C5", 2, 1))]
+        jobs.append(("C4_strong_n1", lambda: sub_c4_strong_n1(model, (g, p, a, h), 2, 1, dev)))
+        for nm, fn_ in jobs:
             try:
                 subs[nm] = fn_()
             except Exception as e:

@@ -68,6 +68,17 @@ struct GemmP {
     // pro_act == 4 (ALGEBRAIC LayerNorm, K <= 1024): W = gamma-scaled weights W', bias = c, ln_g = s (see EncLayerW):
     // C = rstd * (X W'^T - mean * s) + c = LN(X) W^T + b; statistics in the prologue, K loop untouched.
     const float* ln_g; const float* ln_b; float ln_eps;
+    // ---- LayerNorm statistics handed from GEMM to GEMM (round 5: the AR layers' stand-alone LayerNorm launches).
+    // Producer side (any pro_act; groups == 1): stat_out != nullptr asks the epilogue to also write, per output row m and
+    // per wave tile of `stat_w` columns, the pair (mean_t, M2_t) of the FINAL values C[m, tile] (after bias, activation,
+    // residual and mask) as stat_out[(m * stat_nt + t) * 2 + {0, 1}], stat_nt = N / stat_w.  launch_gemm fills stat_nt /
+    // stat_w for the tile it chooses (x6 K-split tiles: 32 columns; 128x128 loader tile: 64) and reports them in
+    // EngineOpts::last_stat_nt / last_stat_w - 0 when that tile has no such epilogue (the launch itself still succeeds).
+    float* stat_out = nullptr; int stat_nt = 0, stat_w = 0;
+    // Consumer side, pro_act == 5 (ALGEBRAIC LayerNorm on PAIR statistics): like pro_act == 4 (W = W', bias = c, ln_g = s), but
+    // mean / rstd of source row r come from merging the ln_nt pairs ln_stat[(r * ln_nt + t) * 2 ...] of ln_w columns each
+    // (Chan's formula, fixed order) - no pass over K.  x6 tiles 55 / 84 / 85 / 86 only; hipErrorNotSupported otherwise.
+    const float* ln_stat = nullptr; int ln_nt = 0, ln_w = 0;
 };
 // Tuning / measurement switches of the engine.  They live in the model handle (mt2_model::opts) or in a local
 // object of a kernel-level entry point - never in process globals: two handles (or two threads) do not see each
@@ -115,6 +126,11 @@ struct EngineOpts {
     bool trace_on = false;       // HIP events around every GEMM launch (measurement only)
     std::vector<TraceRec> trace;
     const char* last_cfg = "";   // name of the tile configuration the last launch used
+    int last_stat_nt = 0, last_stat_w = 0;   // GemmP::stat_out of the last launch: pairs per row / columns per pair (0: none written)
+    int ln_pairs = 1;            // AR layers with more than skinny_rows rows: the residual GEMMs (out-projection, ff.3) write row
+                                 // statistics as (mean, M2) pairs per wave tile in their epilogue and LN1 -> QKV / LN2 -> ff.0 run
+                                 // as ONE pair-fed algebraic-LayerNorm GEMM - no stand-alone LayerNorm launch (0: off; 1: where
+                                 // the producer is not K-split anyway; 2: also un-split the producers with K <= 1024)
 };
 hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
 // gemm_skinny.hip: weight-streaming linear layer for M <= 64 rows (taps = 1, no rowbase, K a multiple of 32)

@@ -224,7 +224,7 @@ int mt2_synthesize_prompt_conditioned(mt2_model* m, void* stream, const int64_t*
 /* ---- tuning.  Every switch lives in the handle (no process-global state): two handles do not see each other's
  * settings.  Names: "ar_groups" (1..8, default 2: the sequences of an autoregressive run are dealt into that many
  * independent kernel chains on internal HIP streams that fork from and join back into `stream`; results do not
- * depend on it), "lnalg" (0: algebraic LayerNorm in the AR layers), "splitk" (1), "lnfuse" (0), "voc_streams" (3),
+ * depend on it), "lnalg" (0: algebraic LayerNorm in the AR layers), "ln_pairs" (1: LayerNorm statistics handed from GEMM to GEMM in the AR layers), "splitk" (1), "lnfuse" (0), "voc_streams" (3),
  * "x6_conv" (1: window convolutions on the bf16 matrix pipe in the f32-equivalent 6-product form), "x6_gemm" (1: the same for
  * the implicit-GEMM launches with enough big tiles), "x6_splitk" (1), "t_x6_256" (160), "t_x6_128" (72), "t_x6_64" (0: tile-count thresholds of
  * the two x6 tile shapes), "nt_weights" (0) / "nt_row_tiles" (2: non-temporal weight loads for launches with at most that many
@@ -254,6 +254,18 @@ int mt2_op_gemm(void* stream, const float* X, int ldx, int Rx, const int32_t* ro
 int mt2_op_gemm_x6(void* stream, const float* X, int ldx, int Rx, int shift0, int taps, int dil, int Cin, const float* W,
                    const void* W3, const float* bias, const float* R, int ldr, const int32_t* valid, float* C, int ldc,
                    int M, int N, int pro_act, float pro_slope, int epi_act, int force_cfg);
+/* LayerNorm statistics handed from GEMM to GEMM (round 5; the AR layers of models/megatts2.py:172-179,264-273 =
+ * TransformerEncoderLayer.forward, modules/transformer.py:88-102: `x = x + out_proj(...)` followed by `norm2(x)`, `x = x + ff(...)`
+ * followed by the next layer's `norm1(x)`).  ONE linear launch C = epi(X @ W^T + bias) + R on a bf16-pipe (x6) tile with
+ *   stat_out != NULL: the epilogue also writes, per row and per wave tile of *stat_w columns, the pair (mean, M2) of the final C
+ *     values: stat_out[M][*stat_nt][2] (*stat_nt = 0: the chosen tile has no such epilogue, nothing was written);
+ *   ln_stat  != NULL: C = LayerNorm(X) @ Wo^T + b in its algebraic form on those pairs - W / W3 = gamma-folded weights
+ *     W'[n,k] = gamma[k] Wo[n,k], bias = c[n] = sum_k beta[k] Wo[n,k] + b[n], ln_s[n] = sum_k W'[n,k]; mean / rstd of source row r
+ *     merged (Chan, fixed order) from ln_stat[r][ln_nt][2] with ln_w columns per pair: rstd * (X W'^T - mean * s) + c. */
+int mt2_op_gemm_x6_ln(void* stream, const float* X, int ldx, int Rx, int a_mul, int shift0, const float* W, const void* W3,
+                      const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epi_act,
+                      int force_cfg, float* stat_out, int32_t* stat_nt, int32_t* stat_w, const float* ln_stat, int ln_nt,
+                      int ln_w, const float* ln_s, float ln_eps);
 /* Linear layers of at most 64 rows on a TILE-MAJOR copy of the weights (round 4; gemm_skinny_tm_kernel - what the AR steps of one
  * utterance and the last-row launches of every batched AR step run on: F.linear at models/megatts2.py:172-179,264-273 with a
  * handful of rows).  mt2_op_tile_major turns a row-major [N, K] matrix (N a multiple of 16, K of 64) into blocks of 16 columns x 64 k,

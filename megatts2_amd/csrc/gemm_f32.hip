@@ -54,6 +54,85 @@ __device__ __forceinline__ float act_rt(int act, float v, float slope) {
     }
 }
 
+// ---- LayerNorm statistics handed from GEMM to GEMM (GemmP::stat_out / ln_stat; round 5).
+// rows_sum32: v[i] = the value of row i (i < NE, a power of two <= 16) in this lane's column (column = lane & 31; the two
+// halves of the wave hold different rows and never mix: every xor mask is < 32).  Returns, in EVERY lane, the sum over the 32
+// columns of row (lane & (NE - 1)).  A reduce-scatter butterfly: at each step a lane keeps half of its values and sends the
+// other half to the partner that keeps those - NE - 1 exchanges instead of 5 NE - then plain butterflies over the remaining
+// lane bits.  Fixed order: deterministic.
+template <int NE>
+__device__ __forceinline__ float rows_sum32(float (&v)[NE], int lane) {
+#pragma unroll
+    for (int w = NE / 2; w >= 1; w >>= 1) {
+        const bool up = (lane & w) != 0;                  // lanes with this bit set keep the upper half of the index range
+#pragma unroll
+        for (int k = 0; k < w; ++k) {
+            const float mine = up ? v[k + w] : v[k], send = up ? v[k] : v[k + w];
+            v[k] = mine + __shfl_xor(send, w);
+        }
+    }
+    float sum = v[0];
+#pragma unroll
+    for (int m = NE; m < 32; m <<= 1) sum += __shfl_xor(sum, m);
+    return sum;
+}
+// Producer: the pair (mean_t, M2_t) of the W = 32 * NJ columns of this wave tile for each of the NE rows e0 .. e0 + NE - 1
+// (accumulator element numbering) of the 32-row block at mw.  sv / qv: per-lane sum and sum of squares over the lane's NJ
+// columns of the FINAL output values (0 outside M x N).  One single-pass (sum, sum of squares) per tile - its cancellation
+// error is eps * (1 + mean_t^2 / var_t), harmless for a residual stream whose channel mean is of the order of its spread
+// (measured: |mean| / std <= 2.2 per tile on the production models) - then Chan's merge across tiles on the consumer side.
+template <int NE>
+__device__ __forceinline__ void emit_row_pairs(const GemmP& p, float (&sv)[NE], float (&qv)[NE], int mw, int t, float w_cols,
+                                               int lane, int e0) {
+    const float S = rows_sum32<NE>(sv, lane), Q = rows_sum32<NE>(qv, lane);
+    const int i = lane & 31;
+    if (i < NE) {
+        const int e = e0 + i;
+        const int m = mw + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        if (m < p.M) {
+            const float mean = S / w_cols;
+            float2 pr;
+            pr.x = mean;
+            pr.y = fmaxf(Q - S * mean, 0.0f);
+            *reinterpret_cast<float2*>(p.stat_out + ((long long)m * p.stat_nt + t) * 2) = pr;
+        }
+    }
+}
+// Consumer (pro_act == PRO_LNX): mean / rstd of source row `src` from its ln_nt pairs of ln_w columns each.  Lane l and lane
+// l ^ 32 work on the SAME row (row = f(lane & 31)) and each takes every other float4 (two pairs) - all loads of a lane go out
+// together (one memory round trip, overlapped with the ring prologue), the halves meet with one shuffle, the second pass
+// (Chan: M2 = sum M2_t + w * sum (mean_t - mean)^2) runs on the registers.  ln_nt even, <= 32.
+__device__ __forceinline__ void lnx_row_stats(const GemmP& p, int m, int lane, float& mu, float& rs) {
+    int src = -1;
+    if (m < p.M) src = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
+    const bool ok = (unsigned)src < (unsigned)p.Rx;
+    const int nq = p.ln_nt >> 1, h = lane >> 5;
+    const float4* __restrict__ pr = reinterpret_cast<const float4*>(p.ln_stat) + (long long)(ok ? src : 0) * nq;
+    float4 q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int qi = j * 2 + h;
+        q[j] = (ok && qi < nq) ? pr[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float sm = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sm += q[j].x + q[j].z;
+    sm += __shfl_xor(sm, 32);
+    const float mean = sm / (float)p.ln_nt, w = (float)p.ln_w;
+    float m2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int qi = j * 2 + h;
+        if (qi < nq) {
+            const float d0 = q[j].x - mean, d1 = q[j].z - mean;
+            m2 += (q[j].y + w * d0 * d0) + (q[j].w + w * d1 * d1);
+        }
+    }
+    m2 += __shfl_xor(m2, 32);
+    mu = ok ? mean : 0.0f;
+    rs = ok ? 1.0f / sqrtf(m2 / ((float)p.ln_nt * w) + p.ln_eps) : 0.0f;
+}
+
 // Fused epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
 // EPG < 16: only accumulator elements e with e / EPG == esel are written (the K-split reduction shares the
 // 16 elements of a 32x32 tile among the K groups; esel is wave-uniform).
@@ -118,7 +197,7 @@ __device__ __forceinline__ void epi_prefetch(const GemmP& p, EpiPre<NE>& q, int 
         q.v[i] = vp[m * vs];
     }
 }
-template <int NE>
+template <int NE, bool STAT = false>
 __device__ __forceinline__ void epilogue_pre(const GemmP& p, const float (&acc)[NE], const EpiPre<NE>& q, int g, int mw,
                                              int nw, int lane, int e0) {
     float* __restrict__ C = p.C + (long long)g * p.strideC;
@@ -128,18 +207,22 @@ __device__ __forceinline__ void epilogue_pre(const GemmP& p, const float (&acc)[
     const bool hasR = p.R != nullptr;
     const int n = nw + (lane & 31);
     const bool nok = n < p.N;
+    float sv[STAT ? NE : 1], qv[STAT ? NE : 1];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int e = e0 + i;
         const int m = mw + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+        float v = 0.0f;
         if (nok && m < p.M) {
-            float v = acc[i] + q.b;
+            v = acc[i] + q.b;
             v = act_rt(epi_act, v, epi_par) * out_scale;
             if (hasR) v += q.r[i];
             if (q.v[i] == 0) v = 0.0f;
             C[(long long)m * p.ldc + n] = v;
         }
+        if constexpr (STAT) { sv[i] = v; qv[i] = v * v; }
     }
+    if constexpr (STAT) emit_row_pairs<NE>(p, sv, qv, mw, nw >> 5, 32.0f, lane, e0);      // one pair per 32-column wave tile
 }
 
 // The same for TM x TN tiles per wave (no K split): residual, row mask and bias of the whole wave tile are
@@ -176,14 +259,20 @@ __device__ __forceinline__ void epi_prefetch_t(const GemmP& p, EpiPreT<TM, TN>& 
             q.v[i][e] = vp[m * vs];
         }
 }
-template <int TM, int TN>
+template <int TM, int TN, bool STAT = false>
 __device__ __forceinline__ void epilogue_pre_t(const GemmP& p, f32x16 (&acc)[TM][TN], const EpiPreT<TM, TN>& q, int g,
                                                int mw, int nw, int lane) {
+    static_assert(!STAT || TM == 1, "row statistics: one 32-row block per wave");
     float* __restrict__ C = p.C + (long long)g * p.strideC;
     const int epi_act = p.epi_act;
     const float epi_par = p.pro_slope;
     const float out_scale = p.out_scale;
     const bool hasR = p.R != nullptr;
+    float sv[STAT ? 16 : 1], qv[STAT ? 16 : 1];
+    if constexpr (STAT) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sv[e] = 0.0f; qv[e] = 0.0f; }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = nw + j * 32 + (lane & 31);
@@ -193,15 +282,18 @@ __device__ __forceinline__ void epilogue_pre_t(const GemmP& p, f32x16 (&acc)[TM]
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = mw + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                float v = 0.0f;
                 if (nok && m < p.M) {
-                    float v = acc[i][j][e] + q.b[j];
+                    v = acc[i][j][e] + q.b[j];
                     v = act_rt(epi_act, v, epi_par) * out_scale;
                     if (hasR) v += q.r[i][j][e];
                     if (q.v[i][e] == 0) v = 0.0f;
                     C[(long long)m * p.ldc + n] = v;
                 }
+                if constexpr (STAT) { sv[e] += v; qv[e] += v * v; }
             }
     }
+    if constexpr (STAT) emit_row_pairs<16>(p, sv, qv, mw, nw / (32 * TN), 32.0f * TN, lane, 0);   // one pair per wave tile of 32 TN columns
 }
 
 // Epilogue with 16-byte stores.  The 32x32 MFMA leaves a lane with ONE column and 16 scattered rows, i.e. 16 dword stores per
@@ -264,6 +356,7 @@ __device__ __forceinline__ void epilogue_t4(const GemmP& p, f32x16 (&acc)[TM][TN
 constexpr int BK = 32;   // K chunk (floats)
 constexpr int PRO_LN = 3;   // prologue kind: LayerNorm of the A rows (value of GemmP::pro_act)
 constexpr int PRO_LNA = 4;  // LayerNorm of the A rows, ALGEBRAIC form: statistics in the prologue, correction in the epilogue
+constexpr int PRO_LNX = 5;  // ... ALGEBRAIC form on PAIR statistics written by the producer GEMM's epilogue (GemmP::ln_stat): no pass over K
 constexpr int LS = 36;   // LDS row stride (floats): 144 B = 9 x 16 B -> conflict-free ds_read_b128
 
 template <int BM, int BN, int WGM, int WGN>
@@ -1778,6 +1871,14 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     constexpr bool PRET = TM * TN <= 2 && !MP;
     EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
     if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    // pair-fed algebraic LayerNorm and row-statistics epilogue (GemmP::ln_stat / stat_out): the plain 128x128 tile only
+    // (one 32-row block per wave, epilogue operands prefetched, ACT_NONE instantiation)
+    constexpr bool LNXOK = PRET && TM == 1 && PRO == ACT_NONE && !XP && !FR;
+    float ln_mu = 0.0f, ln_rs = 0.0f;
+    const bool lnx = LNXOK && p.pro_act == PRO_LNX;
+    if constexpr (LNXOK) {
+        if (lnx) lnx_row_stats(p, m0 + wm * WTM + (lane & 31), lane, ln_mu, ln_rs);
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -2157,7 +2258,22 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     }
 #endif
 #undef MT2_T
-    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    if constexpr (LNXOK) {
+        if (lnx) {                                        // rstd_r * (acc - mean_r * s_n); the bias operand is c
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+                const float s_n = n < p.N ? p.ln_g[n] : 0.0f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int r = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    acc[0][j][e] = __shfl(ln_rs, r) * (acc[0][j][e] - __shfl(ln_mu, r) * s_n);
+                }
+            }
+        }
+        if (p.stat_out) epilogue_pre_t<TM, TN, true>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+        else epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    } else if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     // the 16-byte-store epilogue only where the variant has registers to spare (<= 8 waves: 256 VGPRs; MP: <= 127 in use):
     // in the 12-wave 256x128 tile, which sits at its 168-VGPR cap, the extra code made the allocator spill an in-flight
     // ds_read destination inside the K loop (tools/asm_audit.py; NaNs at production size) - that tile keeps `epilogue`
@@ -2270,6 +2386,11 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x6_ks_kernel(
     const int wm = wave / WGN, wn = wave % WGN;
     EpiPre<EPG> pre;
     epi_prefetch<EPG>(p, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
+    // pair-fed algebraic LayerNorm (PRO_LNX, the ACT_NONE instantiation only): lane l holds mean / rstd of row l & 31 of
+    // the wave's 32-row block, merged from the producer's pairs while the first ring stages are in flight
+    float ln_mu = 0.0f, ln_rs = 0.0f;
+    const bool lnx = PRO == ACT_NONE && p.pro_act == PRO_LNX;
+    if (lnx) lnx_row_stats(p, m0 + wm * 32 + (lane & 31), lane, ln_mu, ln_rs);
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
@@ -2347,12 +2468,32 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x6_ks_kernel(
             for (int g2 = 0; g2 < KS; ++g2) v += smem[(((g2 * NW + wave) * 16) + e) * 64 + lane];
             out[i] = v;
         }
-        epilogue_pre<EPG>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
+        if (lnx) {                                        // rstd_r * (acc - mean_r * s_n); the bias operand is c
+            const int n = n0 + wn * 32 + (lane & 31);
+            const float s_n = n < p.N ? p.ln_g[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < EPG; ++i) {
+                const int e = kg * EPG + i, r = (e & 3) + 8 * (e >> 2) + 4 * half;
+                out[i] = __shfl(ln_rs, r) * (out[i] - __shfl(ln_mu, r) * s_n);
+            }
+        }
+        if (p.stat_out) epilogue_pre<EPG, true>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
+        else epilogue_pre<EPG>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
     } else {
         float out[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) out[e] = acc[e];
-        epilogue_pre<16>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, 0);
+        if (lnx) {
+            const int n = n0 + wn * 32 + (lane & 31);
+            const float s_n = n < p.N ? p.ln_g[n] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int r = (e & 3) + 8 * (e >> 2) + 4 * half;
+                out[e] = __shfl(ln_rs, r) * (out[e] - __shfl(ln_mu, r) * s_n);
+            }
+        }
+        if (p.stat_out) epilogue_pre<16, true>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, 0);
+        else epilogue_pre<16>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, 0);
     }
 }
 
@@ -2368,6 +2509,8 @@ struct TileCfg {
     int win_qs = 0;           // > 0: window convolution for Cin = Cout = 32 * win_qs
     bool x6 = false;          // window convolution on the bf16 pipe (3-way split, 6 products): needs GemmP::W3
     int x6_ks = 0;            // > 0: x6 K-split tile (gemm_x6_ks_kernel): linear layers with K a multiple of 32 * x6_ks
+    int stat_w = 0;           // > 0: the tile has the row-statistics epilogue (GemmP::stat_out: one pair per stat_w columns) and
+                              // the pair-fed algebraic-LayerNorm form (pro_act == PRO_LNX)
 };
 
 // A configuration that was measured, documented (profiles/) and is no longer built: the index keeps its
@@ -2413,7 +2556,8 @@ struct TileCfg {
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),       \
       "x6ldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
       { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
-        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
+        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true, 0,                 \
+      ((BM_) / (WM_) == 32 && (BN_) / (WN_) <= 64) ? (BN_) / (WN_) : 0 }
 #define MT2_WX6L(QS_, BM_, BN_, WM_, WN_, NST_, NL_)                                                         \
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * (((3 * BN_ / 16 + NL_ - 1) / NL_) * NL_ * 1024),                 \
       "x6winl" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                           \
@@ -2440,7 +2584,7 @@ struct TileCfg {
     { BM_, BN_, (WM_* WN_ * KS_ + NL_) * 64, (size_t)KS_ * NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024), \
       "x6ks" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "+" #NL_ "_s" #NST_,                                         \
       { gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_NONE>, gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_RELU>, \
-        gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true, KS_ }
+        gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true, KS_, 32 }
 #define MT2_WX6(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024),   \
       "x6win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                     \
@@ -2560,6 +2704,10 @@ static const TileCfg kCfgs[] = {
     { 64, 32, 512, 0, "skinny64_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },    // 88
     { 32, 32, 512, 0, "skinnytm32_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },  // 89: the same on tile-major weights
     { 64, 32, 512, 0, "skinnytm64_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },  // 90   (+ LayerNorm prologue)
+    // round 5: HALF the footprint of the 128x128 loader tile - 4 compute waves (32x64 each) +
+    // 2 loader waves, 2-deep ring: 6 waves, 64 KiB -> TWO workgroups per CU (12 waves, 168 VGPRs), so that one AR chain's
+    // prologue / epilogue overlaps the other chain's K loop on the same CU.  Routed through x6_small_cfg = 91 (A/B only).
+    MT2_GX6L(64, 128, 2, 2, 2, 2),      // 91
 };
 constexpr int kSkinny32 = 87, kSkinny64 = 88, kSkinnyTm32 = 89, kSkinnyTm64 = 90;
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -2699,15 +2847,15 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     // group, VQ-PE) and from ~100 tiles on inside the model, where two AR chains share the chip (C3 step 297.2 ->
     // 295.2 ms, profiles/r02_opts_ab.txt); below that the K-split f32 tiles keep their latency advantage
     // (out-projection, ff.3, early AR steps).
-    if (o.x6_gemm && p.W3 && (p.K & 7) == 0 && (p.ldw & 7) == 0 && p.pro_act < PRO_LN && p.N > 64) {
+    if (o.x6_gemm && p.W3 && (p.K & 7) == 0 && (p.ldw & 7) == 0 && (p.pro_act < PRO_LN || p.pro_act == PRO_LNX) && p.N > 64) {
         // loader-wave variants (profiles/r02_gemm_sweep_x6_v5_ldr.txt: +10..12 % over 37, +16..20 % over 39)
         if (t256 >= o.t_x6_256) bi = o.x6_loaders ? 51 : 37;
         else if (t128 >= o.t_x6_128) bi = o.x6_loaders ? 55 : 39;
         // small x6 tiles (x6_small_cfg = 63..66) for launches whose 128x128 tiles would leave most of the chip idle
-        if (o.x6_small_cfg >= 63 && o.x6_small_cfg <= 64 && t256 < o.t_x6_256 && t128 <= o.t_x6_small_max) {
+        if (((o.x6_small_cfg >= 63 && o.x6_small_cfg <= 64) || o.x6_small_cfg == 91) && t256 < o.t_x6_256 && t128 <= o.t_x6_small_max) {
             const TileCfg& sc = kCfgs[o.x6_small_cfg];
             const long long ts = (long long)((p.M + sc.bm - 1) / sc.bm) * ((p.N + sc.bn - 1) / sc.bn) * p.groups;
-            if (ts >= o.t_x6_small_min) bi = o.x6_small_cfg;
+            if (ts >= o.t_x6_small_min && (o.x6_small_cfg != 91 || bi == 55)) bi = o.x6_small_cfg;      // 91 stands in for the 128x128 loader tile only
         }
         // MP form of the loader-wave tiles (mid-chunk barrier, fragment fetch / split behind the previous products)
         // K-split tiles on the bf16 pipe (x6_ks: 1 = the 32x64 k4 and 64x64 k4/k2 tiles, 2 = the 32x32 k8 tile too)
@@ -2736,7 +2884,11 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     GemmP p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.groups <= 0) return hipSuccess;
     if ((p.Cin & 3) || (p.ldx & 3) || (p.ldw & 3) || p.K != p.taps * p.Cin) return hipErrorInvalidValue;
-    if (p.pro_act < 0 || p.pro_act > PRO_LNA) return hipErrorInvalidValue;
+    if (p.pro_act < 0 || p.pro_act > PRO_LNX) return hipErrorInvalidValue;
+    if (opts) opts->last_stat_nt = opts->last_stat_w = 0;
+    if (p.pro_act == PRO_LNX && (p.taps != 1 || p.groups != 1 || !p.ln_g || !p.ln_stat || p.ln_nt < 2 || p.ln_nt > 32 ||
+                                 (p.ln_nt & 1) || p.ln_w <= 0 || p.ln_nt * p.ln_w != p.K || (((unsigned long long)p.ln_stat) & 15)))
+        return hipErrorInvalidValue;
     // a handful of rows: the weight-streaming kernel (gemm_skinny.hip) instead of a tile configuration
     const bool sk_forced = o.force_cfg == kSkinny32 || o.force_cfg == kSkinny64;
     const bool tm_forced = o.force_cfg == kSkinnyTm32 || o.force_cfg == kSkinnyTm64;
@@ -2780,6 +2932,18 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     }
     int idx = 0;
     const TileCfg* c = choose_cfg(p, o, &idx);
+    // variant index: the pair-fed algebraic LayerNorm is a run-time branch of the ACT_NONE instantiation (same K loop)
+    const int fi = p.pro_act == PRO_LNX ? 0 : p.pro_act;
+    if (p.pro_act == PRO_LNX && !c->stat_w) return hipErrorNotSupported;      // callers fall back to LayerNorm + GEMM
+    if (p.stat_out) {       // row-statistics epilogue where the chosen tile has one; otherwise the launch simply writes none
+        const int nt = c->stat_w ? p.N / c->stat_w : 0;
+        if (c->stat_w && p.groups == 1 && p.N % c->stat_w == 0 && nt >= 2 && nt <= 32 && (nt & 1) == 0 &&
+            ((((unsigned long long)p.stat_out) & 15) == 0)) {
+            p.stat_w = c->stat_w; p.stat_nt = nt;
+        } else {
+            p.stat_out = nullptr; p.stat_w = p.stat_nt = 0;
+        }
+    }
     if (p.pro_act == PRO_LNA) {     // algebraic LayerNorm: every LDS-DMA configuration has the variant
         if (p.taps != 1 || p.K > 1024 || !p.ln_g || p.groups != 1) return hipErrorInvalidValue;
         if (!c->fn[PRO_LNA]) return hipErrorNotSupported;
@@ -2801,7 +2965,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
         lds = c->lds + (size_t)ks * 2 * 256 * sizeof(float) + (size_t)c->bm * 2 * sizeof(float);
     }
     if (p.pro_act == PRO_LNA) lds = c->lds + (size_t)c->bm * 2 * sizeof(float);     // + row statistics [BM][2]
-    if (c->x6 && (!p.W3 || (p.K & 7) || (p.ldw & 7) || p.pro_act >= PRO_LN)) return hipErrorInvalidValue;
+    if (c->x6 && (!p.W3 || (p.K & 7) || (p.ldw & 7) || (p.pro_act >= PRO_LN && p.pro_act != PRO_LNX))) return hipErrorInvalidValue;
     if (c->x6_ks && (p.taps != 1 || p.K % (BK * c->x6_ks) != 0)) return hipErrorInvalidValue;
     if (c->x6 && p.w3_plane == 0) p.w3_plane = (long long)p.N * p.ldw;
     if (c->win_qs) {
@@ -2809,13 +2973,14 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
         const int wrp = (c->bm + (p.taps - 1) * p.dil + 7) & ~7;
         lds = c->lds + (size_t)c->win_qs * wrp * BK * sizeof(float);
     }
-    void (*fn)(GemmP) = c->fn[p.pro_act];
+    void (*fn)(GemmP) = c->fn[fi];
     if (!fn) return hipErrorNotSupported;           // retired configuration / no variant for this prologue
     {
         if (c->win_qs) lds_attr = c->lds + (size_t)c->win_qs * ((c->bm + 64 + 7) & ~7) * BK * sizeof(float);
-        hipError_t e = dyn_lds_once(g_attr_done[idx][p.pro_act], reinterpret_cast<const void*>(fn), c->win_qs ? lds_attr : lds);
+        hipError_t e = dyn_lds_once(g_attr_done[idx][fi], reinterpret_cast<const void*>(fn), c->win_qs ? lds_attr : lds);
         if (e != hipSuccess) return e;
     }
+    if (opts) { opts->last_stat_nt = p.stat_nt; opts->last_stat_w = p.stat_w; }
     const int tiles = ((p.M + c->bm - 1) / c->bm) * ((p.N + c->bn - 1) / c->bn);
     p.w_nt = (o.nt_weights && (p.M + c->bm - 1) / c->bm <= o.nt_row_tiles) ? 1 : 0;
     p.epi_t4 = o.epi_t4 ? 1 : 0;

@@ -275,7 +275,7 @@ struct Loader {
                         s[n] = (float)ss;
                         c[n] = (float)cc;
                     }
-                    Wl = upload(wl); sv = upload(s); cv = upload(c);
+                    Wl = upload(wl, true); sv = upload(s); cv = upload(c);      // + bf16 planes: the pair-fed form runs on the x6 tiles
                 };
                 fold(qkv, bqkv, get(p + ".norm1.weight", {d}).data, get(p + ".norm1.bias", {d}).data, 3 * d, w.wqkv_l, w.sqkv,
                      w.cqkv);

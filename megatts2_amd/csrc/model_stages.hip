@@ -123,6 +123,14 @@ static void linear(const Ctx& c, const float* x, int ldx, int M, const float* W,
 //     GEMM's prologue while its first operand chunks are in flight, rstd * (acc - mean * s) + c in its epilogue;
 //   prologue  (opts.lnfuse): one launch, fragments normalised on the fly (slower K loop, two smallest tiles only);
 //   plain: launch_layernorm into `h_scratch` + a GEMM.
+// What a layer hands to the next LayerNorm about the residual stream x (AR step forms below):
+//   S > 0    - a residual update not yet applied: x += bias + sum_g parts[g] (split-K through the LayerNorm);
+//   stat     - x is final and the GEMM that wrote it left its row statistics as (mean, M2) pairs per wave tile
+//              (GemmP::stat_out): the consuming LN -> Linear pair runs as ONE pair-fed algebraic-LayerNorm GEMM.
+struct Pending {
+    const float* parts = nullptr; long long pstride = 0; int S = 0; const float* bias = nullptr;
+    const float* stat = nullptr; int stat_nt = 0, stat_w = 0;
+};
 struct LnOps {                 // operands of one LN -> Linear pair, rows [n0, n0 + N) of the weight matrix
     const float *g, *b, *W, *bias;        // LayerNorm affine, Linear weight / bias
     const float *Wl, *s, *c;              // folded operands (nullptr: not available)
@@ -133,7 +141,7 @@ static LnOps ln_ops(const float* g, const float* b, const float* W, const float*
                  c ? c + n0 : nullptr};
 }
 static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, int shift0, int M, const LnOps& w, int N,
-                      int K, float* y, int ldy, float* h_scratch, int epi_act = ACT_NONE) {
+                      int K, float* y, int ldy, float* h_scratch, int epi_act = ACT_NONE, const Pending* st = nullptr) {
     GemmP p{};
     p.X = x; p.ldx = ldx; p.Rx = Rx; p.a_mul = a_mul ? a_mul : 1; p.shift0 = shift0; p.taps = 1; p.dil = 1; p.Cin = K;
     p.K = K; p.W = w.W; p.ldw = K; p.bias = w.bias; p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.groups = 1; p.out_scale = 1.0f;
@@ -151,6 +159,16 @@ static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, 
             if (e == hipSuccess) return;
             if (e != hipErrorNotSupported) MT2_HIP(e);
         }
+    }
+    if (st && st->stat && st->stat_nt > 0 && c.m.opts.ln_pairs && w.Wl && c.m.opts.force_cfg < 0) {
+        // the rows' statistics came with them (pairs from the producer GEMM's epilogue): algebraic LayerNorm with NO pass
+        // over K - rstd * (x W'^T - mean * s) + c on the x6 tiles; a tile without that form answers NotSupported
+        GemmP q = p;
+        q.pro_act = 5; q.W = w.Wl; q.bias = w.c; q.ln_g = w.s; q.ln_stat = st->stat; q.ln_nt = st->stat_nt; q.ln_w = st->stat_w;
+        attach_planes(c.m, q);
+        const hipError_t e = launch_gemm(q, c.s, &c.m.opts);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotSupported) MT2_HIP(e);
     }
     if (c.m.opts.lnalg && w.Wl && K <= 1024) {
         p.pro_act = 4; p.W = w.Wl; p.bias = w.c; p.ln_g = w.s;
@@ -252,7 +270,7 @@ struct AttnGeom {
     const int* start = nullptr; const int* len = nullptr;
     int u_stride = 0, u_len = 0, B = 0, max_len = 0;
 };
-struct EncScratch { float *h, *qkv, *att, *f, *parts; };
+struct EncScratch { float *h, *qkv, *att, *f, *parts, *stat; };
 static EncScratch enc_scratch(const Ctx& c, const EncW& e, int M) {
     EncScratch s;
     s.h = c.ws.get<float>((size_t)M * e.d);
@@ -262,6 +280,7 @@ static EncScratch enc_scratch(const Ctx& c, const EncW& e, int M) {
     // split-K slabs [S][M, d]: the f32 rule of choose_split keeps tiles(32x64) * S <= 256 (S * M * d <= 256 * 32 * 64 *
     // d / 64); the x6 rule splits at most 8 ways at any M
     s.parts = c.ws.get<float>(std::max((size_t)256 * 32 * 64 + (size_t)16 * 32 * e.d, (size_t)8 * M * e.d));
+    s.stat = c.ws.get<float>((size_t)M * 64);      // row statistics handed from GEMM to GEMM: <= 32 (mean, M2) pairs per row
     return s;
 }
 static void attention_self(const Ctx& c, const EncW& e, const AttnGeom& g, const float* qkv, float* att) {
@@ -306,9 +325,6 @@ static void encoder_layer(const Ctx& c, const EncW& e, const EncLayerW& w, float
 // operands and writes a raw partial slab) and the NEXT LayerNorm - a launch the layer has anyway - sums the
 // slabs in fixed order, adds bias and residual, writes the residual stream and its normalisation
 // (launch_ln_reduce).  Deterministic, no extra launch, no inter-workgroup hand-off.
-struct Pending {              // a residual update not yet applied: x += bias + sum_g parts[g]
-    const float* parts = nullptr; long long pstride = 0; int S = 0; const float* bias = nullptr;
-};
 static int choose_split(const Ctx& c, int M, int N, int K) {
     if (!c.m.opts.splitk) return 1;
     // a split GEMM hands its reduction to a stand-alone LayerNorm launch, which the LayerNorm-prologue GEMM
@@ -362,26 +378,43 @@ static void ln_pending(const Ctx& c, float* x, int d, int M, const Pending& in, 
 }
 // everything after attention for M full rows: x += out_proj(att); h = LN2(x); f = relu(ff0(h));
 // x += ff1(f) - the last update is returned as pending when it was split
+// x += a @ W^T + b (residual update in the GEMM's epilogue); with ln_pairs the epilogue also leaves the row statistics of the
+// new x as pairs in `stat` where the chosen tile can - the returned Pending says whether it did
+static Pending linear_residual(const Ctx& c, const float* a, int lda, int M, const float* W, const float* b, int N, int K,
+                               float* x, float* stat) {
+    GemmP p{};
+    p.X = a; p.ldx = lda; p.Rx = M; p.Cin = K; p.W = W; p.bias = b; p.R = x; p.ldr = N; p.C = x; p.ldc = N; p.M = M; p.N = N;
+    const bool want = c.m.opts.ln_pairs > 0 && stat != nullptr && M > 64 && c.m.opts.force_cfg < 0;
+    if (want) p.stat_out = stat;
+    gemm(c, p);
+    Pending r{};
+    if (want && c.m.opts.last_stat_nt > 0) { r.stat = stat; r.stat_nt = c.m.opts.last_stat_nt; r.stat_w = c.m.opts.last_stat_w; }
+    return r;
+}
 static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int M, const float* att,
                              const EncScratch& s) {
     const int d = e.d;
-    const int S1 = choose_split(c, M, d, d);
+    // ln_pairs = 2: the residual GEMMs with a short K chain (<= 1024) are not K-split any more - a split hands its reduction
+    // to a LayerNorm launch, the un-split GEMM hands the statistics to the next GEMM instead
+    const bool unsplit = c.m.opts.ln_pairs >= 2 && M > 64 && c.m.opts.force_cfg < 0;
+    int S1 = choose_split(c, M, d, d);
+    if (unsplit && d <= 1024) S1 = 1;
     if (S1 > 1) {
         linear_splitk(c, att, d, M, w.wo, d, d, S1, s.parts);
         Pending p1{s.parts, (long long)M * d, S1, w.bo};
         ln_pending(c, x, d, M, p1, w.ln2g, w.ln2b, s.h);
         linear(c, s.h, d, M, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, nullptr, 0, nullptr, ACT_RELU);
     } else {
-        linear(c, att, d, M, w.wo, w.bo, d, d, x, d, x, d);
-        ln_linear(c, x, d, M, 1, 0, M, ln2_ff0(w, d), e.ff, d, s.f, e.ff, s.h, ACT_RELU);   // LN2 -> ff.0
+        const Pending p1 = linear_residual(c, att, d, M, w.wo, w.bo, d, d, x, s.stat);                 // x += out_proj(att)
+        ln_linear(c, x, d, M, 1, 0, M, ln2_ff0(w, d), e.ff, d, s.f, e.ff, s.h, ACT_RELU, &p1);         // LN2 -> ff.0
     }
-    const int S2 = choose_split(c, M, d, e.ff);
+    int S2 = choose_split(c, M, d, e.ff);
+    if (unsplit && e.ff <= 1024) S2 = 1;
     if (S2 > 1) {
         linear_splitk(c, s.f, e.ff, M, w.ff1w, d, e.ff, S2, s.parts);
         return Pending{s.parts, (long long)M * d, S2, w.ff1b};
     }
-    linear(c, s.f, e.ff, M, w.ff1w, w.ff1b, d, e.ff, x, d, x, d);
-    return Pending{};
+    return linear_residual(c, s.f, e.ff, M, w.ff1w, w.ff1b, d, e.ff, x, s.stat);                      // x += ff.3(f)
 }
 
 // MIDDLE layer over M = A*n compact rows
@@ -393,7 +426,7 @@ static Pending encoder_layer_ar(const Ctx& c, const EncW& e, const EncLayerW& w,
         ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
         linear(c, s.h, d, M, w.wqkv, w.bqkv, 3 * d, d, s.qkv, 3 * d);
     } else {
-        ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d), 3 * d, d, s.qkv, 3 * d, s.h);     // LN1 -> QKV
+        ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d), 3 * d, d, s.qkv, 3 * d, s.h, ACT_NONE, &in);     // LN1 -> QKV
     }
     attention_self(c, e, g, s.qkv, s.att);
     return ar_layer_tail(c, e, w, x, M, s.att, s);
@@ -419,7 +452,7 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
             ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
             linear(c, s.h, d, M, w.wqkv, w.bqkv, 3 * d, d, qkv, 3 * d);
         } else {
-            ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d), 3 * d, d, qkv, 3 * d, s.h);
+            ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d), 3 * d, d, qkv, 3 * d, s.h, ACT_NONE, &in);
         }
         a.Q = qkv + (size_t)(n - 1) * 3 * d; a.ldq = 3 * d; a.u_qstride = n;      // query of sequence j = row j * n + n - 1
         a.K = qkv + d; a.ldk = 3 * d; a.V = qkv + 2 * d; a.ldv = 3 * d;
@@ -432,8 +465,8 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
         p.C = q; p.ldc = d; p.M = A; p.N = d;
         gemm(c, p);
     } else {   // LN1 fused into both consumers: K|V of all rows, Q of the last row of each sequence
-        ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d, d), 2 * d, d, kv, 2 * d, s.h);
-        ln_linear(c, x, d, M, n, n - 1, A, ln1_qkv(w, d), d, d, q, d, s.f);
+        ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d, d), 2 * d, d, kv, 2 * d, s.h, ACT_NONE, &in);
+        ln_linear(c, x, d, M, n, n - 1, A, ln1_qkv(w, d), d, d, q, d, s.f, ACT_NONE, &in);
     }
     if (!a.Q) {
         a.Q = q; a.ldq = d; a.K = kv; a.ldk = 2 * d; a.V = kv + d; a.ldv = 2 * d;

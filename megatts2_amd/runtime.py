@@ -654,6 +654,39 @@ def op_conv_x6(X, W, bias=None, R=None, valid=None, shift0=0, taps=1, dil=1, Cin
     return out
 
 
+def op_gemm_x6_ln(X, W, bias=None, R=None, M=None, a_mul=1, shift0=0, epi_act=ACT_NONE, force_cfg=-1, want_stats=False,
+                  ln=None, eps=1e-5):
+    """mt2_op_gemm_x6_ln: one linear launch on an x6 tile.  want_stats -> also returns (pairs [M, nt, 2], pair width) written by
+    the epilogue (nt = 0 rows when the tile has none).  ln = (gamma, beta, pairs [rows, nt, 2], pair width): LayerNorm(X) @ W^T + b
+    in the pair-fed algebraic form - gamma / beta are folded into the operands here (float64 sums, as the model loader does)."""
+    import torch
+    lib = load_library()
+    K, N = X.shape[1], W.shape[0]
+    M = M or X.shape[0]
+    dev = X.device
+    out = torch.empty(M, N, device=dev, dtype=torch.float32)
+    stat = torch.zeros(M, 32, 2, device=dev, dtype=torch.float32) if want_stats else None
+    nt, pw = C.c_int32(0), C.c_int32(0)
+    ln_stat, ln_nt, ln_w, ln_s = None, 0, 0, None
+    if ln is not None:
+        gamma, beta, pairs, ln_w = ln
+        Wd = W.double().cpu()
+        Wl = (W.cpu() * gamma.cpu()[None, :]).to(torch.float32)
+        ln_s = Wl.double().sum(1).to(torch.float32).to(dev)
+        bias = (Wd @ beta.double().cpu() + (bias.double().cpu() if bias is not None else 0.0)).to(torch.float32).to(dev)
+        W = Wl.to(dev)
+        ln_stat = pairs.contiguous()
+        ln_nt = pairs.shape[1]
+    W = W.contiguous()
+    W3 = split_bf16x3(W).to(dev)
+    _check(lib.mt2_op_gemm_x6_ln(_stream(), _ptr(X), K, X.shape[0], a_mul, shift0, _ptr(W), _ptr(W3), _ptr(bias), _ptr(R),
+                                 R.shape[1] if R is not None else 0, _ptr(out), N, M, N, K, epi_act, force_cfg, _ptr(stat),
+                                 C.byref(nt), C.byref(pw), _ptr(ln_stat), ln_nt, int(ln_w), _ptr(ln_s), C.c_float(eps)))
+    if want_stats:
+        return out, stat.view(-1)[:M * nt.value * 2].reshape(M, nt.value, 2).clone(), pw.value      # dense [M][nt][2]
+    return out
+
+
 def op_ln_gemm(X, gamma, beta, W, bias=None, M=None, a_mul=1, shift0=0, eps=1e-5, epi_act=ACT_NONE, force_cfg=-1,
                algebraic=False):
     """LN(X) @ W^T + b in one launch.  algebraic=True folds gamma / beta into the operands on the host (float64 sums,

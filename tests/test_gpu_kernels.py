@@ -542,6 +542,61 @@ def test_gemm_with_algebraic_layernorm(rt, cfg, M, N, K):
         assert rel(out2, ref[2::3][:Ms]) < 2e-5
 
 
+@pytest.mark.parametrize("cfg", [55, 63, 64, 84, 85, 86, -1])
+@pytest.mark.parametrize("M,d,N2", [(200, 768, 1024), (1120, 768, 2304), (333, 1024, 4096), (97, 1024, 1024)])
+def test_gemm_layernorm_statistics_handed_from_gemm_to_gemm(rt, cfg, M, d, N2):
+    """The AR layers' stand-alone LayerNorm launches (round 5; modules/transformer.py:88-102: `x = x + out_proj(att)` then
+    `norm2(x)` -> ff.0): the residual GEMM's epilogue writes, per row and per wave tile, the (mean, M2) pair of the NEW x, and
+    the consuming GEMM runs LayerNorm algebraically on those pairs - rstd * (x W'^T - mean * s) + c - with no pass over K.
+    Producer: x_new and every pair against float64; consumer: against float64 LayerNorm + linear, with the error of the
+    two-launch form (LayerNorm kernel + the same tile) as the yardstick; the strided last-row gather; rows with a common offset."""
+    rng = np.random.default_rng(cfg + 7 * M + d)
+    att = rng.standard_normal((M, d)).astype(np.float32)
+    x = (rng.standard_normal((M, d)) * 2.0 + 0.5).astype(np.float32)
+    x[::5] += 6.0                                        # |mean| / std ~ 3 on some rows (production: <= 1)
+    Wo = (rng.standard_normal((d, d)) / math.sqrt(d)).astype(np.float32)
+    bo = rng.standard_normal(d).astype(np.float32)
+    try:
+        xn, pairs, pw = rt.op_gemm_x6_ln(dev(att), dev(Wo), dev(bo), R=dev(x), force_cfg=cfg, want_stats=True)
+    except rt.NativeError as e:                          # K-split tile whose K granularity does not divide d
+        pytest.skip(str(e)[:80])
+    xn = xn.cpu().numpy()
+    ref_x = att.astype(np.float64) @ Wo.T.astype(np.float64) + bo + x
+    assert rel(xn, ref_x) < 2e-6
+    if cfg == -1 and pairs.shape[1] == 0:
+        pytest.skip("the automatic tile choice for this shape has no statistics epilogue (callers fall back)")
+    nt = pairs.shape[1]
+    assert pw in (32, 64) and nt == d // pw
+    pairs_h = pairs.cpu().numpy().astype(np.float64)
+    tiles = xn.astype(np.float64).reshape(M, nt, pw)     # statistics of what was WRITTEN (f32 values)
+    assert np.abs(pairs_h[:, :, 0] - tiles.mean(2)).max() < 5e-6 * (1 + np.abs(tiles.mean(2)).max())
+    m2 = ((tiles - tiles.mean(2, keepdims=True)) ** 2).sum(2)
+    assert np.abs(pairs_h[:, :, 1] - m2).max() < 2e-5 * m2.max()
+    # consumer
+    g = rng.standard_normal(d).astype(np.float32)
+    b = rng.standard_normal(d).astype(np.float32)
+    W = (rng.standard_normal((N2, d)) / math.sqrt(d)).astype(np.float32)
+    bias = rng.standard_normal(N2).astype(np.float32)
+    x64 = xn.astype(np.float64)
+    ln = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * g + b
+    ref = np.maximum(ln @ W.T.astype(np.float64) + bias, 0)
+    dxn = dev(xn)
+    out = rt.op_gemm_x6_ln(dxn, dev(W), dev(bias), epi_act=rt.ACT_RELU, force_cfg=cfg, ln=(dev(g), dev(b), pairs, pw)).cpu().numpy()
+    h = rt.op_layernorm(dxn, dev(g), dev(b))             # the two-launch form on the same tile: the yardstick
+    two = rt.op_gemm_x6_ln(h, dev(W), dev(bias), epi_act=rt.ACT_RELU, force_cfg=cfg).cpu().numpy()
+    e1, e2 = rel(out, ref), rel(two, ref)
+    assert e1 < 4e-6 and e1 < 4 * e2 + 2e-7, (e1, e2)
+    plain = np.ones(M, bool)
+    plain[::5] = False
+    assert rel(out[plain], ref[plain]) < 2e-6
+    # K | V of all rows and Q of the last row of each sequence read the same pairs: strided gather m -> 3 m + 2
+    Ms = (M - 3) // 3 + 1
+    out2 = rt.op_gemm_x6_ln(dxn, dev(W[:d]), dev(bias[:d]), M=Ms, a_mul=3, shift0=2, force_cfg=cfg,
+                            ln=(dev(g), dev(b), pairs, pw)).cpu().numpy()
+    ref2 = (ln @ W[:d].T.astype(np.float64) + bias[:d])[2::3][:Ms]
+    assert rel(out2, ref2) < 4e-6
+
+
 @pytest.mark.parametrize("C", [32, 64, 384, 512, 768, 1024])
 def test_layernorm(rt, C):
     rng = np.random.default_rng(C)

@@ -38,6 +38,11 @@ graph)
   # dependent-launch boundary replayed from a hipGraph vs launch by launch on a stream (tools/ubench/graph_chain.hip)
   timeout 120 variants/ubench/graph_chain > gpurun_out/ubench_graph.txt 2>&1
   echo "graph rc=$?"; cat gpurun_out/ubench_graph.txt ;;
+ab2)
+  # interleaved A/B of several option sets on one box, one after the other: AB2="ln_pairs=0 ln_pairs=2 x6_small_cfg=91"; WL2="C3 C2"
+  for wl in ${WL2:-C3}; do for o in ${AB2}; do
+    timeout 600 python bench.py --workload $wl --steps ${AB_STEPS:-6} --warmup 2 --no-cpu-baseline --no-roofline --ab $o 2>/dev/null | grep "^{" | tee -a gpurun_out/ab.txt
+  done; done ;;
 newtests)
   # this round's added parity tests only (TEST_K selects), before the whole suite is spent on them
   timeout 1500 python -m pytest tests/test_gpu_stages.py tests/test_gpu_kernels.py -m gpu -q --no-header -p no:cacheprovider --maxfail=10 -rf -k "${TEST_K:-exact_256 or in_flight or own_durations_end}" > gpurun_out/newtests.log 2>&1

@@ -5,7 +5,7 @@
 //   (a) launch by launch on one stream (the product's AR step chains today);
 //   (b) the same N launches captured once (hipStreamBeginCapture) and replayed with hipGraphLaunch;
 //   (c) a graph built node by node (hipGraphAddKernelNode, a linear dependency chain).
-// and with kernels that WORK for ~5 us (a dependent FMA chain), where every kernel also stamps s_memrealtime (100 MHz,
+// and with kernels that WORK for 2.5 ... 43 us (a dependent FMA chain), where every kernel also stamps s_memrealtime (100 MHz,
 // constant rate) at entry and exit: gap[i] = entry[i + 1] - exit[i] is the boundary itself, free of event overheads.
 // The one-utterance AR step is ~86 dependent launches: graphs of 86 nodes are measured too (replayed back to back).
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/graph_chain.hip -o variants/ubench/graph_chain && variants/ubench/graph_chain
@@ -74,7 +74,7 @@ int main() {
         med_kernel_us = k[k.size() / 2];
     };
     for (int N : {400, 86}) {
-        for (int iters : {0, 2600}) {              // 0: the trivial kernel of grid_sync.hip; 2600 x ~4 cycles ~ 5 us at 2.1 GHz
+        for (int iters : {0, 150, 300, 600, 2600}) {   // 0: the trivial kernel of grid_sync.hip; a dependent FMA costs ~16.5 ns here: 2.5 / 5 / 10 / 43 us
             // ---- (a) stream
             for (int i = 0; i < 16; ++i) launch_i(i, buf, NEL, stamp, iters, s);
             CK(hipStreamSynchronize(s));
@@ -155,7 +155,7 @@ int main() {
             CK(hipGraphExecDestroy(ex2));
             CK(hipGraphDestroy(g2));
             std::printf("N = %3d dependent launches, kernel body %s (median in-kernel time %.2f us):\n", N,
-                        iters ? "~5 us of dependent FMAs" : "trivial", ka);
+                        iters ? "a chain of dependent FMAs" : "trivial", ka);
             std::printf("  (a) stream, launch by launch : %.2f us per launch   median gap exit -> next entry %.2f us\n", best_a, ga);
             std::printf("  (b) captured graph, replayed : %.2f us per launch   median gap %.2f us   (4 replays back to back: %.2f us per launch)\n",
                         best_b, gb, best_b2);

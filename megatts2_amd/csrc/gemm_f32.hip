@@ -98,37 +98,42 @@ __device__ __forceinline__ void emit_row_pairs(const GemmP& p, float (&sv)[NE], 
         }
     }
 }
-// Consumer (pro_act == PRO_LNX): mean / rstd of source row `src` from its ln_nt pairs of ln_w columns each.  Lane l and lane
-// l ^ 32 work on the SAME row (row = f(lane & 31)) and each takes every other float4 (two pairs) - all loads of a lane go out
-// together (one memory round trip, overlapped with the ring prologue), the halves meet with one shuffle, the second pass
-// (Chan: M2 = sum M2_t + w * sum (mean_t - mean)^2) runs on the registers.  ln_nt even, <= 32.
-__device__ __forceinline__ void lnx_row_stats(const GemmP& p, int m, int lane, float& mu, float& rs) {
+// Consumer (pro_act == PRO_LNX): mean / rstd of source row `src` from its ln_nt pairs of ln_w columns each.  LPR lanes work
+// on the SAME row (`part` = 0 .. LPR - 1 of the row's lane group, `xm` = the distance between the group's lanes: 1 for
+// adjacent lanes, 32 when lane l and l ^ 32 pair up) and each takes every LPR-th float4 (two pairs) - all loads of a lane
+// go out together (one memory round trip, overlapped with the ring prologue), the parts meet in a butterfly, the second
+// pass (Chan: M2 = sum M2_t + w * sum (mean_t - mean)^2) runs on the registers.  ln_nt even, <= 32.
+template <int LPR>
+__device__ __forceinline__ void lnx_row_stats(const GemmP& p, int m, int part, int xm, float& mu, float& rs) {
+    constexpr int NQ = 16 / LPR;                          // float4 loads per lane: 16 pairs-of-pairs at most per row
     int src = -1;
     if (m < p.M) src = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
     const bool ok = (unsigned)src < (unsigned)p.Rx;
-    const int nq = p.ln_nt >> 1, h = lane >> 5;
+    const int nq = p.ln_nt >> 1;
     const float4* __restrict__ pr = reinterpret_cast<const float4*>(p.ln_stat) + (long long)(ok ? src : 0) * nq;
-    float4 q[8];
+    float4 q[NQ];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int qi = j * 2 + h;
+    for (int j = 0; j < NQ; ++j) {
+        const int qi = j * LPR + part;
         q[j] = (ok && qi < nq) ? pr[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     float sm = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sm += q[j].x + q[j].z;
-    sm += __shfl_xor(sm, 32);
+    for (int j = 0; j < NQ; ++j) sm += q[j].x + q[j].z;
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) sm += __shfl_xor(sm, o * xm);
     const float mean = sm / (float)p.ln_nt, w = (float)p.ln_w;
     float m2 = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int qi = j * 2 + h;
+    for (int j = 0; j < NQ; ++j) {
+        const int qi = j * LPR + part;
         if (qi < nq) {
             const float d0 = q[j].x - mean, d1 = q[j].z - mean;
             m2 += (q[j].y + w * d0 * d0) + (q[j].w + w * d1 * d1);
         }
     }
-    m2 += __shfl_xor(m2, 32);
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) m2 += __shfl_xor(m2, o * xm);
     mu = ok ? mean : 0.0f;
     rs = ok ? 1.0f / sqrtf(m2 / ((float)p.ln_nt * w) + p.ln_eps) : 0.0f;
 }
@@ -502,6 +507,21 @@ __device__ __forceinline__ f32x4 lds_read_b128(unsigned byte_addr) {
     f32x4 v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr) : "memory");
     return v;
+}
+
+// ... with a constant byte offset in the instruction's 16-bit offset field: the wave tile's second 32-row block, the weight planes
+// and the column tiles are constants of the tile shape - folding them into the immediate takes a v_add (and its register) per
+// read out of the K loop (round 5: the 256x128 loader tile sat at its 168-VGPR cap and reloaded a spilled address every chunk)
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read_b128_imm(unsigned byte_addr) {
+    static_assert(OFF >= 0 && OFF < 65536 && (OFF & 15) == 0, "ds_read_b128 immediate offset");
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
 }
 
 // issue priority of a LOADER wave (GemmP::ldr_prio, 0..3; the immediate of s_setprio must be a constant).  Round 4
@@ -1872,12 +1892,24 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
     if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     // pair-fed algebraic LayerNorm and row-statistics epilogue (GemmP::ln_stat / stat_out): the plain 128x128 tile only
-    // (one 32-row block per wave, epilogue operands prefetched, ACT_NONE instantiation)
-    constexpr bool LNXOK = PRET && TM == 1 && PRO == ACT_NONE && !XP && !FR;
-    float ln_mu = 0.0f, ln_rs = 0.0f;
+    // (one 32-row block per wave, epilogue operands prefetched) in its PRO_LNX instantiation - the K loop of ACT_NONE, a
+    // kernel of its own so that the plain launches keep their register allocation (the tile sits at its 168-VGPR cap)
+    constexpr bool LNXOK = PRET && TM == 1 && PRO == PRO_LNX && !XP && !FR;
     const bool lnx = LNXOK && p.pro_act == PRO_LNX;
+    // [BM][2] (mean, rstd) behind the ring: the NW compute waves share the merge - 64 NW / BM adjacent lanes per row, <= 16 / LPR
+    // float4 loads each (this tile sits at its 168-register cap with the epilogue operands in flight) - and every wave reads
+    // its 32 rows back in the epilogue (the K loop's barriers order the two)
+    [[maybe_unused]] float* lnstat = reinterpret_cast<float*>(ring + NST * STAGE);
     if constexpr (LNXOK) {
-        if (lnx) lnx_row_stats(p, m0 + wm * WTM + (lane & 31), lane, ln_mu, ln_rs);
+        if (lnx) {
+            constexpr int LPR = NW * 64 / BM;
+            static_assert(LPR >= 1 && LPR <= 16 && (LPR & (LPR - 1)) == 0, "lanes per row");
+            const int tc = wave * 64 + lane, row = tc / LPR;
+            float mu, rs;
+            lnx_row_stats<LPR>(p, m0 + row, tc % LPR, 1, mu, rs);
+            if (tc % LPR == 0) { lnstat[2 * row] = mu; lnstat[2 * row + 1] = rs; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the write is in LDS before this wave's first s_barrier
+        }
     }
 
     f32x16 acc[TM][TN];
@@ -1910,18 +1942,17 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     u32x4 pln[2][3];
     constexpr int F = 2 * TM, NMF = 6 * TN, VPM = (44 + NMF - 1) / NMF;
     auto fetch = [&](int b, unsigned sa, unsigned sb) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            ra[b][i][0] = lds_read_b128(sa + koffa[b][0] + i * 32 * BK * 4);
-            ra[b][i][1] = lds_read_b128(sa + koffa[b][1] + i * 32 * BK * 4);
-        }
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
-                rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
-            }
+        // three address registers per k-block; everything that is a constant of the tile shape rides in the offset field
+        const unsigned va0 = sa + koffa[b][0], va1 = sa + koffa[b][1], vb = sb + koffb[b];
+        static_for(std::make_integer_sequence<int, TM>{}, [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            ra[b][i][0] = lds_read_b128_imm<i * 32 * BK * 4>(va0);
+            ra[b][i][1] = lds_read_b128_imm<i * 32 * BK * 4>(va1);
+        });
+        static_for(std::make_integer_sequence<int, 3 * TN>{}, [&](auto ic) {
+            constexpr int pl = decltype(ic)::value / TN, j = decltype(ic)::value % TN;
+            rb[b][pl][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<(pl * BN + j * 32) * 64>(vb));
+        });
     };
     // products t0 <= t < t1 of fragment (b, i) with the column tiles of k-block b
     auto products = [&](int b, int i, const u32x4* pp, int t0, int t1) {
@@ -2266,8 +2297,8 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
                 const float s_n = n < p.N ? p.ln_g[n] : 0.0f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int r = (e & 3) + 8 * (e >> 2) + 4 * half;
-                    acc[0][j][e] = __shfl(ln_rs, r) * (acc[0][j][e] - __shfl(ln_mu, r) * s_n);
+                    const float2 st2 = reinterpret_cast<const float2*>(lnstat)[wm * WTM + (e & 3) + 8 * (e >> 2) + 4 * half];
+                    acc[0][j][e] = st2.y * (acc[0][j][e] - st2.x * s_n);
                 }
             }
         }
@@ -2386,11 +2417,12 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x6_ks_kernel(
     const int wm = wave / WGN, wn = wave % WGN;
     EpiPre<EPG> pre;
     epi_prefetch<EPG>(p, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
-    // pair-fed algebraic LayerNorm (PRO_LNX, the ACT_NONE instantiation only): lane l holds mean / rstd of row l & 31 of
-    // the wave's 32-row block, merged from the producer's pairs while the first ring stages are in flight
+    // pair-fed algebraic LayerNorm and row-statistics epilogue: the PRO_LNX instantiation (K loop of ACT_NONE; its own kernel so
+    // that the plain launches keep their register allocation).  Lane l holds mean / rstd of row l & 31 of the wave's 32-row
+    // block, merged from the producer's pairs while the first ring stages are in flight
     float ln_mu = 0.0f, ln_rs = 0.0f;
-    const bool lnx = PRO == ACT_NONE && p.pro_act == PRO_LNX;
-    if (lnx) lnx_row_stats(p, m0 + wm * 32 + (lane & 31), lane, ln_mu, ln_rs);
+    const bool lnx = PRO == PRO_LNX && p.pro_act == PRO_LNX;
+    if (lnx) lnx_row_stats<2>(p, m0 + wm * 32 + (lane & 31), lane >> 5, 32, ln_mu, ln_rs);      // lanes l and l ^ 32 share a row
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
@@ -2477,7 +2509,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x6_ks_kernel(
                 out[i] = __shfl(ln_rs, r) * (out[i] - __shfl(ln_mu, r) * s_n);
             }
         }
-        if (p.stat_out) epilogue_pre<EPG, true>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
+        if (PRO == PRO_LNX && p.stat_out) epilogue_pre<EPG, PRO == PRO_LNX>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
         else epilogue_pre<EPG>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
     } else {
         float out[16];
@@ -2492,7 +2524,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x6_ks_kernel(
                 out[e] = __shfl(ln_rs, r) * (out[e] - __shfl(ln_mu, r) * s_n);
             }
         }
-        if (p.stat_out) epilogue_pre<16, true>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, 0);
+        if (PRO == PRO_LNX && p.stat_out) epilogue_pre<16, PRO == PRO_LNX>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, 0);
         else epilogue_pre<16>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, 0);
     }
 }
@@ -2505,7 +2537,8 @@ struct TileCfg {
     int bm, bn, threads;
     size_t lds;               // window configurations: the ring part only (the window depends on taps and dilation)
     const char* name;
-    void (*fn[5])(GemmP);     // indexed by the prologue: none / relu / leaky relu / LayerNorm / algebraic LayerNorm (nullptr: no variant)
+    void (*fn[6])(GemmP);     // indexed by the prologue: none / relu / leaky relu / LayerNorm / algebraic LayerNorm / none + pair statistics
+                              // (PRO_LNX: pair-fed algebraic LayerNorm and the row-statistics epilogue) - nullptr: no variant
     int win_qs = 0;           // > 0: window convolution for Cin = Cout = 32 * win_qs
     bool x6 = false;          // window convolution on the bf16 pipe (3-way split, 6 products): needs GemmP::W3
     int x6_ks = 0;            // > 0: x6 K-split tile (gemm_x6_ks_kernel): linear layers with K a multiple of 32 * x6_ks
@@ -2556,8 +2589,20 @@ struct TileCfg {
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),       \
       "x6ldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
       { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
-        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true, 0,                 \
-      ((BM_) / (WM_) == 32 && (BN_) / (WN_) <= 64) ? (BN_) / (WN_) : 0 }
+        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
+// ... with the PRO_LNX variant (LayerNorm statistics handed from GEMM to GEMM): the production AR tiles only
+#define MT2_GX6L_S(BM_, BN_, WM_, WN_, NL_, NST_)                                                              \
+    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),       \
+      "x6ldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
+      { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
+        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr,                               \
+        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, PRO_LNX> }, 0, true, 0, (BN_) / (WN_) }
+#define MT2_GX6K_S(BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                         \
+    { BM_, BN_, (WM_* WN_ * KS_ + NL_) * 64, (size_t)KS_ * NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024), \
+      "x6ks" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "+" #NL_ "_s" #NST_,                                         \
+      { gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_NONE>, gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_RELU>, \
+        gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr,                           \
+        gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, PRO_LNX> }, 0, true, KS_, 32 }
 #define MT2_WX6L(QS_, BM_, BN_, WM_, WN_, NST_, NL_)                                                         \
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * (((3 * BN_ / 16 + NL_ - 1) / NL_) * NL_ * 1024),                 \
       "x6winl" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                           \
@@ -2584,7 +2629,7 @@ struct TileCfg {
     { BM_, BN_, (WM_* WN_ * KS_ + NL_) * 64, (size_t)KS_ * NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024), \
       "x6ks" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "+" #NL_ "_s" #NST_,                                         \
       { gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_NONE>, gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_RELU>, \
-        gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true, KS_, 32 }
+        gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true, KS_ }
 #define MT2_WX6(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024),   \
       "x6win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                     \
@@ -2656,7 +2701,7 @@ static const TileCfg kCfgs[] = {
     MT2_GX6L(256, 128, 4, 2, 2, 2),  // 52: 8 + 2
     MT2_RETIRED("x6ldr128x128_4x2+4_s2"),  // 53: 8 + 4
     MT2_RETIRED("x6ldr128x128_4x2+2_s2"),  // 54: 8 + 2
-    MT2_GX6L(128, 128, 4, 2, 4, 3),  // 55: 8 + 4, 3-deep ring (120 KiB)
+    MT2_GX6L_S(128, 128, 4, 2, 4, 3),  // 55: 8 + 4, 3-deep ring (120 KiB); + the PRO_LNX variant
     MT2_RETIRED("x6ldrx128x128_4x2+4_s3"),    // 56: the same with cross-chunk prefetch of the first fragments
     MT2_RETIRED("x6ldrx128x128_4x2+2_s3"),    // 57: 8 + 2 loader waves
     // v3c: x6 window convolutions with loader waves
@@ -2696,9 +2741,9 @@ static const TileCfg kCfgs[] = {
     MT2_RETIRED("x6ks32x64_1x2_k4+2_s2"),    // 81: 79 with 2 loader waves
     MT2_GX6K(32, 32, 1, 1, 8, 4, 2),    // 82: 8 K groups of one wave + 4 loader waves, 112 KiB: the 28 tile
     MT2_RETIRED("x6ks64x64_2x2_k2+4_s2"),    // 83: 80 with a 2-deep ring (80 KiB)
-    MT2_GX6K(32, 64, 1, 2, 4, 8, 2),    // 84: 79 with EIGHT loader waves (16 waves: a round's 64 pieces are 8 per loader)
-    MT2_GX6K(64, 64, 2, 2, 2, 8, 3),    // 85: 80 with eight loader waves (5 pieces per loader and round)
-    MT2_GX6K(32, 32, 1, 1, 8, 8, 2),    // 86: 82 with eight loader waves
+    MT2_GX6K_S(32, 64, 1, 2, 4, 8, 2),  // 84 (+ PRO_LNX): 79 with EIGHT loader waves (16 waves: a round's 64 pieces are 8 per loader)
+    MT2_GX6K_S(64, 64, 2, 2, 2, 8, 3),  // 85 (+ PRO_LNX): 80 with eight loader waves (5 pieces per loader and round)
+    MT2_GX6K_S(32, 32, 1, 1, 8, 8, 2),  // 86 (+ PRO_LNX): 82 with eight loader waves
     // names only: the weight-streaming kernel for M <= 64 rows lives in gemm_skinny.hip (launch_gemm routes to it)
     { 32, 32, 512, 0, "skinny32_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },    // 87
     { 64, 32, 512, 0, "skinny64_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },    // 88
@@ -2743,7 +2788,7 @@ const char* gemm_config_name(int idx) { return idx >= 0 && idx < kNumCfgs ? kCfg
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per-DEVICE state of the code object: a "done" mask per (configuration,
 // prologue) with one bit per device only saves the call; the benign race (two threads setting the same value) is harmless.
-static std::atomic<unsigned long long> g_attr_done[kNumCfgs][5];   // bit per device (dyn_lds_once)
+static std::atomic<unsigned long long> g_attr_done[kNumCfgs][6];   // bit per device (dyn_lds_once)
 
 // ---- launch trace (measurement only): HIP events around every GEMM launch, on the launch stream; the records
 // live in the EngineOpts of whoever asked for the trace (the model handle).
@@ -2932,18 +2977,18 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     }
     int idx = 0;
     const TileCfg* c = choose_cfg(p, o, &idx);
-    // variant index: the pair-fed algebraic LayerNorm is a run-time branch of the ACT_NONE instantiation (same K loop)
-    const int fi = p.pro_act == PRO_LNX ? 0 : p.pro_act;
-    if (p.pro_act == PRO_LNX && !c->stat_w) return hipErrorNotSupported;      // callers fall back to LayerNorm + GEMM
+    if (p.pro_act == PRO_LNX && !(c->stat_w && c->fn[PRO_LNX])) return hipErrorNotSupported;      // callers fall back to LayerNorm + GEMM
     if (p.stat_out) {       // row-statistics epilogue where the chosen tile has one; otherwise the launch simply writes none
         const int nt = c->stat_w ? p.N / c->stat_w : 0;
-        if (c->stat_w && p.groups == 1 && p.N % c->stat_w == 0 && nt >= 2 && nt <= 32 && (nt & 1) == 0 &&
-            ((((unsigned long long)p.stat_out) & 15) == 0)) {
+        if (c->stat_w && c->fn[PRO_LNX] && (p.pro_act == ACT_NONE || p.pro_act == PRO_LNX) && p.groups == 1 &&
+            p.N % c->stat_w == 0 && nt >= 2 && nt <= 32 && (nt & 1) == 0 && ((((unsigned long long)p.stat_out) & 15) == 0)) {
             p.stat_w = c->stat_w; p.stat_nt = nt;
         } else {
             p.stat_out = nullptr; p.stat_w = p.stat_nt = 0;
         }
     }
+    // variant index: pair statistics (consumer and / or producer side) run the PRO_LNX instantiation - the K loop of ACT_NONE
+    const int fi = (p.pro_act == PRO_LNX || p.stat_out) ? PRO_LNX : p.pro_act;
     if (p.pro_act == PRO_LNA) {     // algebraic LayerNorm: every LDS-DMA configuration has the variant
         if (p.taps != 1 || p.K > 1024 || !p.ln_g || p.groups != 1) return hipErrorInvalidValue;
         if (!c->fn[PRO_LNA]) return hipErrorNotSupported;
@@ -2965,6 +3010,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
         lds = c->lds + (size_t)ks * 2 * 256 * sizeof(float) + (size_t)c->bm * 2 * sizeof(float);
     }
     if (p.pro_act == PRO_LNA) lds = c->lds + (size_t)c->bm * 2 * sizeof(float);     // + row statistics [BM][2]
+    if (p.pro_act == PRO_LNX && !c->x6_ks) lds = c->lds + (size_t)c->bm * 2 * sizeof(float);     // likewise (loader-wave tiles)
     if (c->x6 && (!p.W3 || (p.K & 7) || (p.ldw & 7) || (p.pro_act >= PRO_LN && p.pro_act != PRO_LNX))) return hipErrorInvalidValue;
     if (c->x6_ks && (p.taps != 1 || p.K % (BK * c->x6_ks) != 0)) return hipErrorInvalidValue;
     if (c->x6 && p.w3_plane == 0) p.w3_plane = (long long)p.N * p.ldw;

@@ -160,7 +160,7 @@ static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, 
             if (e != hipErrorNotSupported) MT2_HIP(e);
         }
     }
-    if (st && st->stat && st->stat_nt > 0 && c.m.opts.ln_pairs && w.Wl && c.m.opts.force_cfg < 0) {
+    if (st && st->stat && st->stat_nt > 0 && c.m.opts.ln_pairs && w.Wl && c.m.opts.force_cfg < 0 && M <= c.m.opts.ln_pairs_maxm) {
         // the rows' statistics came with them (pairs from the producer GEMM's epilogue): algebraic LayerNorm with NO pass
         // over K - rstd * (x W'^T - mean * s) + c on the x6 tiles; a tile without that form answers NotSupported
         GemmP q = p;
@@ -384,7 +384,7 @@ static Pending linear_residual(const Ctx& c, const float* a, int lda, int M, con
                                float* x, float* stat) {
     GemmP p{};
     p.X = a; p.ldx = lda; p.Rx = M; p.Cin = K; p.W = W; p.bias = b; p.R = x; p.ldr = N; p.C = x; p.ldc = N; p.M = M; p.N = N;
-    const bool want = c.m.opts.ln_pairs > 0 && stat != nullptr && M > 64 && c.m.opts.force_cfg < 0;
+    const bool want = c.m.opts.ln_pairs > 0 && stat != nullptr && M > 64 && M <= c.m.opts.ln_pairs_maxm && c.m.opts.force_cfg < 0;
     if (want) p.stat_out = stat;
     gemm(c, p);
     Pending r{};
@@ -396,9 +396,9 @@ static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, fl
     const int d = e.d;
     // ln_pairs = 2: the residual GEMMs with a short K chain (<= 1024) are not K-split any more - a split hands its reduction
     // to a LayerNorm launch, the un-split GEMM hands the statistics to the next GEMM instead
-    const bool unsplit = c.m.opts.ln_pairs >= 2 && M > 64 && c.m.opts.force_cfg < 0;
+    const bool unsplit = c.m.opts.ln_pairs >= 2 && M > 64 && M <= c.m.opts.ln_pairs_maxm && c.m.opts.force_cfg < 0;
     int S1 = choose_split(c, M, d, d);
-    if (unsplit && d <= 1024) S1 = 1;
+    if (unsplit && d <= c.m.opts.ln_pairs_maxk) S1 = 1;
     if (S1 > 1) {
         linear_splitk(c, att, d, M, w.wo, d, d, S1, s.parts);
         Pending p1{s.parts, (long long)M * d, S1, w.bo};
@@ -409,7 +409,7 @@ static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, fl
         ln_linear(c, x, d, M, 1, 0, M, ln2_ff0(w, d), e.ff, d, s.f, e.ff, s.h, ACT_RELU, &p1);         // LN2 -> ff.0
     }
     int S2 = choose_split(c, M, d, e.ff);
-    if (unsplit && e.ff <= 1024) S2 = 1;
+    if (unsplit && e.ff <= c.m.opts.ln_pairs_maxk) S2 = 1;
     if (S2 > 1) {
         linear_splitk(c, s.f, e.ff, M, w.ff1w, d, e.ff, S2, s.parts);
         return Pending{s.parts, (long long)M * d, S2, w.ff1b};

@@ -130,7 +130,10 @@ struct EngineOpts {
     int ln_pairs = 1;            // AR layers with more than skinny_rows rows: the residual GEMMs (out-projection, ff.3) write row
                                  // statistics as (mean, M2) pairs per wave tile in their epilogue and LN1 -> QKV / LN2 -> ff.0 run
                                  // as ONE pair-fed algebraic-LayerNorm GEMM - no stand-alone LayerNorm launch (0: off; 1: where
-                                 // the producer is not K-split anyway; 2: also un-split the producers with K <= 1024)
+                                 // the producer is not K-split anyway; 2: also un-split the producers with K <= ln_pairs_maxk)
+    int ln_pairs_maxk = 1024;    // ... ln_pairs = 2: the longest K chain that is taken out of the K split
+    int ln_pairs_maxm = 2048;    // ... only for launches of at most this many rows: beyond, the consumers run on the 256x128 tile
+                                 // (no pair-fed form) and a LayerNorm launch is no longer a latency item (C5: 5342 vs 5210 ms without the cap)
 };
 hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
 // gemm_skinny.hip: weight-streaming linear layer for M <= 64 rows (taps = 1, no rowbase, K a multiple of 32)

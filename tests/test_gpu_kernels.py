@@ -542,7 +542,7 @@ def test_gemm_with_algebraic_layernorm(rt, cfg, M, N, K):
         assert rel(out2, ref[2::3][:Ms]) < 2e-5
 
 
-@pytest.mark.parametrize("cfg", [55, 63, 64, 84, 85, 86, -1])
+@pytest.mark.parametrize("cfg", [55, 84, 85, 86, -1])
 @pytest.mark.parametrize("M,d,N2", [(200, 768, 1024), (1120, 768, 2304), (333, 1024, 4096), (97, 1024, 1024)])
 def test_gemm_layernorm_statistics_handed_from_gemm_to_gemm(rt, cfg, M, d, N2):
     """The AR layers' stand-alone LayerNorm launches (round 5; modules/transformer.py:88-102: `x = x + out_proj(att)` then

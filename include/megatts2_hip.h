@@ -224,7 +224,7 @@ int mt2_synthesize_prompt_conditioned(mt2_model* m, void* stream, const int64_t*
 /* ---- tuning.  Every switch lives in the handle (no process-global state): two handles do not see each other's
  * settings.  Names: "ar_groups" (1..8, default 2: the sequences of an autoregressive run are dealt into that many
  * independent kernel chains on internal HIP streams that fork from and join back into `stream`; results do not
- * depend on it), "lnalg" (0: algebraic LayerNorm in the AR layers), "ln_pairs" (1: LayerNorm statistics handed from GEMM to GEMM in the AR layers), "splitk" (1), "lnfuse" (0), "voc_streams" (3), "voc_pair" (0: vocoder stages of at most that many channels run each ResBlock pair as one launch),
+ * depend on it), "lnalg" (0: algebraic LayerNorm in the AR layers), "ln_pairs" (1: LayerNorm statistics handed from GEMM to GEMM in the AR layers), "splitk" (1), "lnfuse" (0), "voc_streams" (3),
  * "x6_conv" (1: window convolutions on the bf16 matrix pipe in the f32-equivalent 6-product form), "x6_gemm" (1: the same for
  * the implicit-GEMM launches with enough big tiles), "x6_splitk" (1), "t_x6_256" (160), "t_x6_128" (72), "t_x6_64" (0: tile-count thresholds of
  * the two x6 tile shapes), "nt_weights" (0) / "nt_row_tiles" (2: non-temporal weight loads for launches with at most that many
@@ -266,11 +266,6 @@ int mt2_op_gemm_x6_ln(void* stream, const float* X, int ldx, int Rx, int a_mul, 
                       const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epi_act,
                       int force_cfg, float* stat_out, int32_t* stat_nt, int32_t* stat_w, const float* ln_stat, int ln_nt,
                       int ln_w, const float* ln_s, float ln_eps);
-/* One ResBlock1 pair of the HiFi-GAN generator (speechbrain HifiganGenerator; call site models/megatts2.py:370-372) in ONE launch:
- * Y = X + conv_b(lrelu(conv_a(lrelu(X), k taps, dilation dil) + bias_a), k taps) + bias_b over time-major rows [M, C], C in {32, 64}, rows
- * with valid[m] == 0 written as zero; the weights as three bf16 planes [3][C][taps * C] each (truncation split, exact sum). */
-int mt2_op_conv_pair(void* stream, const float* X, int M, int C, int taps, int dil, const void* W3a, const float* bias_a,
-                     const void* W3b, const float* bias_b, const int32_t* valid, float slope, float* Y);
 /* Linear layers of at most 64 rows on a TILE-MAJOR copy of the weights (round 4; gemm_skinny_tm_kernel - what the AR steps of one
  * utterance and the last-row launches of every batched AR step run on: F.linear at models/megatts2.py:172-179,264-273 with a
  * handful of rows).  mt2_op_tile_major turns a row-major [N, K] matrix (N a multiple of 16, K of 64) into blocks of 16 columns x 64 k,

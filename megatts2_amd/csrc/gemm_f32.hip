@@ -1345,235 +1345,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x6_kernel(Gemm
 
 
 // ===================================================================================================
-// v3d (round 5): a whole ResBlock1 PAIR of the HiFi-GAN generator in one launch - the measurement VERDICT r2-r4 asked for
-// instead of a price.  hifigan_rows runs, per stage and resblock, three pairs  h <- h + conv_b(lrelu(conv_a(lrelu(h), dil)))
-// (speechbrain HifiganGenerator ResBlock1; call site models/megatts2.py:370-372) as two window convolutions with the
-// intermediate t1 and the residual h travelling through HBM.  Here a workgroup owns BO = BT - (k - 1) output rows:
-//   * the input window (BT + (k - 1) dil rows of raw h) is loaded into LDS once, exactly as in conv_win_x6_kernel;
-//   * phase A = conv_a over BT rows of t1 (the k - 1 extra rows are conv_b's halo, recomputed by the neighbour workgroup:
-//     <= 4 % redundant products at BT = 256), leaky ReLU in the A split, epilogue bias + leaky ReLU + gap-row mask - and the
-//     result goes to a SECOND LDS window in the slot-swizzled layout the A fragments are read from, not to memory;
-//   * phase B = conv_b over that window (dilation 1), epilogue bias + residual (read back from the FIRST window: the raw
-//     h rows are still there) + mask -> HBM.  Rows r >= BO of the 32-row MFMA tiles read past the t1 window and are dropped.
-// The weight ring simply carries the 2 k QS chunks of both convolutions back to back (loader waves, one s_barrier per chunk;
-// the barrier in front of conv_b's first chunk also orders the t1 writes before their reads).  Same arithmetic and the same
-// summation order per output element as the two-launch form (tap-major, 32-wide chunks): bit-identical results.
-template <int QS, int BT, int NST, int NL>
-__global__ __launch_bounds__((BT / 32 + NL) * 64) void conv_pair_x6_kernel(PairP p) {
-    constexpr int NW = BT / 32, BN = 32 * QS, TN = QS;
-    constexpr int BPIECES = 3 * BN / 16, B_IT = (BPIECES + NL - 1) / NL, STAGE_B = B_IT * NL * 1024;
-    static_assert(NL > 0 && NST >= 2 && (NST - 2) * B_IT < 64 && BT % 32 == 0, "config");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave_all >= NW;
-    const int wave = loader ? wave_all - NW : wave_all;
-    const int taps = p.taps, dil = p.dil, h2 = (taps - 1) / 2, h1 = h2 * dil;
-    const int BO = BT - (taps - 1);
-    const int WR0 = BT + (taps - 1) * dil, WR0p = (WR0 + 7) & ~7;
-    const int WR1p = (BT + taps - 1 + 7) & ~7;
-    char* ring = reinterpret_cast<char*>(smem);
-    float* win0 = smem + NST * STAGE_B / 4;                           // [QS][WR0p][32] raw input rows
-    float* win1 = win0 + QS * WR0p * 32;                              // [QS][WR1p][32] t1 rows
-
-    const int ntm = (p.M + BO - 1) / BO;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, qq = ntm >> 3, rr = ntm & 7;
-    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-    const int o0 = tile * BO, t0 = o0 - h2, x0 = t0 - h1;             // first output / t1 / input row of this workgroup
-
-    const float* __restrict__ X = p.X;
-    const long long zoff_x = (const float*)g_zero16 - X;
-    const int ldx = p.ldx, M = p.M;
-    {   // ---- the f32 input window, once, by every wave
-        const int lrow = lane >> 3;
-        const int ppq = WR0p >> 3, pieces = QS * ppq;
-        for (int pc = wave_all; pc < pieces; pc += NW + NL) {
-            const int q = pc / ppq, r8 = pc - q * ppq;
-            const int row = r8 * 8 + lrow;
-            const int grow = x0 + row;
-            const int slot = (lane & 7) ^ ((row >> 1) & 7);
-            const bool ok = (row < WR0) & ((unsigned)grow < (unsigned)M);
-            const long long off = ok ? (long long)grow * ldx + q * 32 + slot * 4 : zoff_x;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
-                                             (__attribute__((address_space(3))) void*)(win0 + (q * WR0p + r8 * 8) * 32), 16, 0, 0);
-        }
-    }
-    const int nk = taps * QS;                                         // chunks of ONE convolution (K = taps * C, 32 per chunk)
-    if (loader) {       // ---- loader wave: the weight chunks of conv_a, then of conv_b, through the ring
-        loader_priority(p.ldr_prio);
-        const unsigned short* __restrict__ Wa = reinterpret_cast<const unsigned short*>(p.W3a);
-        const unsigned short* __restrict__ Wb = reinterpret_cast<const unsigned short*>(p.W3b);
-        const int ldw = taps * BN;
-        long long wofs[B_IT];
-#pragma unroll
-        for (int j = 0; j < B_IT; ++j) {
-            const int pc = j * NL + wave;                    // piece = plane * (BN / 16) + row block
-            const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
-            const int n = rb * 16 + (lane >> 2);
-            const int sl = (lane & 3) ^ ((n >> 2) & 3);
-            wofs[j] = pc < BPIECES ? pl * p.plane + (long long)n * ldw + sl * 8 : -1;
-        }
-        auto issue = [&](int c, int st) {
-            const unsigned short* __restrict__ W3 = c < nk ? Wa : Wb;
-            const int cl = c < nk ? c : c - nk;
-            char* Bs = ring + st * STAGE_B + wave * 1024;
-#pragma unroll
-            for (int j = 0; j < B_IT; ++j) {
-                const unsigned short* src = wofs[j] >= 0 ? W3 + wofs[j] + cl * 32 : reinterpret_cast<const unsigned short*>(g_zero16);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16, 0, 0);
-            }
-        };
-        const int nc = 2 * nk;
-#pragma unroll
-        for (int st = 0; st < NST - 1; ++st)
-            if (st < nc) issue(st, st);
-        int st = 0;
-        for (int c = 0; c < nc; ++c) {
-            if (c + NST - 2 < nc) wait_vmcnt<(NST - 2) * B_IT>();     // window pieces (older) and chunk c have landed
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (c + NST - 1 < nc) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
-            st = st + 1 == NST ? 0 : st + 1;
-        }
-        return;
-    }
-    // ---- compute wave `wave`: rows wave*32 .. +31 of the t1 tile (phase A) and of the output tile (phase B), all C columns
-    const int half = lane >> 5, n32 = lane & 31;
-    float ba[TN], bb[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) { ba[j] = p.bias_a[j * 32 + n32]; bb[j] = p.bias_b[j * 32 + n32]; }
-    unsigned mt = 0u, mo = 0u;                           // row masks of the lane's 16 accumulator rows: t1 rows / output rows
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        const int gt = t0 + r, go = o0 + r;
-        const int vt = ((unsigned)gt < (unsigned)M) ? (p.valid ? p.valid[gt] : 1) : 0;
-        const int vo = ((unsigned)go < (unsigned)M && r < BO) ? (p.valid ? p.valid[go] : 1) : 0;
-        mt |= (vt != 0 ? 1u : 0u) << e;
-        mo |= (vo != 0 ? 1u : 0u) << e;
-    }
-    wait_vmcnt<0>();                                     // this wave's window pieces (and the loads above), before the first barrier
-
-    f32x16 acc[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
-    const float slope = p.slope;
-    const unsigned lds_ring = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
-    const unsigned lds_w0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)win0;
-    const unsigned lds_w1 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)win1;
-    const unsigned b_lane = lds_ring + n32 * 64;
-    const int swzb = (n32 >> 2) & 3;
-    unsigned koffb[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
-
-    // one 32-deep chunk: A fragments of row `arow` of window `wbase` (row pitch 128 B, plane q), weights from ring stage st
-    auto chunk = [&](auto pro_tag, unsigned wbase, int arow, int st) {
-        constexpr int PROC = decltype(pro_tag)::value;
-        const int swza = (arow >> 1) & 7;
-        const unsigned sa = wbase + (unsigned)(arow * BK) * 4;
-        const unsigned sb = b_lane + (unsigned)st * STAGE_B;
-        f32x4 ra[2][2];
-        u32x4 rb[2][3][TN], pln[3];
-        auto fetch = [&](int b) {
-            ra[b][0] = lds_read_b128(sa + (unsigned)(((b * 4 + half * 2) ^ swza) * 16));
-            ra[b][1] = lds_read_b128(sa + (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16));
-            const unsigned vb = sb + koffb[b];
-            static_for(std::make_integer_sequence<int, 3 * TN>{}, [&](auto ic) {
-                constexpr int pl = decltype(ic)::value / TN, j = decltype(ic)::value % TN;
-                rb[b][pl][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<(pl * BN + j * 32) * 64>(vb));
-            });
-        };
-        auto wait_block = [&](int b) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(ra[b][0]), "+v"(ra[b][1]));
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
-        };
-        auto products = [&](int b) {
-            const bf16x8 A1 = __builtin_bit_cast(bf16x8, pln[0]), A2 = __builtin_bit_cast(bf16x8, pln[1]), A3 = __builtin_bit_cast(bf16x8, pln[2]);
-            constexpr int PA[6] = {3, 1, 2, 2, 1, 1}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const bf16x8 At = PA[t] == 1 ? A1 : (PA[t] == 2 ? A2 : A3);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, __builtin_bit_cast(bf16x8, rb[b][PB[t]][j]), acc[j], 0, 0, 0);
-            }
-        };
-        fetch(0);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_block(0);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(1);
-        __builtin_amdgcn_sched_barrier(0);
-        split3_bf16<PROC>(ra[0][0], ra[0][1], slope, pln[0], pln[1], pln[2]);
-        products(0);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_block(1);
-        __builtin_amdgcn_sched_barrier(0);
-        split3_bf16<PROC>(ra[1][0], ra[1][1], slope, pln[0], pln[1], pln[2]);
-        products(1);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    int st = 0, tap = 0, q = 0;
-    const int arow0 = wave * 32 + n32;
-    // ---- phase A: conv_a (leaky ReLU on the input, dilation dil) over the raw window
-    for (int c = 0; c < nk; ++c) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        chunk(std::integral_constant<int, ACT_LRELU>{}, lds_w0 + (unsigned)(q * WR0p * BK) * 4, arow0 + tap * dil, st);
-        st = st + 1 == NST ? 0 : st + 1;
-        if (++q == QS) { q = 0; ++tap; }
-    }
-    // t1 = mask * lrelu(acc + bias_a) -> the second window, slot-swizzled like the first (element (row, k): 16-byte slot (k / 4)
-    // ^ ((row >> 1) & 7)); the inner leaky ReLU has one consumer and is applied once here
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-            float v = acc[j][e] + ba[j];
-            v = fmaxf(v, v * slope);
-            if (!((mt >> e) & 1u)) v = 0.0f;
-            win1[(j * WR1p + r) * 32 + (((n32 >> 2) ^ ((r >> 1) & 7)) << 2) + (n32 & 3)] = v;
-            acc[j][e] = 0.0f;
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the t1 rows are in LDS before this wave reaches the next barrier
-    // ---- phase B: conv_b (dilation 1) over the t1 window
-    tap = 0; q = 0;
-    for (int c = 0; c < nk; ++c) {
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        chunk(std::integral_constant<int, ACT_NONE>{}, lds_w1 + (unsigned)(q * WR1p * BK) * 4, arow0 + tap, st);
-        st = st + 1 == NST ? 0 : st + 1;
-        if (++q == QS) { q = 0; ++tap; }
-    }
-    // Y = mask * (acc + bias_b + h): the residual rows are still in the first window (row r of the output tile = window row
-    // r + h2 + h1)
-    float* __restrict__ Y = p.Y;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-            const int wr = r + h2 + h1;
-            const float xr = win0[(j * WR0p + wr) * 32 + (((n32 >> 2) ^ ((wr >> 1) & 7)) << 2) + (n32 & 3)];
-            float v = acc[j][e] + bb[j] + xr;
-            if (!((mo >> e) & 1u)) v = 0.0f;
-            if (r < BO && o0 + r < M) Y[(long long)(o0 + r) * p.ldy + j * 32 + n32] = v;
-        }
-}
-
-// ===================================================================================================
 // v2b: the implicit-GEMM engine on the bf16 matrix pipe, f32-equivalent ("x6", see conv_win_x6_kernel for the
 // arithmetic).  Same operand path as gemm_f32_dma_kernel - A chunks (f32, conv taps / row gathers / zero fill) and B
 // chunks through an LDS-DMA ring, XOR-swizzled, counted vmcnt - except that B travels as three bf16 planes
@@ -3281,25 +3052,5 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     return hipGetLastError();
 }
 
-
-// ResBlock pair in one launch (PairP, mt2_kernels.h)
-hipError_t launch_conv_pair(const PairP& p, hipStream_t s) {
-    if (p.M <= 0) return hipSuccess;
-    if (!(p.C == 32 || p.C == 64) || p.taps < 3 || !(p.taps & 1) || p.taps > 11 || p.dil < 1 || !p.W3a || !p.W3b ||
-        (p.ldx & 3) || p.plane <= 0 || !p.bias_a || !p.bias_b)
-        return hipErrorNotSupported;
-    const int BT = p.C == 32 ? 256 : 128, QS = p.C / 32, NST = 3, NL = 4;
-    const int WR0p = (BT + (p.taps - 1) * p.dil + 7) & ~7, WR1p = (BT + p.taps - 1 + 7) & ~7;
-    const int BPIECES = 3 * p.C / 16, B_IT = (BPIECES + NL - 1) / NL;
-    const size_t lds = (size_t)NST * B_IT * NL * 1024 + (size_t)QS * (WR0p + WR1p) * 32 * sizeof(float);
-    if (lds > 160 * 1024) return hipErrorNotSupported;
-    void (*fn)(PairP) = p.C == 32 ? conv_pair_x6_kernel<1, 256, 3, 4> : conv_pair_x6_kernel<2, 128, 3, 4>;
-    static std::atomic<unsigned long long> done[2];
-    hipError_t e = dyn_lds_once(done[QS - 1], reinterpret_cast<const void*>(fn), 160 * 1024);
-    if (e != hipSuccess) return e;
-    const int BO = BT - (p.taps - 1);
-    hipLaunchKernelGGL(fn, dim3((p.M + BO - 1) / BO), dim3((BT / 32 + NL) * 64), lds, s, p);
-    return hipGetLastError();
-}
 
 }  // namespace mt2

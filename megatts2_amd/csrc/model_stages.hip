@@ -1256,22 +1256,6 @@ static float* hifigan_rows(const Ctx& c, const float* xmel, const RowSet& M0) {
             const float* h = up;
             for (int n = 0; n < 3; ++n) {
                 float* out = n == 2 ? rb[j] : (n == 0 ? ha : hb);
-                if (!reflect && m.opts.voc_pair >= ch && m.opts.x6_conv && m.opts.force_cfg < 0) {
-                    // the whole pair in ONE launch, t1 and the residual never leave LDS (conv_pair_x6_kernel): narrow stages
-                    GemmP wa{}, wb{};
-                    wa.W = r.c1[n].w; wb.W = r.c2[n].w;
-                    attach_planes(m, wa);
-                    attach_planes(m, wb);
-                    if (wa.W3 && wb.W3 && wa.w3_plane == wb.w3_plane) {
-                        PairP pp{};
-                        pp.X = h; pp.ldx = ch; pp.M = (int)R; pp.W3a = wa.W3; pp.bias_a = r.c1[n].b; pp.dil = r.dil[n];
-                        pp.W3b = wb.W3; pp.bias_b = r.c2[n].b; pp.plane = wa.w3_plane; pp.taps = r.k; pp.C = ch; pp.valid = valid;
-                        pp.Y = out; pp.ldy = ch; pp.slope = slope; pp.ldr_prio = m.opts.ldr_prio;
-                        const hipError_t e = launch_conv_pair(pp, cj.s);
-                        if (e == hipSuccess) { h = out; continue; }
-                        if (e != hipErrorNotSupported) MT2_HIP(e);
-                    }
-                }
                 // x + conv2(lrelu(conv1(lrelu(x)))): the inner leaky ReLU has ONE consumer, so it is applied once in
                 // conv1's epilogue instead of on every operand fragment of conv2 (same values, no VALU in that loop)
                 if (n > 0) halo(cj, const_cast<float*>(h), ch, (r.k - 1) / 2 * r.dil[n]);

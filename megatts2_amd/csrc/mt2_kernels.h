@@ -93,8 +93,6 @@ struct EngineOpts {
     bool lnalg = false;          // ALGEBRAIC LayerNorm in the AR layers: LN1 -> QKV and LN2 -> ff.0 are ONE launch each,
                                  // statistics in the GEMM's prologue, rstd * (acc - mean * s) + c in its epilogue
     int voc_streams = 3;         // resblock chains of a vocoder stage in flight (1 = serial)
-    int voc_pair = 0;            // vocoder stages with at most this many channels (32 / 64; 0 = off) run every ResBlock pair
-                                 // (dilated conv -> conv -> add) as ONE launch with the intermediate in LDS (conv_pair_x6_kernel)
     bool win_conv = true;        // window-convolution kernel for narrow square convs (Cin = Cout in {32, 64, 128})
     bool x6_conv = true;         // ... on the bf16 matrix pipe, f32-equivalent 3-way split (6 products), where W3 planes exist
     bool x6_gemm = true;         // the big-tile implicit GEMMs likewise (gemm_x6_dma_kernel)
@@ -141,19 +139,6 @@ struct EngineOpts {
                                  // (no pair-fed form) and a LayerNorm launch is no longer a latency item (C5: 5342 vs 5210 ms without the cap)
 };
 hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
-// One ResBlock1 pair of the HiFi-GAN generator in ONE launch (round 5, gemm_f32.hip conv_pair_x6_kernel):
-//   Y = X + conv_b(lrelu(conv_a(lrelu(X), k taps, dilation dil) + bias_a), k taps, dilation 1) + bias_b      (rows masked by `valid`)
-// for C = Cin = Cout in {32, 64} over time-major rows [M, C] whose gap rows are zero; the intermediate never leaves LDS and the
-// residual is read from the input window.  Weights as three bf16 planes [3][C][k * C] (GemmP::W3 layout), both convolutions
-// with the same plane stride.  hipErrorNotSupported when the shape has no such kernel (callers run the two launches).
-struct PairP {
-    const float* X; int ldx; int M;
-    const void* W3a; const float* bias_a; int dil;
-    const void* W3b; const float* bias_b;
-    long long plane; int taps; int C;
-    const int* valid; float* Y; int ldy; float slope; int ldr_prio = 3;
-};
-hipError_t launch_conv_pair(const PairP& p, hipStream_t s);
 // gemm_skinny.hip: weight-streaming linear layer for M <= 64 rows (taps = 1, no rowbase, K a multiple of 32)
 bool gemm_skinny_eligible(const GemmP& p, int max_rows);
 hipError_t launch_gemm_skinny(const GemmP& p, hipStream_t s);

@@ -687,18 +687,6 @@ def op_gemm_x6_ln(X, W, bias=None, R=None, M=None, a_mul=1, shift0=0, epi_act=AC
     return out
 
 
-def op_conv_pair(X, Wa, ba, Wb, bb, taps, dil, valid=None, slope=0.1):
-    """mt2_op_conv_pair: X [M, C] f32, Wa / Wb [C, taps * C] (tap-major K: W[n, t * C + c]) -> Y = X + conv_b(lrelu(conv_a(lrelu(X))))"""
-    import torch
-    lib = load_library()
-    M, Cc = X.shape
-    out = torch.empty_like(X)
-    W3a, W3b = split_bf16x3(Wa.contiguous()).to(X.device), split_bf16x3(Wb.contiguous()).to(X.device)
-    _check(lib.mt2_op_conv_pair(_stream(), _ptr(X), M, Cc, taps, dil, _ptr(W3a), _ptr(ba), _ptr(W3b), _ptr(bb), _ptr(valid),
-                                C.c_float(slope), _ptr(out)))
-    return out
-
-
 def op_ln_gemm(X, gamma, beta, W, bias=None, M=None, a_mul=1, shift0=0, eps=1e-5, epi_act=ACT_NONE, force_cfg=-1,
                algebraic=False):
     """LN(X) @ W^T + b in one launch.  algebraic=True folds gamma / beta into the operands on the host (float64 sums,

@@ -597,50 +597,6 @@ def test_gemm_layernorm_statistics_handed_from_gemm_to_gemm(rt, cfg, M, d, N2):
     assert rel(out2, ref2) < 4e-6
 
 
-@pytest.mark.parametrize("k,dil", [(3, 1), (3, 5), (7, 3), (11, 5), (11, 1)])
-@pytest.mark.parametrize("C", [32, 64])
-def test_resblock_pair_in_one_launch(rt, C, k, dil):
-    """HiFi-GAN ResBlock1 pair h + conv_b(lrelu(conv_a(lrelu(h), dilation))) (speechbrain HifiganGenerator; call site
-    models/megatts2.py:370-372) as ONE launch with the intermediate and the residual in LDS (conv_pair_x6_kernel) against the
-    two window-convolution launches it replaces - same arithmetic, same order: bit-identical - and against float64; utterance
-    gaps (masked rows), a row count that is no multiple of the tile, the last tile's tail."""
-    rng = np.random.default_rng(100 * C + 10 * k + dil)
-    G = (k - 1) // 2 * dil + 4
-    lens = [700, 33, 1250, 311]
-    valid = np.zeros(G + sum(l + G for l in lens), np.int32)
-    r = G
-    for l in lens:
-        valid[r:r + l] = 1
-        r += l + G
-    M = valid.size
-    X = (rng.standard_normal((M, C)) * valid[:, None]).astype(np.float32)
-    Wa = (rng.standard_normal((C, k * C)) / math.sqrt(k * C)).astype(np.float32)
-    Wb = (rng.standard_normal((C, k * C)) / math.sqrt(k * C)).astype(np.float32)
-    ba, bb = rng.standard_normal(C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
-    dX, dv = dev(X), dev(valid)
-    out = rt.op_conv_pair(dX, dev(Wa), dev(ba), dev(Wb), dev(bb), k, dil, valid=dv, slope=0.1).cpu().numpy()
-    t1 = rt.op_conv_x6(dX, dev(Wa), dev(ba), valid=dv, shift0=-((k - 1) // 2) * dil, taps=k, dil=dil, pro_act=rt.ACT_LRELU,
-                       pro_slope=0.1, epi_act=rt.ACT_LRELU)
-    two = rt.op_conv_x6(t1, dev(Wb), dev(bb), R=dX, valid=dv, shift0=-((k - 1) // 2), taps=k, dil=1).cpu().numpy()
-    assert np.array_equal(out, two), float(np.abs(out - two).max())
-
-    def conv64(x, W, b, d):
-        y = np.zeros((M, C))
-        for t in range(k):
-            sh = (t - (k - 1) // 2) * d
-            xs = np.zeros_like(x)
-            lo, hi = max(0, -sh), min(M, M - sh)
-            xs[lo:hi] = x[lo + sh:hi + sh]
-            y += xs @ W[:, t * C:(t + 1) * C].T.astype(np.float64)
-        return y + b
-    lr = lambda v: np.where(v >= 0, v, 0.1 * v)                                  # noqa: E731
-    x64 = X.astype(np.float64)
-    t64 = lr(conv64(lr(x64), Wa, ba, dil)) * valid[:, None]
-    ref = (conv64(t64, Wb, bb, 1) + x64) * valid[:, None]
-    assert rel(out, ref) < 2e-6
-    assert not out[valid == 0].any()
-
-
 @pytest.mark.parametrize("C", [32, 64, 384, 512, 768, 1024])
 def test_layernorm(rt, C):
     rng = np.random.default_rng(C)

@@ -6,7 +6,7 @@ contents (cdna_hip_programming.md 5.7 item 1).  The kernels keep every such regi
 holds while the allocator has room.  A variant at its VGPR cap can acquire such a spill from an unrelated edit (round 3: the
 16-byte-store epilogue pushed `gemm_x6_ldr_kernel<256,128,...>` over: `ds_read_b128 v[2:5]` followed by `scratch_store_dwordx4
 v[2:5]` inside the K loop -> NaNs at production size, kernel tests green).  `audit` lists every scratch access inside a loop
-of a kernel whose loops contain inline-asm LDS reads; a STORE there fails the build."""
+of a kernel whose loops contain inline-asm LDS reads; a STORE or (since round 5) a RELOAD there fails the build."""
 import re
 
 
@@ -47,16 +47,20 @@ def audit(path: str):
 
 
 def report(path: str):
-    """-> (number of kernels with in-loop scratch STORES, text report)"""
+    """-> (number of kernels with scratch accesses inside LDS-reading loops, text report)"""
     bad = audit(path)
-    # a STORE is the hazard (it can save an in-flight ds_read destination); a reload of a loop-invariant value (the LDS base
-    # offset of the 168-VGPR 256x128 variants, present since round 2) is only a cost and is reported as a note
+    # a STORE is the hazard (it can save an in-flight ds_read destination).  A reload of a loop-invariant value used to be
+    # tolerated as a note (the 168-VGPR 256x128 loader tiles re-read a spilled LDS base every chunk, rounds 2-4); since the
+    # ds_read offsets ride in the instruction's offset field (round 5) no audited loop touches scratch at all - and a LOAD
+    # there now fails the build too: it is a memory round trip behind every s_barrier of the hottest loops.
     stores = [b for b in bad if b[2].startswith("scratch_store")]
+    loads = [b for b in bad if b not in stores]
     lines = []
-    for tag, rows in (("IN-LOOP SCRATCH STORE", stores), ("note: in-loop reload", [b for b in bad if b not in stores])):
+    for tag, rows in (("IN-LOOP SCRATCH STORE", stores), ("IN-LOOP SCRATCH RELOAD", loads)):
         for k in sorted({b[0] for b in rows}):
             hits = [b[2] for b in rows if b[0] == k]
             lines.append(f"{tag}: {k}: {len(hits)} access(es), e.g. {hits[0]}")
-    n = len({b[0] for b in stores})
-    lines.append(f"{n} kernel(s) with scratch STORES inside LDS-reading loops")
+    n = len({b[0] for b in bad})
+    lines.append(f"{len({b[0] for b in stores})} kernel(s) with scratch STORES inside LDS-reading loops")
+    lines.append(f"{len({b[0] for b in loads})} kernel(s) with scratch RELOADS inside LDS-reading loops")
     return n, "\n".join(lines)

@@ -2752,10 +2752,6 @@ static const TileCfg kCfgs[] = {
     { 64, 32, 512, 0, "skinny64_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },    // 88
     { 32, 32, 512, 0, "skinnytm32_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },  // 89: the same on tile-major weights
     { 64, 32, 512, 0, "skinnytm64_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },  // 90   (+ LayerNorm prologue)
-    // round 5: HALF the footprint of the 128x128 loader tile - 4 compute waves (32x64 each) +
-    // 2 loader waves, 2-deep ring: 6 waves, 64 KiB -> TWO workgroups per CU (12 waves, 168 VGPRs), so that one AR chain's
-    // prologue / epilogue overlaps the other chain's K loop on the same CU.  Routed through x6_small_cfg = 91 (A/B only).
-    MT2_GX6L(64, 128, 2, 2, 2, 2),      // 91
 };
 constexpr int kSkinny32 = 87, kSkinny64 = 88, kSkinnyTm32 = 89, kSkinnyTm64 = 90;
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -2900,10 +2896,10 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
         if (t256 >= o.t_x6_256) bi = o.x6_loaders ? 51 : 37;
         else if (t128 >= o.t_x6_128) bi = o.x6_loaders ? 55 : 39;
         // small x6 tiles (x6_small_cfg = 63..66) for launches whose 128x128 tiles would leave most of the chip idle
-        if (((o.x6_small_cfg >= 63 && o.x6_small_cfg <= 64) || o.x6_small_cfg == 91) && t256 < o.t_x6_256 && t128 <= o.t_x6_small_max) {
+        if (o.x6_small_cfg >= 63 && o.x6_small_cfg <= 64 && t256 < o.t_x6_256 && t128 <= o.t_x6_small_max) {
             const TileCfg& sc = kCfgs[o.x6_small_cfg];
             const long long ts = (long long)((p.M + sc.bm - 1) / sc.bm) * ((p.N + sc.bn - 1) / sc.bn) * p.groups;
-            if (ts >= o.t_x6_small_min && (o.x6_small_cfg != 91 || bi == 55)) bi = o.x6_small_cfg;      // 91 stands in for the 128x128 loader tile only
+            if (ts >= o.t_x6_small_min) bi = o.x6_small_cfg;
         }
         // MP form of the loader-wave tiles (mid-chunk barrier, fragment fetch / split behind the previous products)
         // K-split tiles on the bf16 pipe (x6_ks: 1 = the 32x64 k4 and 64x64 k4/k2 tiles, 2 = the 32x32 k8 tile too)

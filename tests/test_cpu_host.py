@@ -394,8 +394,14 @@ def test_asm_audit_flags_a_spilled_lds_read_and_the_build_is_clean(tmp_path):
         "\ts_cbranch_scc1 .LBB1_1\n"
         ".Lfunc_end1:\n")
     n, text = asm_audit.report(str(listing))
-    assert n == 1 and "IN-LOOP SCRATCH STORE: _ZN3mt24demoEv" in text and "note: in-loop reload: _ZN3mt24demoEv" in text
+    assert n == 1 and "IN-LOOP SCRATCH STORE: _ZN3mt24demoEv" in text and "IN-LOOP SCRATCH RELOAD: _ZN3mt24demoEv" in text
     assert "_ZN3mt25cleanEv" not in text
+    # a reload alone fails too (round 5: the 256x128 loader tiles no longer re-read a spilled LDS base every chunk)
+    only_load = tmp_path / "l.s"
+    only_load.write_text(listing.read_text().replace("\tscratch_store_dwordx4 off, v[2:5], off ; 16-byte Folded Spill\n", ""))
+    n2, text2 = asm_audit.report(str(only_load))
+    assert n2 == 1 and "IN-LOOP SCRATCH STORE" not in text2 and "IN-LOOP SCRATCH RELOAD: _ZN3mt24demoEv" in text2
     build.build()
     rep = open(os.path.join(build.LIBDIR, "gemm_f32.asm_audit.txt")).read()
-    assert rep.strip().endswith("0 kernel(s) with scratch STORES inside LDS-reading loops")
+    assert "0 kernel(s) with scratch STORES inside LDS-reading loops" in rep
+    assert rep.strip().endswith("0 kernel(s) with scratch RELOADS inside LDS-reading loops")

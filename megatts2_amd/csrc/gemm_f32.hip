@@ -2939,6 +2939,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     if (tm_forced || (o.skinny_tm && o.skinny_rows > 0 && o.force_cfg < 0 && p.groups >= o.skinny_groups &&
                       gemm_skinny_tm_eligible(p, o.skinny_rows))) {
         if (!gemm_skinny_tm_eligible(p, 64)) return hipErrorInvalidValue;
+        p.sk_nw = o.skinny_nw;
         const int sidx = p.M <= 32 ? kSkinnyTm32 : kSkinnyTm64;
         if (opts) opts->last_cfg = kCfgs[sidx].name;
         if (opts && opts->trace_on) {

@@ -336,7 +336,7 @@ static int choose_split(const Ctx& c, int M, int N, int K) {
     // blocks x 256 KiB); there the K slices are 1024 wide (256 workgroups x 64 KiB) and the reduction rides on LN1 as before
     if (c.m.opts.skinny_tm && c.m.opts.skinny_rows > 0 && M <= c.m.opts.skinny_rows && M <= 64 && c.m.opts.force_cfg < 0 &&
         (N & 15) == 0 && (K & 63) == 0) {
-        if (K <= 1536) return 1;
+        if (K <= 1536 || c.m.opts.skinny_unsplit) return 1;
         int S = 1;
         while (S < 16 && K % (S * 2) == 0 && K / (S * 2) >= 1024 && (K / (S * 2)) % 64 == 0) S *= 2;
         return S;

@@ -48,6 +48,7 @@ struct GemmP {
     unsigned long long* dbg = nullptr;   // MT2_PHASE_TIMING builds only: per-phase cycle sums of one wave (tools/x6_phase_timing.py)
     int w_nt = 0;               // weight loads with the non-temporal cache policy (set by launch_gemm: weights streamed ~once per launch)
     int epi_t4 = 1;             // 16-byte-store epilogue where the layout allows it (set by launch_gemm from EngineOpts::epi_t4)
+    int sk_nw = 8;              // gemm_skinny_tm_kernel: waves per workgroup that split K (8; 16 = option skinny_nw, set by launch_gemm)
     int ldr_prio = 0;           // s_setprio of the loader waves of the loader-wave kernels (set by launch_gemm from EngineOpts::ldr_prio)
     const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like
     long long w3_plane = 0;     // W (same ldw / strideW, in bf16 elements), planes w3_plane elements apart (0: N * ldw) -
@@ -118,6 +119,9 @@ struct EngineOpts {
     int attn_ds = 1;             // short sequences on the AR heads: head dim split over the waves as well (AttnP::ds_short)
     bool skinny_tm = true;       // ... on the tile-major weight copy where one exists (gemm_skinny_tm_kernel; LayerNorm prologue included)
     int skinny_groups = 1;       // ... only for launches with at least this many GemmP groups (split-K slabs)
+    int skinny_unsplit = 0;      // launches of at most skinny_rows rows: no K split even for the long chains (PLM ff.3, K = 4096): the
+                                 // kernel adds bias + residual itself and the next LayerNorm rides in the consuming GEMM's prologue
+    int skinny_nw = 8;           // waves of the tile-major weight-streaming kernel that split K (8; 16: four per SIMD, M <= 32)
     int skinny_nt = 0;           // gemm_skinny.hip (0: off); skinny_nt: non-temporal weight loads (measured: C1 65.2 ms with, 56.8 without)
     int x6_small_cfg = 0;        // 63..64: small loader-wave x6 tile for launches with at most t_x6_small_max 128x128 tiles and
     int t_x6_small_max = 200, t_x6_small_min = 48;   // at least t_x6_small_min small tiles (0: off)

@@ -272,7 +272,8 @@ int mt2_op_gemm_x6_ln(void* stream, const float* X, int ldx, int Rx, int a_mul, 
  * block (nb, kb) at (nb * K/64 + kb) * 1024 floats, inside a block [j][lane][i] = W[nb*16 + lane%16][kb*64 + j*16 + (lane/16)*4 + i].
  * mt2_op_gemm_tm: C[g][M,N] = epi(pro(X[g] rows m*a_mul + shift0) @ Wsub[g]^T + bias) with Wsub[g] = rows [n0, n0 + N), columns
  * [k0, k0 + K) of the whole [*, Kw] matrix, moved by g * w_gstride row-major elements per group (split-K slabs: w_gstride = K).
- * ln_gamma != NULL: LayerNorm(X rows; gamma, beta, eps) as the prologue (K <= 1024, groups = 1) instead of pro_act. */
+ * ln_gamma != NULL: LayerNorm(X rows; gamma, beta, eps) as the prologue (K <= 1024, groups = 1) instead of pro_act.
+ * pro_act + 0x100: the eight-wave form of the kernel (default: sixteen / twelve waves split K at M <= 32, round 5). */
 int mt2_op_tile_major(void* stream, const float* W, int N, int K, float* out);
 int mt2_op_gemm_tm(void* stream, const float* X, long long x_gstride, int ldx, int Rx, int a_mul, int shift0, const float* Wtm,
                    int Kw, int n0, int k0, long long w_gstride, int groups, const float* bias, const float* R, int ldr,

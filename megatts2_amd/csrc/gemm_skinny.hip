@@ -237,7 +237,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_tm_kernel(GemmP p) {
         const int Kf = p.K;
         const float inv_k = 1.0f / (float)Kf;
         const float* __restrict__ Xg = p.X + (long long)g * p.strideX;
-        constexpr int RF = NW >= 16 ? 2 : 4;      // rows of this wave in flight: ONE memory round trip for up to 32 rows per workgroup
+        constexpr int RF = NW >= 12 ? 2 : 4;      // rows of this wave in flight: ONE memory round trip for up to 32 rows per workgroup
         for (int r0 = wave; r0 < p.M; r0 += RF * NW) {
             f32x4 xv[RF][4];
 #pragma unroll
@@ -390,11 +390,17 @@ hipError_t launch_gemm_skinny_tm(const GemmP& p, hipStream_t s) {
     if (!gemm_skinny_tm_eligible(p, 64)) return hipErrorInvalidValue;
     const bool ln = p.pro_act == 3;
     const int per_wave = ((p.K >> 6) + 7) / 8;          // K chunks of the busiest wave
-    // GemmP::sk_nw == 16 (option skinny_nw, A/B): SIXTEEN waves split K - four per SIMD, one 64-wide chunk each at K = 1024
-    // (a wave's dependent MFMA chain and its share of the loads halve; the LDS reduction sums 16 slabs).  M <= 32 only.
+    // GemmP::sk_nw == 16 (option skinny_nw, default since round 5): SIXTEEN waves split K - four per SIMD, one 64-wide chunk each at
+    // K = 1024 (a wave's dependent MFMA chain and its share of the loads halve; the LDS reduction sums 16 slabs in wave order) -
+    // or TWELVE when K has only twelve chunks (the ADM's d = 768).  M <= 32 only (registers: 128 / 168 per wave).  Interleaved
+    // A/B on the one-utterance path: C1 42.5 -> 41.75 ms (profiles/r05_opts_ab.txt).
     if (p.sk_nw == 16 && p.M <= 32 && (p.K >> 6) >= 16) {
         if (p.M <= 16) return ln ? sk_tm_launch<1, 1, true, 16>(p, s) : (per_wave > 2 ? sk_tm_launch<1, 2, false, 16>(p, s) : sk_tm_launch<1, 1, false, 16>(p, s));
         return ln ? sk_tm_launch<2, 1, true, 16>(p, s) : (per_wave > 2 ? sk_tm_launch<2, 2, false, 16>(p, s) : sk_tm_launch<2, 1, false, 16>(p, s));
+    }
+    if (p.sk_nw == 16 && p.M <= 32 && (p.K >> 6) == 12) {
+        if (p.M <= 16) return ln ? sk_tm_launch<1, 1, true, 12>(p, s) : sk_tm_launch<1, 1, false, 12>(p, s);
+        return ln ? sk_tm_launch<2, 1, true, 12>(p, s) : sk_tm_launch<2, 1, false, 12>(p, s);
     }
     switch ((p.M + 15) / 16) {
         case 1:

@@ -120,8 +120,10 @@ struct EngineOpts {
     bool skinny_tm = true;       // ... on the tile-major weight copy where one exists (gemm_skinny_tm_kernel; LayerNorm prologue included)
     int skinny_groups = 1;       // ... only for launches with at least this many GemmP groups (split-K slabs)
     int skinny_unsplit = 0;      // launches of at most skinny_rows rows: no K split even for the long chains (PLM ff.3, K = 4096): the
-                                 // kernel adds bias + residual itself and the next LayerNorm rides in the consuming GEMM's prologue
-    int skinny_nw = 8;           // waves of the tile-major weight-streaming kernel that split K (8; 16: four per SIMD, M <= 32)
+                                 // kernel adds bias + residual itself and the next LayerNorm rides in the consuming GEMM's prologue.
+                                 // MEASURED NEGATIVE: C1 +7.3 % (64 workgroups stream 256 KiB each; the four-slice form keeps 256 busy)
+    int skinny_nw = 16;          // waves of the tile-major weight-streaming kernel that split K (8; 16: four per SIMD - twelve for K = 768 -
+                                 // at M <= 32: C1 -1.8 %, profiles/r05_opts_ab.txt)
     int skinny_nt = 0;           // gemm_skinny.hip (0: off); skinny_nt: non-temporal weight loads (measured: C1 65.2 ms with, 56.8 without)
     int x6_small_cfg = 0;        // 63..64: small loader-wave x6 tile for launches with at most t_x6_small_max 128x128 tiles and
     int t_x6_small_max = 200, t_x6_small_min = 48;   // at least t_x6_small_min small tiles (0: off)

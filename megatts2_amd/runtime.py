@@ -611,9 +611,9 @@ def op_tile_major(W):
 
 
 def op_gemm_tm(X, Wtm, Kw, N, K, n0=0, k0=0, groups=1, x_gstride=0, w_gstride=0, bias=None, R=None, valid=None, M=None,
-               a_mul=1, shift0=0, pro_act=ACT_NONE, pro_slope=0.0, epi_act=ACT_NONE, ln=None, eps=1e-5, ldx=None):
+               a_mul=1, shift0=0, pro_act=ACT_NONE, pro_slope=0.0, epi_act=ACT_NONE, ln=None, eps=1e-5, ldx=None, waves8=False):
     """Linear layer of at most 64 rows on tile-major weights; groups > 1 -> out [groups, M, N] (split-K slabs, ...);
-    ln = (gamma, beta): LayerNorm prologue."""
+    ln = (gamma, beta): LayerNorm prologue; waves8: the eight-wave form (default: sixteen / twelve waves at M <= 32)."""
     import torch
     lib = load_library()
     ldx = ldx or X.shape[-1]
@@ -622,7 +622,7 @@ def op_gemm_tm(X, Wtm, Kw, N, K, n0=0, k0=0, groups=1, x_gstride=0, w_gstride=0,
     g_, b_ = ln if ln is not None else (None, None)
     _check(lib.mt2_op_gemm_tm(_stream(), _ptr(X), C.c_longlong(x_gstride), ldx, X.shape[-2], a_mul, shift0, _ptr(Wtm), Kw, n0, k0,
                               C.c_longlong(w_gstride), groups, _ptr(bias), _ptr(R), R.shape[-1] if R is not None else 0,
-                              _ptr(valid), _ptr(out), C.c_longlong(M * N), N, M, N, K, pro_act, C.c_float(pro_slope), epi_act,
+                              _ptr(valid), _ptr(out), C.c_longlong(M * N), N, M, N, K, pro_act | (0x100 if waves8 else 0), C.c_float(pro_slope), epi_act,
                               _ptr(g_), _ptr(b_), C.c_float(eps)))
     return out[0] if groups == 1 else out
 

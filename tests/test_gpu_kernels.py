@@ -339,12 +339,14 @@ def test_gemm_skinny_streams_weights_for_a_handful_of_rows(rt, M, N, K, a_mul, s
                                                  (16, 1024, 1024, 5, 4), (40, 96, 64, 2, 1), (32, 64, 64, 1, 0),
                                                  (5, 128, 2880, 1, 0), (17, 48, 320, 1, 0), (48, 512, 1024, 1, 0)])
 @pytest.mark.parametrize("pro", ["none", "relu", "lrelu", "ln"])
-def test_gemm_skinny_tile_major_weights_and_layernorm_prologue(rt, M, N, K, a_mul, shift0, pro):
+@pytest.mark.parametrize("waves8", [False, True])
+def test_gemm_skinny_tile_major_weights_and_layernorm_prologue(rt, M, N, K, a_mul, shift0, pro, waves8):
     """Round 4: gemm_skinny_tm_kernel - the weight-streaming kernel on the TILE-MAJOR copy of the weights (16-column x 64-k
     blocks, 1 KiB contiguous per load instruction, v_mfma_f32_16x16x4_f32 on 1..4 row tiles of 16), every prologue incl.
     LayerNorm (statistics of all rows per workgroup, A values normalised on the fly), strided row selection, K splits uneven
     over the eight waves (K/64 not a multiple of 8, waves without a chunk), all epilogue operands - against float64 and never
-    worse than twice the tiled f32-MFMA engine's error on the same inputs."""
+    worse than twice the tiled f32-MFMA engine's error on the same inputs.  Round 5: sixteen waves split K at M <= 32 (twelve
+    for K = 768) - the model's default - and the eight-wave form (`waves8`) for everything else."""
     if pro == "ln" and K > 1024:
         pytest.skip("LayerNorm prologue: K <= 1024")
     rng = np.random.default_rng(M * 131 + N + K + len(pro))
@@ -364,7 +366,8 @@ def test_gemm_skinny_tile_major_weights_and_layernorm_prologue(rt, M, N, K, a_mu
     ref = (np.maximum(a @ W.T.astype(np.float64) + b, 0) + R) * valid[:, None]
     Wt = rt.op_tile_major(dev(W))
     y = rt.op_gemm_tm(dev(X), Wt, K, N, K, bias=dev(b), R=dev(R), valid=dev(valid), M=M, a_mul=a_mul, shift0=shift0,
-                      pro_act=act, pro_slope=slope, epi_act=rt.ACT_RELU, ln=(dev(gam), dev(bet)) if pro == "ln" else None).cpu().numpy()
+                      pro_act=act, pro_slope=slope, epi_act=rt.ACT_RELU, ln=(dev(gam), dev(bet)) if pro == "ln" else None,
+                      waves8=waves8).cpu().numpy()
     assert np.isfinite(y).all()
     assert rel(y, ref) < 2e-6, rel(y, ref)
     assert not y[valid == 0].any()

@@ -279,6 +279,12 @@ int mt2_op_gemm_tm(void* stream, const float* X, long long x_gstride, int ldx, i
                    int Kw, int n0, int k0, long long w_gstride, int groups, const float* bias, const float* R, int ldr,
                    const int32_t* valid, float* C, long long c_gstride, int ldc, int M, int N, int K, int pro_act, float pro_slope,
                    int epi_act, const float* ln_gamma, const float* ln_beta, float ln_eps);
+/* The same hand-off at a handful of rows (tile-major weight-streaming kernel, M <= 64): stat_out != NULL - the epilogue also writes
+ * (mean, M2) of every final row per 16-column block, stat_out[M][N / 16][2]; ln_stat != NULL (with ln_gamma / ln_beta) - the LayerNorm
+ * prologue takes mean / rstd of source row r from ln_stat[r][ln_nt = K / 16][2] instead of reading the rows. */
+int mt2_op_gemm_tm_pairs(void* stream, const float* X, int ldx, int Rx, int a_mul, int shift0, const float* Wtm, int Kw,
+                         const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epi_act,
+                         const float* ln_gamma, const float* ln_beta, float ln_eps, float* stat_out, const float* ln_stat, int ln_nt);
 /* C[M,N] = act(LayerNorm(X rows m*a_mul + shift0; gamma, beta, eps) @ W^T + bias) in one launch (AR steps: LN1 -> QKV,
  * LN2 -> ff.0).  K <= 1024.  algebraic = 0: fragments normalised on the fly (force_cfg -1 or a 2-deep-ring config);
  * algebraic = 1 (what the model runs): W must be the gamma-scaled weights W'[n,k] = gamma[k] W[n,k], `bias` the vector

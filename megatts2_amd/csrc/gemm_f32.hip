@@ -2940,6 +2940,12 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
                       gemm_skinny_tm_eligible(p, o.skinny_rows))) {
         if (!gemm_skinny_tm_eligible(p, 64)) return hipErrorInvalidValue;
         p.sk_nw = o.skinny_nw;
+        if (p.stat_out) {       // row statistics as pairs per 16-column block (gemm_skinny_tm_kernel's epilogue): N / 16 <= 64 pairs per row
+            const int nt = p.N / 16;
+            if (p.groups == 1 && (nt & 1) == 0 && nt <= 64 && ((((unsigned long long)p.stat_out) & 15) == 0)) { p.stat_nt = nt; p.stat_w = 16; }
+            else { p.stat_out = nullptr; p.stat_nt = p.stat_w = 0; }
+        }
+        if (opts) { opts->last_stat_nt = p.stat_nt; opts->last_stat_w = p.stat_w; }
         const int sidx = p.M <= 32 ? kSkinnyTm32 : kSkinnyTm64;
         if (opts) opts->last_cfg = kCfgs[sidx].name;
         if (opts && opts->trace_on) {

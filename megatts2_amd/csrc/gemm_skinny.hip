@@ -233,7 +233,41 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_tm_kernel(GemmP p) {
     float mu[RT], rs[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) { mu[i] = 0.0f; rs[i] = 1.0f; }
-    if (LNP) {
+    if (LNP && p.ln_stat) {
+        // Round 5: the rows came with their statistics - (mean, M2) pairs per 16-column block, written by the epilogue of the
+        // GEMM that produced them (GemmP::stat_out, below).  Sixteen lanes per row merge its <= 64 pairs (Chan, fixed order:
+        // two float4 = four pairs per lane at most) instead of every workgroup re-reading all M x K activations twice.
+        const int nq = p.ln_nt >> 1, part = lane & 15;
+        const float wc = (float)p.ln_w, inv_nt = 1.0f / (float)p.ln_nt;
+        for (int r0 = wave * 4; r0 < p.M; r0 += NW * 4) {
+            const int r = r0 + (lane >> 4);
+            const int src = r * p.a_mul + p.shift0;
+            const bool ok = r < p.M && src >= 0 && src < p.Rx;
+            const f32x4* __restrict__ pr = reinterpret_cast<const f32x4*>(p.ln_stat) + (long long)(ok ? src : 0) * nq;
+            f32x4 q0 = f32x4{0.f, 0.f, 0.f, 0.f}, q1 = q0;
+            if (ok && part < nq) q0 = pr[part];
+            if (ok && part + 16 < nq) q1 = pr[part + 16];
+            float sm = (q0.x + q0.z) + (q1.x + q1.z);
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
+            const float mean = sm * inv_nt;
+            float m2 = 0.0f;
+            if (part < nq) { const float d0 = q0.x - mean, d1 = q0.z - mean; m2 += (q0.y + wc * d0 * d0) + (q0.w + wc * d1 * d1); }
+            if (part + 16 < nq) { const float d0 = q1.x - mean, d1 = q1.z - mean; m2 += (q1.y + wc * d0 * d0) + (q1.w + wc * d1 * d1); }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) m2 += __shfl_xor(m2, o);
+            if (part == 0 && r < p.M) {
+                stat[2 * r] = ok ? mean : 0.0f;
+                stat[2 * r + 1] = ok ? rsqrtf(m2 * inv_nt / wc + p.ln_eps) : 0.0f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            const int m = i * 16 + col;
+            if (m < p.M) { mu[i] = stat[2 * m]; rs[i] = stat[2 * m + 1]; }
+        }
+    } else if (LNP) {
         const int Kf = p.K;
         const float inv_k = 1.0f / (float)Kf;
         const float* __restrict__ Xg = p.X + (long long)g * p.strideX;
@@ -348,11 +382,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_tm_kernel(GemmP p) {
 #pragma unroll
         for (int w2 = 1; w2 < NW; ++w2) sacc += sk_red[((w2 * RT + i) * 4 + e) * 64 + ln];
         const int m = i * 16 + (ln >> 4) * 4 + e, n = n0 + (ln & 15);
+        float v = 0.0f;
         if (m < p.M && n < p.N) {
-            float v = sk_act(epi, sacc + (bias ? bias[n] : 0.0f), slope) * osc;
+            v = sk_act(epi, sacc + (bias ? bias[n] : 0.0f), slope) * osc;
             if (R) v += R[(long long)m * p.ldr + n];
             if (p.valid && p.valid[m] == 0) v = 0.0f;
             C[(long long)m * p.ldc + n] = v;
+        }
+        if (p.stat_out) {       // (mean, M2) of this row's 16 columns: the 16 lanes that hold them are neighbours (t is wave-uniform in range)
+            float sv = v, qv = v * v;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { sv += __shfl_xor(sv, o); qv += __shfl_xor(qv, o); }
+            if ((ln & 15) == 0 && m < p.M) {
+                const float mean = sv * (1.0f / 16.0f);
+                float2 pr2;
+                pr2.x = mean;
+                pr2.y = fmaxf(qv - sv * mean, 0.0f);
+                *reinterpret_cast<float2*>(p.stat_out + ((long long)m * p.stat_nt + nb) * 2) = pr2;
+            }
         }
     }
 }
@@ -377,8 +424,10 @@ bool gemm_skinny_eligible(const GemmP& p, int max_rows) {
 // tile-major form: whole 16-column x 64-k blocks only; the LayerNorm prologue exists in this form only
 bool gemm_skinny_tm_eligible(const GemmP& p, int max_rows) {
     if (!p.Wtm || p.tm_kb <= 0) return false;
+    const bool pairs_ok = !p.ln_stat || (p.ln_w == 16 && p.ln_nt * 16 == p.K && (p.ln_nt & 1) == 0 && p.ln_nt <= 64 &&
+                                         (reinterpret_cast<uintptr_t>(p.ln_stat) & 15) == 0);
     const bool pro_ok = (p.pro_act >= ACT_NONE && p.pro_act <= ACT_LRELU) ||
-                        (p.pro_act == 3 && p.ln_g && p.ln_b && p.K <= 1024 && p.groups == 1);
+                        (p.pro_act == 3 && p.ln_g && p.ln_b && p.K <= 1024 && p.groups == 1 && pairs_ok);
     return p.taps == 1 && !p.rowbase && p.M >= 1 && p.M <= max_rows && p.M <= 64 && p.K >= 64 && (p.K & 63) == 0 &&
            (p.N & 15) == 0 && (p.ldx & 3) == 0 && (p.ldw & 63) == 0 && (p.strideX & 3) == 0 && (p.strideW & 63) == 0 &&
            (p.groups == 1 || ((p.strideW % p.ldw) == 0 && ((p.strideW / p.ldw) & 15) == 0) ||

@@ -151,6 +151,9 @@ static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, 
         // one launch, statistics computed while the first weight pieces are in flight
         GemmP q = p;
         q.pro_act = 3; q.ln_g = w.g; q.ln_b = w.b;
+        if (st && st->stat && st->stat_w == 16 && c.m.opts.skinny_pairs) {      // the rows' statistics came with them (16-column pairs)
+            q.ln_stat = st->stat; q.ln_nt = st->stat_nt; q.ln_w = 16;
+        }
         attach_tm(c.m, q);
         if (q.Wtm && gemm_skinny_tm_eligible(q, c.m.opts.skinny_rows)) {
             // launch_gemm routes to the tile-major kernel only when its own conditions hold too (skinny_groups); with another
@@ -280,7 +283,7 @@ static EncScratch enc_scratch(const Ctx& c, const EncW& e, int M) {
     // split-K slabs [S][M, d]: the f32 rule of choose_split keeps tiles(32x64) * S <= 256 (S * M * d <= 256 * 32 * 64 *
     // d / 64); the x6 rule splits at most 8 ways at any M
     s.parts = c.ws.get<float>(std::max((size_t)256 * 32 * 64 + (size_t)16 * 32 * e.d, (size_t)8 * M * e.d));
-    s.stat = c.ws.get<float>((size_t)M * 64);      // row statistics handed from GEMM to GEMM: <= 32 (mean, M2) pairs per row
+    s.stat = c.ws.get<float>((size_t)M * 128);     // row statistics handed from GEMM to GEMM: <= 64 (mean, M2) pairs per row
     return s;
 }
 static void attention_self(const Ctx& c, const EncW& e, const AttnGeom& g, const float* qkv, float* att) {
@@ -381,10 +384,13 @@ static void ln_pending(const Ctx& c, float* x, int d, int M, const Pending& in, 
 // x += a @ W^T + b (residual update in the GEMM's epilogue); with ln_pairs the epilogue also leaves the row statistics of the
 // new x as pairs in `stat` where the chosen tile can - the returned Pending says whether it did
 static Pending linear_residual(const Ctx& c, const float* a, int lda, int M, const float* W, const float* b, int N, int K,
-                               float* x, float* stat) {
+                               float* x, float* stat, const float* res = nullptr, int ldr = 0) {
     GemmP p{};
-    p.X = a; p.ldx = lda; p.Rx = M; p.Cin = K; p.W = W; p.bias = b; p.R = x; p.ldr = N; p.C = x; p.ldc = N; p.M = M; p.N = N;
-    const bool want = c.m.opts.ln_pairs > 0 && stat != nullptr && M > 64 && M <= c.m.opts.ln_pairs_maxm && c.m.opts.force_cfg < 0;
+    p.X = a; p.ldx = lda; p.Rx = M; p.Cin = K; p.W = W; p.bias = b; p.R = res ? res : x; p.ldr = res ? ldr : N; p.C = x; p.ldc = N;
+    p.M = M; p.N = N;
+    const bool small = M <= 64 && M <= c.m.opts.skinny_rows && c.m.opts.skinny_tm && c.m.opts.skinny_pairs;     // tile-major kernel: pairs per 16 columns
+    const bool want = stat != nullptr && c.m.opts.force_cfg < 0 &&
+                      (small || (c.m.opts.ln_pairs > 0 && M > 64 && M <= c.m.opts.ln_pairs_maxm));
     if (want) p.stat_out = stat;
     gemm(c, p);
     Pending r{};
@@ -479,8 +485,8 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
     a.ds_short = c.m.opts.attn_ds;
     MT2_HIP(launch_attention(a, c.s));
     // y = x[last rows] + out_proj(att): the residual rows sit n*d floats apart starting at row n-1
-    linear(c, att, d, A, w.wo, w.bo, d, d, y, d, x + (size_t)(n - 1) * d, n * d);
-    ln_linear(c, y, d, A, 1, 0, A, ln2_ff0(w, d), e.ff, d, s.f, e.ff, s.h, ACT_RELU);   // LN2 -> ff.0
+    const Pending py = linear_residual(c, att, d, A, w.wo, w.bo, d, d, y, s.stat, x + (size_t)(n - 1) * d, n * d);
+    ln_linear(c, y, d, A, 1, 0, A, ln2_ff0(w, d), e.ff, d, s.f, e.ff, s.h, ACT_RELU, &py);   // LN2 -> ff.0
     linear(c, s.f, e.ff, A, w.ff1w, w.ff1b, d, e.ff, y, d, y, d);
 }
 

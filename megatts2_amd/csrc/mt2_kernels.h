@@ -122,6 +122,8 @@ struct EngineOpts {
     int skinny_unsplit = 0;      // launches of at most skinny_rows rows: no K split even for the long chains (PLM ff.3, K = 4096): the
                                  // kernel adds bias + residual itself and the next LayerNorm rides in the consuming GEMM's prologue.
                                  // MEASURED NEGATIVE: C1 +7.3 % (64 workgroups stream 256 KiB each; the four-slice form keeps 256 busy)
+    int skinny_pairs = 1;        // launches of at most skinny_rows rows: the residual GEMM's epilogue leaves (mean, M2) pairs per 16-column block
+                                 // and the LayerNorm prologue of the consuming launch merges them instead of re-reading all M x K rows
     int skinny_nw = 16;          // waves of the tile-major weight-streaming kernel that split K (8; 16: four per SIMD - twelve for K = 768 -
                                  // at M <= 32: C1 -1.8 %, profiles/r05_opts_ab.txt)
     int skinny_nt = 0;           // gemm_skinny.hip (0: off); skinny_nt: non-temporal weight loads (measured: C1 65.2 ms with, 56.8 without)

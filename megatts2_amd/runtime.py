@@ -627,6 +627,22 @@ def op_gemm_tm(X, Wtm, Kw, N, K, n0=0, k0=0, groups=1, x_gstride=0, w_gstride=0,
     return out[0] if groups == 1 else out
 
 
+def op_gemm_tm_pairs(X, Wtm, Kw, N, K, bias=None, R=None, M=None, a_mul=1, shift0=0, epi_act=ACT_NONE, ln=None, want_stats=False,
+                     pairs=None, eps=1e-5):
+    """mt2_op_gemm_tm_pairs: the <= 64-row kernel with the statistics epilogue (want_stats -> (out, pairs [M, N / 16, 2])) and / or
+    the pair-fed LayerNorm prologue (ln = (gamma, beta), pairs = [rows, K / 16, 2] of the source rows)."""
+    import torch
+    lib = load_library()
+    M = M or X.shape[0]
+    out = torch.empty(M, N, device=X.device, dtype=torch.float32)
+    stat = torch.zeros(M, N // 16, 2, device=X.device, dtype=torch.float32) if want_stats else None
+    g_, b_ = ln if ln is not None else (None, None)
+    _check(lib.mt2_op_gemm_tm_pairs(_stream(), _ptr(X), X.shape[1], X.shape[0], a_mul, shift0, _ptr(Wtm), Kw, _ptr(bias), _ptr(R),
+                                    R.shape[1] if R is not None else 0, _ptr(out), N, M, N, K, epi_act, _ptr(g_), _ptr(b_),
+                                    C.c_float(eps), _ptr(stat), _ptr(pairs), pairs.shape[1] if pairs is not None else 0))
+    return (out, stat) if want_stats else out
+
+
 def split_bf16x3(W):
     """f32 tensor -> three bf16 planes (uint16 bit patterns, [3, *W.shape]) by truncation; their sum is W exactly."""
     import torch

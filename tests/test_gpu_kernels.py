@@ -377,6 +377,41 @@ def test_gemm_skinny_tile_major_weights_and_layernorm_prologue(rt, M, N, K, a_mu
         assert rel(y, ref) <= 2.0 * rel(f32, ref) + 1e-7
 
 
+@pytest.mark.parametrize("M,d,N2", [(16, 1024, 4096), (1, 768, 1024), (23, 768, 2304), (32, 1024, 3072), (42, 768, 1024), (64, 1024, 1024)])
+def test_skinny_layernorm_prologue_fed_by_pairs(rt, M, d, N2):
+    """Round 5, the one-utterance path (F.linear with a handful of rows at models/megatts2.py:172-179,264-273 inside
+    TransformerEncoderLayer.forward, modules/transformer.py:88-102): the residual GEMM on the tile-major kernel leaves (mean, M2) of
+    every new row per 16-column block, and the LayerNorm prologue of the consuming launch merges those pairs (Chan) instead of
+    re-reading all M x K rows in every workgroup.  Pairs and both outputs against float64; the self-computed prologue as yardstick."""
+    rng = np.random.default_rng(M * 7 + d + N2)
+    att = rng.standard_normal((M, d)).astype(np.float32)
+    x = (rng.standard_normal((M, d)) * 2.0 + 0.5).astype(np.float32)
+    x[::3] += 5.0
+    Wo = (rng.standard_normal((d, d)) / math.sqrt(d)).astype(np.float32)
+    bo = rng.standard_normal(d).astype(np.float32)
+    Wt = rt.op_tile_major(dev(Wo))
+    xn, pairs = rt.op_gemm_tm_pairs(dev(att), Wt, d, d, d, bias=dev(bo), R=dev(x), want_stats=True)
+    xn_h = xn.cpu().numpy()
+    assert rel(xn_h, att.astype(np.float64) @ Wo.T.astype(np.float64) + bo + x) < 2e-6
+    tiles = xn_h.astype(np.float64).reshape(M, d // 16, 16)
+    ph = pairs.cpu().numpy().astype(np.float64)
+    assert np.abs(ph[:, :, 0] - tiles.mean(2)).max() < 5e-6 * (1 + np.abs(tiles).max())
+    m2 = ((tiles - tiles.mean(2, keepdims=True)) ** 2).sum(2)
+    assert np.abs(ph[:, :, 1] - m2).max() < 3e-5 * m2.max()
+    g = (1 + 0.2 * rng.standard_normal(d)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(d)).astype(np.float32)
+    W = (rng.standard_normal((N2, d)) / math.sqrt(d)).astype(np.float32)
+    bias = rng.standard_normal(N2).astype(np.float32)
+    W2 = rt.op_tile_major(dev(W))
+    x64 = xn_h.astype(np.float64)
+    ln = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * g + b
+    ref = np.maximum(ln @ W.T.astype(np.float64) + bias, 0)
+    fed = rt.op_gemm_tm_pairs(xn, W2, d, N2, d, bias=dev(bias), epi_act=rt.ACT_RELU, ln=(dev(g), dev(b)), pairs=pairs).cpu().numpy()
+    own = rt.op_gemm_tm_pairs(xn, W2, d, N2, d, bias=dev(bias), epi_act=rt.ACT_RELU, ln=(dev(g), dev(b))).cpu().numpy()
+    e1, e2 = rel(fed, ref), rel(own, ref)
+    assert e1 < 2e-6 and e1 < 3 * e2 + 1e-7, (e1, e2)
+
+
 def test_skinny_prologues_treat_non_finite_inputs_like_the_tiled_engine(rt):
     """the <= 64-row kernels' branch-free prologue once computed `v * 0` for ReLU (-inf -> NaN) where the tiled
     engine's fmaxf(v, 0) gives 0.  Rows carrying -inf / +inf / NaN through ReLU and leaky ReLU: the row-major kernel (87), the

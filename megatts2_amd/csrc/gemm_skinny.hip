@@ -451,6 +451,11 @@ hipError_t launch_gemm_skinny_tm(const GemmP& p, hipStream_t s) {
         if (p.M <= 16) return ln ? sk_tm_launch<1, 1, true, 12>(p, s) : sk_tm_launch<1, 1, false, 12>(p, s);
         return ln ? sk_tm_launch<2, 1, true, 12>(p, s) : sk_tm_launch<2, 1, false, 12>(p, s);
     }
+    // three row tiles (the ADM's steps 33 .. 48 of a lone utterance): twelve waves at K = 768 (168 registers per wave); sixteen at
+    // K = 1024 for the plain prologue only (128 registers: the LayerNorm form and a second chunk in flight would spill)
+    if (p.sk_nw == 16 && p.M > 32 && p.M <= 48 && (p.K >> 6) == 12)
+        return ln ? sk_tm_launch<3, 1, true, 12>(p, s) : sk_tm_launch<3, 1, false, 12>(p, s);
+    if (p.sk_nw == 16 && p.M > 32 && p.M <= 48 && (p.K >> 6) >= 16 && (p.K >> 6) <= 16 && !ln) return sk_tm_launch<3, 1, false, 16>(p, s);
     switch ((p.M + 15) / 16) {
         case 1:
             if (ln) return sk_tm_launch<1, 2, true>(p, s);

@@ -341,7 +341,8 @@ static int choose_split(const Ctx& c, int M, int N, int K) {
         (N & 15) == 0 && (K & 63) == 0) {
         if (K <= 1536 || c.m.opts.skinny_unsplit) return 1;
         int S = 1;
-        while (S < 16 && K % (S * 2) == 0 && K / (S * 2) >= 1024 && (K / (S * 2)) % 64 == 0) S *= 2;
+        const int kmin = c.m.opts.skinny_kslice >= 256 ? c.m.opts.skinny_kslice : 1024;      // narrowest K slice
+        while (S < 16 && K % (S * 2) == 0 && K / (S * 2) >= kmin && (K / (S * 2)) % 64 == 0) S *= 2;
         return S;
     }
     // x6 form (large M): the N = d GEMMs of a layer (out-projection, ff.3) have too few 128x128 tiles for the bf16 pipe

@@ -119,6 +119,7 @@ struct EngineOpts {
     int attn_ds = 1;             // short sequences on the AR heads: head dim split over the waves as well (AttnP::ds_short)
     bool skinny_tm = true;       // ... on the tile-major weight copy where one exists (gemm_skinny_tm_kernel; LayerNorm prologue included)
     int skinny_groups = 1;       // ... only for launches with at least this many GemmP groups (split-K slabs)
+    int skinny_kslice = 1024;    // ... the narrowest K slice of such a split (PLM ff.3, K = 4096: four slices of 1024)
     int skinny_unsplit = 0;      // launches of at most skinny_rows rows: no K split even for the long chains (PLM ff.3, K = 4096): the
                                  // kernel adds bias + residual itself and the next LayerNorm rides in the consuming GEMM's prologue.
                                  // MEASURED NEGATIVE: C1 +7.3 % (64 workgroups stream 256 KiB each; the four-slice form keeps 256 busy)

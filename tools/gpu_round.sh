@@ -13,6 +13,7 @@
 #   sweep sweep_ar sweep_voc sweep_vocx   GEMM engine sweeps (all / AR shapes / vocoder shapes / vocoder launch variants)
 #   sweep_x6 sweep_x6s sweep_x6k sweep_skinny   x6 tile forms / under-filled AR launches / K-split x6 tiles / M <= 64 kernel
 #   frontend s2                      rows f3 / f2 measurements
+#   pmc1                             C1: per-kernel FETCH_SIZE and MFMA-busy PMC passes (tools/pmc_summary.py)
 #   graph newtests                   hipGraph replay vs stream launches (boundary ubench); this round's new parity tests (TEST_K)
 #   gridsync cpuinfo                 phase-boundary ubench (launch chain vs in-kernel grid barrier); host CPU limits of the box
 #   strong                           bench.py --scaling strong on one rank (C4: 256 ragged utterances in one call)
@@ -225,6 +226,17 @@ thresh)
     IFS=, read a b c <<< "$t"
     timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --opt t_ks4=$a --opt t_ks2=$b --opt t32=$c > gpurun_out/bench_t_$t.log 2>&1
     echo "thresh $t rc=$?"; tail -1 gpurun_out/bench_t_$t.log | cut -c1-400
+  done ;;
+pmc1)
+  # the one-utterance path (C1): HBM-side read bytes and matrix-pipe cycles per kernel (two separate --pmc passes, kernel trace only)
+  for c in FETCH_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+    t=$(echo $c | cut -d" " -f1)
+    rm -rf gpurun_out/pmc1_$t
+    (cd /tmp && timeout 600 rocprofv3 --pmc $c --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc1_$t -o pmc -- python $GRAFT_REPO_ROOT/bench.py --workload C1 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-sub-workloads) > gpurun_out/pmc1_$t.log 2>&1
+    echo "pmc1 $t rc=$?"; tail -1 gpurun_out/pmc1_$t.log | cut -c1-200
+    f=$(find gpurun_out/pmc1_$t -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python tools/pmc_summary.py "$f" 2 gpurun_out/pmc1_$t.md | head -24 | cut -c1-220
+    find gpurun_out/pmc1_$t -name "*.csv" -size +8M -delete
   done ;;
 pmc)
   for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES"; do

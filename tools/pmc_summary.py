@@ -15,7 +15,7 @@ def main(path, steps="1", out=None):
     seen = set()
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
-            name = re.sub(r"\(.*", "", row.get("Kernel_Name", "?")).replace("void ", "")
+            name = re.sub(r"\(.*", "", row.get("Kernel_Name", "?").replace("(anonymous namespace)::", "")).replace("void ", "")
             cn = row.get("Counter_Name")
             per[name][cn] += float(row.get("Counter_Value", 0) or 0)
             key = (row.get("Dispatch_Id"), name)

@@ -835,6 +835,12 @@ static TcResult tc_latent_rows(const Ctx& c, const int64_t* phone, const int* ph
 // non-causally, exactly as the reference does (models/megatts2.py:172-179,264-273) -
 // a KV cache would change the result.
 
+// per-stage value of an engine option for the duration of a stage driver (restored on every exit path)
+struct OptGuard {
+    int& slot; int saved;
+    OptGuard(int& s_, int v) : slot(s_), saved(s_) { if (v >= 0) slot = v; }
+    ~OptGuard() { slot = saved; }
+};
 struct ArOrder {
     std::vector<int> slot_b, len;   // slot j -> utterance, length
     int nmax = 0;
@@ -899,6 +905,7 @@ static void adm_run(const Ctx& c, const float* tc, int ld_tc, int tc_rows, const
                     const ArPrefix& pre = ArPrefix()) {
     mt2_model& m = c.m;
     const mt2_config& cfg = m.cfg;
+    const OptGuard pairs_guard(m.opts.ln_pairs, m.opts.ln_pairs_adm);
     const EncW& e = m.adm_enc;
     const int d = e.d, Dc = cfg.adm_tc_emb_dim, De = cfg.adm_emb_dim;
     ArOrder ord = ar_order(lens, B);
@@ -974,6 +981,7 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
                     const ArPrefix& pre = ArPrefix()) {
     mt2_model& m = c.m;
     const mt2_config& cfg = m.cfg;
+    const OptGuard pairs_guard(m.opts.ln_pairs, m.opts.ln_pairs_plm);
     const EncW& e = m.plm_enc;
     const int d = e.d, Dc = cfg.plm_tc_dim, De = cfg.plm_vq_dim, NB = cfg.plm_bins;
     ArOrder ord = ar_order(lens, B);

@@ -143,9 +143,13 @@ struct EngineOpts {
                                  // Parity-green and MEASURED NEGATIVE, hence 0 (profiles/r05_opts_ab.txt, interleaved: C3 +0.65 %
                                  // with 1, +0.9 % with 2; C5 +2.0 %; C2 -1.0 %): the LayerNorm launches it removes ran in the
                                  // shadow of the other AR chain, the epilogue work it adds does not
+    int ln_pairs_adm = 2, ln_pairs_plm = -1;       // per-stage override of ln_pairs (-1: none).  The ADM alone (d = 768: both residual GEMMs
+                                 // have K <= 1024, nothing rides on a K-split reduce any more) is where the hand-off pays at B = 32:
+                                 // interleaved C3 -0.43 %, C2 -1.3 %, C5 +0.1 % with the row cap below (profiles/r05_opts_ab.txt)
     int ln_pairs_maxk = 1024;    // ... ln_pairs = 2: the longest K chain that is taken out of the K split
-    int ln_pairs_maxm = 2048;    // ... only for launches of at most this many rows: beyond, the consumers run on the 256x128 tile
-                                 // (no pair-fed form) and a LayerNorm launch is no longer a latency item (C5: 5342 vs 5210 ms without the cap)
+    int ln_pairs_maxm = 1280;    // ... only for launches of at most this many rows: beyond, the consumers run on the 256x128 tile
+                                 // (no pair-fed form) and a LayerNorm launch is no longer a latency item (C5: 5342 vs 5210 ms without a cap,
+                                 // +0.46 % for the ADM alone at 2048, +0.1 % at 1280)
 };
 hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
 // gemm_skinny.hip: weight-streaming linear layer for M <= 64 rows (taps = 1, no rowbase, K a multiple of 32)

@@ -224,7 +224,7 @@ int mt2_synthesize_prompt_conditioned(mt2_model* m, void* stream, const int64_t*
 /* ---- tuning.  Every switch lives in the handle (no process-global state): two handles do not see each other's
  * settings.  Names: "ar_groups" (1..8, default 2: the sequences of an autoregressive run are dealt into that many
  * independent kernel chains on internal HIP streams that fork from and join back into `stream`; results do not
- * depend on it), "lnalg" (0: algebraic LayerNorm in the AR layers), "ln_pairs" (0; 1 / 2: LayerNorm statistics handed from GEMM to GEMM in the AR layers), "skinny_pairs" (1: the same inside the <= 64-row kernel), "skinny_nw" (16), "splitk" (1), "lnfuse" (0), "voc_streams" (3),
+ * depend on it), "lnalg" (0: algebraic LayerNorm in the AR layers), "ln_pairs" (0; 1 / 2: LayerNorm statistics handed from GEMM to GEMM in the AR layers) with the per-stage overrides "ln_pairs_adm" (2) / "ln_pairs_plm" (-1), "skinny_pairs" (1: the same inside the <= 64-row kernel), "skinny_nw" (16), "splitk" (1), "lnfuse" (0), "voc_streams" (3),
  * "x6_conv" (1: window convolutions on the bf16 matrix pipe in the f32-equivalent 6-product form), "x6_gemm" (1: the same for
  * the implicit-GEMM launches with enough big tiles), "x6_splitk" (1), "t_x6_256" (160), "t_x6_128" (72), "t_x6_64" (0: tile-count thresholds of
  * the two x6 tile shapes), "nt_weights" (0) / "nt_row_tiles" (2: non-temporal weight loads for launches with at most that many

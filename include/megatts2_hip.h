@@ -254,6 +254,21 @@ int mt2_op_gemm(void* stream, const float* X, int ldx, int Rx, const int32_t* ro
 int mt2_op_gemm_x6(void* stream, const float* X, int ldx, int Rx, int shift0, int taps, int dil, int Cin, const float* W,
                    const void* W3, const float* bias, const float* R, int ldr, const int32_t* valid, float* C, int ldc,
                    int M, int N, int pro_act, float pro_slope, int epi_act, int force_cfg);
+/* The same launch with the weights ALSO as two fp16 planes Wh [2][N][K] (hi, lo * 2^11) of the row-scaled matrix and the inverse
+ * power-of-two row scales wh_inv [N] (mt2_x3h_split): the Linear / Conv1d of modules/transformer.py:35-57,88-102 and
+ * modules/convnet.py:23-31 on the fp16 matrix pipe in the f32-equivalent THREE-product form (csrc/gemm_x3h.hip; force_cfg 91..94
+ * or -1).  range_flag (device int32, may be NULL): |= 1 when an activation with |a| >= 65504 was converted (fp16 range). */
+int mt2_op_gemm_x3h(void* stream, const float* X, int ldx, int Rx, int shift0, int taps, int dil, int Cin, const float* W,
+                    const void* W3, const void* Wh, const float* wh_inv, const float* bias, const float* R, int ldr,
+                    const int32_t* valid, float* C, int ldc, int M, int N, int pro_act, float pro_slope, int epi_act, int force_cfg,
+                    int32_t* range_flag);
+/* host helper: the fp16-pipe operand format of a row-major f32 matrix W [rows][row_len] (host memory): planes [2][rows * row_len]
+ * uint16 (fp16 bit patterns), inv [rows] */
+int mt2_x3h_split(const float* W, long long rows, long long row_len, uint16_t* planes, float* inv);
+/* Range guard of the fp16-pipe GEMMs inside a model handle (option "x3h", default 1): waits for the handle's last call, then
+ * *tripped = 1 (and the guard is re-armed) when that call converted an activation outside the fp16 range - its outputs are then
+ * to be discarded and the call repeated with mt2_set_option(m, "x3h", 0) (the bf16 six-product form has f32's exponent range). */
+int mt2_x3h_guard(mt2_model* m, int* tripped);
 /* LayerNorm statistics handed from GEMM to GEMM (round 5; the AR layers of models/megatts2.py:172-179,264-273 =
  * TransformerEncoderLayer.forward, modules/transformer.py:88-102: `x = x + out_proj(...)` followed by `norm2(x)`, `x = x + ff(...)`
  * followed by the next layer's `norm1(x)`).  ONE linear launch C = epi(X @ W^T + bias) + R on a bf16-pipe (x6) tile with
@@ -323,6 +338,10 @@ const char* mt2_gemm_config_name(int idx);
  * flags bit0: leaky-ReLU prologue, bit1: bias + residual + row-mask epilogue, bit2: clock probe - one wave of the
  * loader-wave x6 kernel reads s_memtime and s_memrealtime around its K loop; `sustained_ghz` (nullable) receives the
  * shader clock that launch ran at (0 when the configuration has no probe), bit3: no stderr report; average ms */
+int mt2_op_gemm_x3h_ln(void* stream, const float* X, int ldx, int Rx, int a_mul, int shift0, const float* W, const void* W3,
+                       const void* Wh, const float* wh_inv, const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N,
+                       int K, int epi_act, int force_cfg, float* stat_out, int32_t* stat_nt, int32_t* stat_w, const float* ln_stat,
+                       int ln_nt, int ln_w, const float* ln_s, float ln_eps);   /* mt2_op_gemm_x6_ln with the fp16 planes as well */
 int mt2_bench_gemm(void* stream, int M, int N, int K, int taps, int dil, int flags, int force_cfg, int iters,
                    int w_copies, float* avg_ms, char* cfg_name, int cfg_name_cap, double* sustained_ghz);
 

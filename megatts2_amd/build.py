@@ -21,11 +21,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmegatts2_hip.so")
-UNITS = ["gemm_f32.hip", "gemm_skinny.hip", "attention.hip", "rowops.hip", "model_load.hip", "model_stages.hip"]
-AUDITED = ["gemm_f32.hip"]      # units whose device assembly is audited (inline-asm LDS reads in loops)
-DEPS = ["mt2_kernels.h", "mt2_model.h", "capi.inc", os.path.join("..", "..", "include", "megatts2_hip.h")]
+UNITS = ["gemm_f32.hip", "gemm_x3h.hip", "gemm_skinny.hip", "attention.hip", "rowops.hip", "model_load.hip", "model_stages.hip"]
+AUDITED = ["gemm_f32.hip", "gemm_x3h.hip"]      # units whose device assembly is audited (inline-asm LDS reads in loops)
+DEPS = ["mt2_kernels.h", "mt2_model.h", "gemm_common.h", "x3h_planes.h", "capi.inc", os.path.join("..", "..", "include", "megatts2_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("MT2_EXTRA_HIPCC_FLAGS", "").split()      # e.g. -DMT2_PHASE_TIMING (tools/x6_phase_timing.py)
+# per unit: the fp16 split of gemm_x3h.hip wants scalar f32 VALU (v_mul_f32 + v_fma_mix_f32), not hipcc's SLP-packed v_pk_* forms
+UNIT_FLAGS = {"gemm_x3h.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:
@@ -41,6 +43,7 @@ def _digest() -> str:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(UNIT_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -56,7 +59,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def compile_one(unit: str) -> str:
         obj = os.path.join(LIBDIR, unit.replace(".hip", ".o"))
         if unit not in AUDITED:
-            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, unit), "-o", obj]
+            cmd = [hipcc, *FLAGS, *UNIT_FLAGS.get(unit, []), "-c", os.path.join(CSRC, unit), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
@@ -69,7 +72,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         stem = unit.replace(".hip", "")
         with tempfile.TemporaryDirectory(prefix="mt2_build_") as tmp:
             tobj = os.path.join(tmp, stem + ".o")
-            cmd = [hipcc, *FLAGS, "-save-temps=obj", "-c", os.path.join(CSRC, unit), "-o", tobj]
+            cmd = [hipcc, *FLAGS, *UNIT_FLAGS.get(unit, []), "-save-temps=obj", "-c", os.path.join(CSRC, unit), "-o", tobj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -12,6 +12,7 @@
 //   ConvTranspose1d weight [Cin, Cout, k=2s] (padding s/2) -> two phase matrices [s/2*Cout, 2*Cin]
 //            (see hifigan stage in model_stages.hip)
 #include "mt2_model.h"
+#include "x3h_planes.h"
 
 #include <algorithm>
 #include <cstring>
@@ -130,15 +131,35 @@ struct Loader {
     }
     bool has(const std::string& name) const { return m.host.count(name) != 0; }
 
-    // planes = true: a GEMM / conv weight matrix - also kept as three bf16 planes (PlaneRange)
-    float* upload(const std::vector<float>& v, bool planes = false) {
+    // row_len > 0: a GEMM / conv weight matrix with rows of row_len elements - also kept as three bf16 planes and as two fp16
+    // planes of the row-scaled matrix (PlaneRange)
+    float* upload(const std::vector<float>& v, size_t row_len = 0) {
+        const bool planes = row_len > 0;
         float* d = nullptr;
         const size_t bytes = v.size() * sizeof(float);
         MT2_HIP(hipMalloc(reinterpret_cast<void**>(&d), bytes ? bytes : 4));
         if (bytes) MT2_HIP(hipMemcpy(d, v.data(), bytes, hipMemcpyHostToDevice));
         m.dev_allocs.push_back(d);
         m.weight_bytes += bytes;
-        if (planes && !v.empty()) m.planes.push_back({d, v.size(), upload_planes(v)});
+        if (planes && !v.empty()) {
+            MT2_REQUIRE(v.size() % row_len == 0, "weight buffer is not a whole number of rows");
+            PlaneRange pr{d, v.size(), upload_planes(v)};
+            const size_t rows = v.size() / row_len;
+            std::vector<uint16_t> ph(2 * v.size());
+            std::vector<float> inv(rows);
+            x3h_split_rows(v.data(), rows, row_len, ph.data(), inv.data());
+            void* dp = nullptr;
+            MT2_HIP(hipMalloc(&dp, ph.size() * sizeof(uint16_t)));
+            MT2_HIP(hipMemcpy(dp, ph.data(), ph.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            m.dev_allocs.push_back(dp);
+            void* di = nullptr;
+            MT2_HIP(hipMalloc(&di, inv.size() * sizeof(float)));
+            MT2_HIP(hipMemcpy(di, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice));
+            m.dev_allocs.push_back(di);
+            m.weight_bytes += ph.size() * sizeof(uint16_t) + inv.size() * sizeof(float);
+            pr.ph = static_cast<const uint16_t*>(dp); pr.inv = static_cast<const float*>(di); pr.row_len = row_len;
+            m.planes.push_back(pr);
+        }
         return d;
     }
     // f32 -> three bf16 planes by truncation: v = p1 + p2 + p3 EXACTLY (3 x 8 significant bits); [3][n] uint16
@@ -201,11 +222,11 @@ struct Loader {
         w.cout = cout; w.cin = cin; w.k = k;
         std::vector<float> packed;
         pack_conv(get(p + ".weight", {cout, cin, k}), packed);
-        w.w = upload(packed, true);
+        w.w = upload(packed, (size_t)k * cin);
         w.b = vec(p + ".bias", cout);
         return w;
     }
-    float* wmat(const std::string& name, int64_t r, int64_t c) { return upload(get(name, {r, c}).data, true); }
+    float* wmat(const std::string& name, int64_t r, int64_t c) { return upload(get(name, {r, c}).data, (size_t)c); }
     // ResidualBlockStack of `groups` parallel branches; prefix(l) gives branch l's stack prefix
     template <class F> StackW stack(F prefix, int groups, int C, int k, int nstack, int nblock) {
         StackW s;
@@ -224,7 +245,7 @@ struct Loader {
                     const auto& ee = get(p + ".norm.bias", {C}).data;
                     be.insert(be.end(), ee.begin(), ee.end());
                 }
-        s.w = upload(w, true); s.b = upload(b); s.g = upload(g); s.be = upload(be);
+        s.w = upload(w, (size_t)C * k); s.b = upload(b); s.g = upload(g); s.be = upload(be);
         return s;
     }
     EncW encoder(const std::string& prefix, int layers, int d, int ff, int heads, bool conv_ff) {
@@ -242,15 +263,15 @@ struct Loader {
                 const auto& bb = get(p + ".attn." + n + ".bias", {d}).data;
                 bqkv.insert(bqkv.end(), bb.begin(), bb.end());
             }
-            w.wqkv = upload(qkv, true); w.bqkv = upload(bqkv);
+            w.wqkv = upload(qkv, (size_t)d); w.bqkv = upload(bqkv);
             w.wo = wmat(p + ".attn.out_proj.0.weight", d, d);
             w.bo = vec(p + ".attn.out_proj.0.bias", d);
             if (conv_ff) {
                 std::vector<float> a, c;
                 pack_conv(get(p + ".ff.0.weight", {ff, d, 5}), a);
                 pack_conv(get(p + ".ff.2.weight", {d, ff, 5}), c);
-                w.ff0w = upload(a, true); w.ff0b = vec(p + ".ff.0.bias", ff);
-                w.ff1w = upload(c, true); w.ff1b = vec(p + ".ff.2.bias", d);
+                w.ff0w = upload(a, (size_t)5 * d); w.ff0b = vec(p + ".ff.0.bias", ff);
+                w.ff1w = upload(c, (size_t)5 * ff); w.ff1b = vec(p + ".ff.2.bias", d);
             } else {
                 w.ff0w = wmat(p + ".ff.0.weight", ff, d); w.ff0b = vec(p + ".ff.0.bias", ff);
                 w.ff1w = wmat(p + ".ff.3.weight", d, ff); w.ff1b = vec(p + ".ff.3.bias", d);
@@ -275,7 +296,7 @@ struct Loader {
                         s[n] = (float)ss;
                         c[n] = (float)cc;
                     }
-                    Wl = upload(wl, true); sv = upload(s); cv = upload(c);      // + bf16 planes: the pair-fed form runs on the x6 tiles
+                    Wl = upload(wl, (size_t)d); sv = upload(s); cv = upload(c);      // + bf16 planes: the pair-fed form runs on the x6 tiles
                 };
                 fold(qkv, bqkv, get(p + ".norm1.weight", {d}).data, get(p + ".norm1.bias", {d}).data, 3 * d, w.wqkv_l, w.sqkv,
                      w.cqkv);
@@ -336,7 +357,7 @@ void finalize_model(mt2_model& m) {
             const auto& bb = L.get(std::string("G.mrte.mha.") + n + ".bias", {H}).data;
             bkv.insert(bkv.end(), bb.begin(), bb.end());
         }
-        m.x_wkv = L.upload(kv, true);
+        m.x_wkv = L.upload(kv, (size_t)H);
         m.x_bkv = L.upload(bkv);
     }
     m.x_wo = L.wmat("G.mrte.mha.out_proj.0.weight", H, H);
@@ -432,7 +453,7 @@ void finalize_model(mt2_model& m) {
                 }
             UpW u;
             u.cin = ch; u.cout = co; u.stride = s;
-            u.wlo = L.upload(lo, true); u.whi = L.upload(hi, true); u.bias = L.upload(bias);
+            u.wlo = L.upload(lo, (size_t)2 * ch); u.whi = L.upload(hi, (size_t)2 * ch); u.bias = L.upload(bias);
             m.hg_up.push_back(u);
             for (int j = 0; j < c.hg_n_res; ++j) {
                 ResW r;

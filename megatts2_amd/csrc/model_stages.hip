@@ -4,6 +4,7 @@
 // runs" (SURVEY.md N1): per-utterance zero gaps for convolutions, per-utterance attention ranges,
 // positional indices restarting at 0.
 #include "mt2_model.h"
+#include "x3h_planes.h"
 
 #include <algorithm>
 #include <cmath>
@@ -78,6 +79,15 @@ static void attach_planes(const mt2_model& m, GemmP& p) {
     if (p.W < it->base + it->n) {
         p.W3 = it->p3 + (p.W - it->base);
         p.w3_plane = (long long)it->n;
+        // the fp16 planes carry one scale per weight row: usable when this launch walks the buffer with the rows it was split by
+        // (K slices of a row - split-K - share the row's scale)
+        const int ldw = p.ldw ? p.ldw : (p.taps > 0 ? p.taps : 1) * p.Cin;
+        if (it->ph && ldw == (int)it->row_len && p.strideW % (long long)it->row_len == 0) {
+            p.Wh = it->ph + (p.W - it->base);
+            p.wh_plane = (long long)it->n;
+            p.wh_inv = it->inv + (size_t)(p.W - it->base) / it->row_len;
+            p.wh_inv_stride = p.strideW / (long long)it->row_len;
+        }
     }
 }
 // the tile-major copy of the matrix a weight pointer lies in, if it has one (mt2_model::tm, sorted by base) and the

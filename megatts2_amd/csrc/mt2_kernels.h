@@ -53,6 +53,12 @@ struct GemmP {
     const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like
     long long w3_plane = 0;     // W (same ldw / strideW, in bf16 elements), planes w3_plane elements apart (0: N * ldw) -
                                 // lets launch_gemm run on the bf16 matrix pipe in the f32-equivalent 6-product form
+    const void* Wh = nullptr;   // optional: the same weights as two fp16 planes (hi, lo * 2^11) of the ROW-SCALED matrix (x3h_planes.h), addressed
+    long long wh_plane = 0;     // like W (same ldw / strideW, in fp16 elements), planes wh_plane elements apart; wh_inv[n] = the inverse (an
+    const float* wh_inv = nullptr;   // exact power of two) of the scale of weight row n, n = 0 being W's first row; group g: + g * wh_inv_stride.
+    long long wh_inv_stride = 0;     // Lets launch_gemm run on the fp16 matrix pipe in the f32-equivalent 3-product form (gemm_x3h.hip)
+    int* x3h_flag = nullptr;    // device word: |= 1 when an x3h launch converted an activation with |a| >= 65504 (fp16 range; set by launch_gemm
+                                // from EngineOpts::x3h_flag - the caller repeats the call without x3h)
     const float* Wtm = nullptr; // optional: the WHOLE matrix W points into, as tile-major blocks of 16 columns x 64 k (gemm_skinny.hip;
     int tm_n0 = 0, tm_k0 = 0;   // model_load.hip TmRange); (tm_n0, tm_k0) = block coordinates of W's first element (row / 16, column /
     int tm_kb = 0;              // 64), tm_kb = column blocks per block row (ldw / 64).  Lets launch_gemm stream the weights of a
@@ -98,6 +104,10 @@ struct EngineOpts {
     bool x6_conv = true;         // ... on the bf16 matrix pipe, f32-equivalent 3-way split (6 products), where W3 planes exist
     bool x6_gemm = true;         // the big-tile implicit GEMMs likewise (gemm_x6_dma_kernel)
     bool x6_splitk = true;       // K slices (through the next LayerNorm) to give the N = d AR GEMMs enough x6 tiles
+    int x3h = 1;                 // f32-equivalent THREE-product form on the fp16 pipe (gemm_x3h.hip) wherever an x6 tile has one and the
+                                 // weights come with fp16 planes (GemmP::Wh): 0 off (everything stays x6)
+    int* x3h_flag = nullptr;     // device word of the range guard (GemmP::x3h_flag); the model handle owns one
+    int t_x3h_w4 = 400, x3h_w4_mink = 1536;   // x3h: from this many 128x128 tiles and this K on the 64x64-per-wave form (tile 94) instead of 91
     bool x6_loaders = true;      // x6 GEMM tiles with loader waves (gemm_x6_ldr_kernel) instead of self-refilling compute waves
     bool nt_weights = false;     // non-temporal weight loads when a launch has at most nt_row_tiles row tiles (AR steps)
     int nt_row_tiles = 2;
@@ -152,6 +162,11 @@ struct EngineOpts {
                                  // +0.46 % for the ADM alone at 2048, +0.1 % at 1280)
 };
 hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
+// gemm_x3h.hip: the kernels of the fp16-pipe form by tile id and variant (prologue none / relu / leaky relu / - / - / pair statistics);
+// nullptr: no such variant
+enum X3hTile : int { X3H_LDR_128x128 = 0, X3H_LDR_128x128_S4, X3H_LDR_128x128_W4, X3H_LDR_128x128_W4_S4, kX3hTiles };
+typedef void (*X3hKernel)(GemmP);
+X3hKernel x3h_kernel(int tile, int variant);
 // gemm_skinny.hip: weight-streaming linear layer for M <= 64 rows (taps = 1, no rowbase, K a multiple of 32)
 bool gemm_skinny_eligible(const GemmP& p, int max_rows);
 hipError_t launch_gemm_skinny(const GemmP& p, hipStream_t s);

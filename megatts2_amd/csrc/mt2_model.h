@@ -90,7 +90,9 @@ struct ConvW { float* w = nullptr; float* b = nullptr; int cout = 0, cin = 0, k 
 // A GEMM weight buffer that also exists as three bf16 planes (truncation split, exact sum; model_load.hip): the stage
 // drivers look a weight pointer up here and hand the planes to launch_gemm (GemmP::W3), which may then run the launch
 // on the bf16 matrix pipe in the f32-equivalent 6-product form.
-struct PlaneRange { const float* base; size_t n; const uint16_t* p3; };
+// ... and as two fp16 planes of the row-scaled matrix + the inverse row scales (x3h_planes.h; rows of row_len elements): GemmP::Wh /
+// wh_inv, the 3-product form on the fp16 pipe.
+struct PlaneRange { const float* base; size_t n; const uint16_t* p3; const uint16_t* ph = nullptr; const float* inv = nullptr; size_t row_len = 0; };
 // A linear layer's [N, K] weight matrix (N a multiple of 16, K of 64) that also exists as tile-major blocks (gemm_skinny.hip):
 // the matrices of the AR encoders and the PLM head - what a launch of at most 64 rows streams.
 struct TmRange { const float* base; size_t n; int K; const float* tm; };
@@ -190,6 +192,10 @@ struct mt2_model {
     int* id_flag_dev = nullptr;
     int* id_flag_host = nullptr;       // hipHostMalloc
     bool id_open = false;              // checks enqueued, verdict not read yet
+    // range guard of the fp16-pipe GEMMs (gemm_x3h.hip): a device word the kernels OR into when an activation leaves the fp16
+    // range; every API call copies it to the pinned host word before its end event (CallScope), mt2_x3h_guard reads it there
+    int* x3h_flag_dev = nullptr;
+    int* x3h_flag_host = nullptr;      // hipHostMalloc
 
     // mel front-end constants for the last mt2_audio_config seen (windowed DFT basis, mel filterbank)
     mt2_audio_config fe_cfg{};

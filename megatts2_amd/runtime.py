@@ -670,8 +670,57 @@ def op_conv_x6(X, W, bias=None, R=None, valid=None, shift0=0, taps=1, dil=1, Cin
     return out
 
 
+def split_f16x2_rows(W):
+    """f32 matrix [N, K] -> the x3h operand format, written independently of csrc/x3h_planes.h (numpy float16 rounds to nearest
+    even with gradual underflow): (planes int16 [2, N, K] = fp16 bit patterns of hi and lo * 2^11 of the row-scaled matrix,
+    inv f32 [N] = the inverse power-of-two row scales)."""
+    import torch
+    w = W.detach().to(torch.float32).cpu().numpy()
+    mx = np.abs(np.where(np.isfinite(w), w, 0)).max(axis=1)
+    e = np.zeros(w.shape[0], np.int32)
+    nz = mx > 0
+    e[nz] = np.clip(15 - np.frexp(mx[nz])[1], -100, 100)
+    s = np.ldexp(np.float32(1), e).astype(np.float32)
+    v = (w * s[:, None]).astype(np.float32)
+    hi = v.astype(np.float16)
+    lo = ((v - hi.astype(np.float32)) * np.float32(2048)).astype(np.float16)
+    planes = np.stack([hi.view(np.int16), lo.view(np.int16)])
+    return torch.from_numpy(planes.copy()), torch.from_numpy(np.ldexp(np.float32(1), -e).astype(np.float32))
+
+
+def x3h_split_native(W):
+    """The library's own host splitter (mt2_x3h_split) on a CPU f32 matrix: (planes int16 [2, N, K], inv f32 [N])."""
+    import torch
+    lib = load_library()
+    w = W.detach().to(torch.float32).cpu().contiguous()
+    planes = torch.empty((2,) + tuple(w.shape), dtype=torch.int16)
+    inv = torch.empty(w.shape[0], dtype=torch.float32)
+    _check(lib.mt2_x3h_split(C.c_void_p(w.data_ptr()), C.c_longlong(w.shape[0]), C.c_longlong(w.shape[1]),
+                             C.c_void_p(planes.data_ptr()), C.c_void_p(inv.data_ptr())))
+    return planes, inv
+
+
+def op_conv_x3h(X, W, bias=None, R=None, valid=None, shift0=0, taps=1, dil=1, Cin=None, pro_act=ACT_NONE, pro_slope=0.0,
+                epi_act=ACT_NONE, force_cfg=-1, want_flag=False):
+    """mt2_op_gemm_x3h: one GEMM / convolution launch with the weights given as f32, as bf16 planes and as fp16 planes (so that
+    every tile configuration can be forced): X [rows, Cin] f32, W [N, taps*Cin] f32.  want_flag -> (out, range flag)."""
+    import torch
+    lib = load_library()
+    Cin = Cin or X.shape[1]
+    N, M = W.shape[0], X.shape[0]
+    W3 = split_bf16x3(W).to(X.device)
+    ph, inv = split_f16x2_rows(W)
+    ph, inv = ph.to(X.device), inv.to(X.device)
+    out = torch.empty(M, N, device=X.device, dtype=torch.float32)
+    flag = torch.zeros(4, device=X.device, dtype=torch.int32)
+    _check(lib.mt2_op_gemm_x3h(_stream(), _ptr(X), X.shape[1], M, shift0, taps, dil, Cin, _ptr(W), _ptr(W3), _ptr(ph), _ptr(inv),
+                               _ptr(bias), _ptr(R), R.shape[1] if R is not None else 0, _ptr(valid), _ptr(out), N, M, N, pro_act,
+                               C.c_float(pro_slope), epi_act, force_cfg, _ptr(flag)))
+    return (out, int(flag[0].item())) if want_flag else out
+
+
 def op_gemm_x6_ln(X, W, bias=None, R=None, M=None, a_mul=1, shift0=0, epi_act=ACT_NONE, force_cfg=-1, want_stats=False,
-                  ln=None, eps=1e-5):
+                  ln=None, eps=1e-5, x3h=False):
     """mt2_op_gemm_x6_ln: one linear launch on an x6 tile.  want_stats -> also returns (pairs [M, nt, 2], pair width) written by
     the epilogue (nt = 0 rows when the tile has none).  ln = (gamma, beta, pairs [rows, nt, 2], pair width): LayerNorm(X) @ W^T + b
     in the pair-fed algebraic form - gamma / beta are folded into the operands here (float64 sums, as the model loader does)."""
@@ -695,9 +744,17 @@ def op_gemm_x6_ln(X, W, bias=None, R=None, M=None, a_mul=1, shift0=0, epi_act=AC
         ln_nt = pairs.shape[1]
     W = W.contiguous()
     W3 = split_bf16x3(W).to(dev)
-    _check(lib.mt2_op_gemm_x6_ln(_stream(), _ptr(X), K, X.shape[0], a_mul, shift0, _ptr(W), _ptr(W3), _ptr(bias), _ptr(R),
-                                 R.shape[1] if R is not None else 0, _ptr(out), N, M, N, K, epi_act, force_cfg, _ptr(stat),
-                                 C.byref(nt), C.byref(pw), _ptr(ln_stat), ln_nt, int(ln_w), _ptr(ln_s), C.c_float(eps)))
+    if x3h:      # the same launch with the fp16 planes as well (mt2_op_gemm_x3h_ln): the fp16-pipe tiles 91 / 92
+        ph, inv = split_f16x2_rows(W)
+        ph, inv = ph.to(dev), inv.to(dev)
+        _check(lib.mt2_op_gemm_x3h_ln(_stream(), _ptr(X), K, X.shape[0], a_mul, shift0, _ptr(W), _ptr(W3), _ptr(ph), _ptr(inv),
+                                      _ptr(bias), _ptr(R), R.shape[1] if R is not None else 0, _ptr(out), N, M, N, K, epi_act,
+                                      force_cfg, _ptr(stat), C.byref(nt), C.byref(pw), _ptr(ln_stat), ln_nt, int(ln_w), _ptr(ln_s),
+                                      C.c_float(eps)))
+    else:
+        _check(lib.mt2_op_gemm_x6_ln(_stream(), _ptr(X), K, X.shape[0], a_mul, shift0, _ptr(W), _ptr(W3), _ptr(bias), _ptr(R),
+                                     R.shape[1] if R is not None else 0, _ptr(out), N, M, N, K, epi_act, force_cfg, _ptr(stat),
+                                     C.byref(nt), C.byref(pw), _ptr(ln_stat), ln_nt, int(ln_w), _ptr(ln_s), C.c_float(eps)))
     if want_stats:
         return out, stat.view(-1)[:M * nt.value * 2].reshape(M, nt.value, 2).clone(), pw.value      # dense [M][nt][2]
     return out

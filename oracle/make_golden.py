@@ -357,9 +357,47 @@ def make_prompted(kind: str, seed: int, n_ph: int, n_pp: int, n_pr: int, n_fr: i
     print(kind, "prompted", {k: v.shape for k, v in out.items()}, "codes", out["p_codes"][:10], "prompt codes", out["prompt_codes"][:8])
 
 
+def make_vq_near_ties() -> None:
+    """tests/golden/{tiny,prod}_vq_near_ties.npz: the indices of the LIVE `EuclideanCodebook.quantize` (core_vq.py:175-183) on the
+    rows of megatts2_oracle.vq_near_tie_rows - tiny: the 4 096 rows of test_tiny_vq_quantize_near_ties; prod: 10^5 random rows of
+    which 512 are exact hits and 512 engineered near-ties.  The rows are regenerated from the seed by the
+    tests (their sha256 is stored); the file holds the reference's indices, its top-2 score gap, and the float64 runner-up."""
+    import hashlib
+    import megatts2_oracle as O
+    ref_shim.install()
+    from modules.quantization.core_vq import EuclideanCodebook
+    for kind, n in (("tiny", 4096), ("prod", 100000)):
+        emb = np.load(os.path.join(GOLDEN, f"codebook_{kind}.npy"))
+        cb = EuclideanCodebook(dim=emb.shape[1], codebook_size=emb.shape[0])
+        cb.embed.copy_(torch.from_numpy(emb))
+        cb.inited.fill_(1)
+        cb.eval()
+        x = O.vq_near_tie_rows(emb, n, 3)
+        with torch.no_grad():
+            idx = cb.quantize(torch.from_numpy(x)).numpy().astype(np.int64)
+            torch.set_num_threads(1)
+            idx1 = cb.quantize(torch.from_numpy(x)).numpy().astype(np.int64)
+            torch.set_num_threads(max(1, os.cpu_count() or 1))
+        assert np.array_equal(idx, idx1), "the live reference's indices depend on the thread count"
+        d = O.vq_distances(emb, x)                                   # float64 scores: the decision margins
+        part = np.partition(d, -2, axis=1)
+        margin = (part[:, -1] - part[:, -2]).astype(np.float64)
+        best64 = d.argmax(1).astype(np.int64)
+        out = {"ref_idx": idx.astype(np.int16 if emb.shape[0] < 32768 else np.int32), "margin64": margin.astype(np.float32),
+               "best64": best64.astype(np.int16 if emb.shape[0] < 32768 else np.int32), "n_rows": np.int64(n), "seed": np.int64(3),
+               "x_sha256": np.frombuffer(hashlib.sha256(x.tobytes()).digest(), np.uint8)}
+        np.savez_compressed(os.path.join(GOLDEN, f"{kind}_vq_near_ties.npz"), **out)
+        ora = O.vq_quantize(emb, x)
+        print(kind, "rows", n, "live reference vs float64 argmax:", int((idx != best64).sum()), "| numpy oracle vs live reference:",
+              int((ora != idx).sum()), "rows", np.nonzero(ora != idx)[0][:10])
+
+
 def main() -> None:
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
+    if "--extra-vq" in sys.argv:
+        make_vq_near_ties()
+        return
     if "--extra-prompted" in sys.argv:
         make_prompted("tiny", 7007, 9, 7, 56, 45)
         make_prompted("prod", 7008, 42, 30, 256, 200)

@@ -360,6 +360,31 @@ def vq_quantize(embed: np.ndarray, x: np.ndarray) -> np.ndarray:
     return np.argmax(dist, axis=-1).astype(np.int64)
 
 
+def vq_near_tie_rows(embed: np.ndarray, n_random: int, seed: int = 3) -> np.ndarray:
+    """The rows of the near-tie fixtures (tests/golden/*_vq_near_ties.npz): n_random random rows at the
+    codebook's scale - the first 512 replaced by EXACT codebook rows, the next 512 by midpoints of two codebook rows + 1e-4 noise
+    (engineered near-ties) - for n_random = 4096 and seed 3 exactly the rows test_tiny_vq_quantize_near_ties has always drawn."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n_random, embed.shape[1])).astype(F32) * embed.std()
+    x[:512] = embed[rng.integers(0, embed.shape[0], 512)]
+    mid = 0.5 * (embed[rng.integers(0, embed.shape[0], 512)] + embed[rng.integers(0, embed.shape[0], 512)])
+    x[512:1024] = mid + 1e-4 * rng.standard_normal(mid.shape).astype(F32)
+    return x
+
+
+def vq_flips_within_roundoff(embed: np.ndarray, x: np.ndarray, a: np.ndarray, b: np.ndarray, ulps: float = 16.0) -> np.ndarray:
+    """For rows x where two evaluations of `quantize` picked different indices a != b: True where the float64 scores of the two
+    picks differ by less than `ulps` f32 roundings of the expanded distance's own terms (|x|^2 + max |e|^2 + 2 max |x.e|) - i.e.
+    where the decision lies inside the round-off of core_vq.py:177-181 itself and depends on the BLAS that evaluates it."""
+    xb = x.astype(np.float64)
+    d = vq_distances(embed, x)
+    r = np.arange(x.shape[0])
+    gap = np.abs(d[r, a] - d[r, b])
+    e64 = embed.astype(np.float64)
+    mag = (xb * xb).sum(1) + (e64 ** 2).sum(1).max() + 2 * np.abs(xb @ e64.T).max(1)
+    return gap < ulps * np.finfo(F32).eps * mag
+
+
 def vq_distances(embed: np.ndarray, x: np.ndarray) -> np.ndarray:
     """The score matrix of `vq_quantize` in float64 (for decision-margin reporting only)."""
     x = x.astype(np.float64)
@@ -623,7 +648,7 @@ def enable_torch_kernels(threads: Optional[int] = None) -> None:
         torch.set_num_threads(int(threads))
     g = globals()
     if not _NUMPY_PRIMS:
-        _NUMPY_PRIMS.update({k: g[k] for k in ("linear", "conv1d", "layer_norm", "mha", "hifigan")})
+        _NUMPY_PRIMS.update({k: g[k] for k in ("linear", "conv1d", "layer_norm", "mha", "hifigan", "vq_quantize")})
 
     def t(a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=F32))

@@ -405,3 +405,27 @@ def test_asm_audit_flags_a_spilled_lds_read_and_the_build_is_clean(tmp_path):
     rep = open(os.path.join(build.LIBDIR, "gemm_f32.asm_audit.txt")).read()
     assert "0 kernel(s) with scratch STORES inside LDS-reading loops" in rep
     assert rep.strip().endswith("0 kernel(s) with scratch RELOADS inside LDS-reading loops")
+
+
+def test_x3h_host_split_matches_numpy_float16():
+    """csrc/x3h_planes.h (the loader's fp16 planes) against an independent numpy float16 implementation: bit-identical planes and
+    scales on magnitudes from 1e-30 to 1e+30, zero rows, subnormal results, ties."""
+    import torch
+    from megatts2_amd import runtime as rt
+    rng = np.random.default_rng(5)
+    W = (rng.standard_normal((300, 160)) * np.exp(rng.uniform(-20, 20, (300, 160)))).astype(np.float32)
+    W[3] = 0.0
+    W[4] = (rng.standard_normal(160) * 1e-30).astype(np.float32)
+    W[5] = (rng.standard_normal(160) * 1e30).astype(np.float32)
+    W[6, :] = np.float32(1.0) + np.arange(160, dtype=np.float32) * np.float32(2.0 ** -11)          # exact ties of the hi plane
+    a, ai = rt.split_f16x2_rows(torch.from_numpy(W))
+    b, bi = rt.x3h_split_native(torch.from_numpy(W))
+    assert torch.equal(a, b) and torch.equal(ai, bi)
+    hi = a[0].numpy().view(np.float16).astype(np.float64)
+    lo = a[1].numpy().view(np.float16).astype(np.float64)
+    rec = (hi + lo / 2048.0) * ai.numpy().astype(np.float64)[:, None]
+    w = W.astype(np.float64)
+    rowmax = np.maximum(np.abs(w).max(1, keepdims=True), 1e-300)
+    big = np.abs(w) > rowmax * 2.0 ** -26      # hi AND the scaled residual are normal fp16 numbers
+    assert (np.abs(rec - w)[big] <= 2.0 ** -23 * np.abs(w)[big]).all()
+    assert (np.abs(rec - w) <= 2.0 ** -23 * np.abs(w) + 2.0 ** -50 * rowmax).all()

@@ -283,6 +283,125 @@ def test_gemm_x6_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
     assert not x6[valid == 0].any()
 
 
+X3H_SHAPES = [(300, 512, 1, 256, 1), (77, 96, 1, 104, 1), (1000, 384, 5, 384, 1), (700, 64, 3, 80, 1), (515, 256, 7, 256, 3),
+              (2240, 4096, 1, 1024, 1), (864, 1024, 1, 4096, 1)]
+
+
+@pytest.mark.parametrize("cfg", [91, 92, 93, 94])
+@pytest.mark.parametrize("M,N,taps,cin,dil", X3H_SHAPES)
+def test_gemm_x3h_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
+    """Round 6: the implicit-GEMM engine on the fp16 matrix pipe in the THREE-product form (gemm_x3h_ldr_kernel: a = a_hi + 2^-11
+    a_lo in fp16, weights split at load after a power-of-two row scale, cross terms in their own accumulator) - held to the bar of
+    test_gemm_x6_is_f32_equivalent on the same wide-dynamic-range data: as accurate against float64 as the f32-MFMA kernel
+    (err <= 2 err_f32 + 1e-7), K tails, tap boundaries inside a chunk, M / N tails, every epilogue operand, masked rows zero; the
+    range guard stays quiet."""
+    rng = np.random.default_rng(M + N + taps * cin)
+    K = taps * cin
+    G = ((taps - 1) // 2) * dil
+    X = (rng.standard_normal((M, cin)) * np.exp(rng.uniform(-3, 3, (M, cin)))).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / math.sqrt(K) * np.exp(rng.uniform(-2, 2, (N, K)))).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    valid = (rng.random(M) > 0.1).astype(np.int32)
+    kw = dict(valid=dev(valid), shift0=-G, taps=taps, dil=dil, Cin=cin, pro_act=rt.ACT_RELU, epi_act=rt.ACT_NONE)
+    x3, flag = rt.op_conv_x3h(dev(X), dev(W), dev(b), dev(R), force_cfg=cfg, want_flag=True, **kw)
+    x3 = x3.cpu().numpy()
+    f32 = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=16, **kw).cpu().numpy()
+    a = np.maximum(X, 0).astype(np.float64)
+    ap = np.zeros((M + 2 * G, cin))
+    ap[G:G + M] = a
+    ref = np.zeros((M, N))
+    for t in range(taps):
+        ref += ap[t * dil:t * dil + M] @ W[:, t * cin:(t + 1) * cin].T.astype(np.float64)
+    ref = (ref + b + R) * valid[:, None]
+    e3, e32 = rel(x3, ref), rel(f32, ref)
+    assert e3 < 1e-6 and e3 <= 2.0 * e32 + 1e-7, (e3, e32)
+    assert not x3[valid == 0].any()
+    assert flag == 0
+    # element-wise, without the epilogue operands in the denominator: every output within a few f32 roundings of the exact dot
+    # product measured against sum |a||w| (the scale the f32 chain's own error bound is written in)
+    y3 = rt.op_conv_x3h(dev(X), dev(W), force_cfg=cfg, **{**kw, "valid": None}).cpu().numpy()
+    y32 = rt.op_gemm(dev(X), dev(W), force_cfg=16, **{**kw, "valid": None}).cpu().numpy()
+    dot = np.zeros((M, N))
+    mag = np.zeros((M, N))
+    for t in range(taps):
+        wt = W[:, t * cin:(t + 1) * cin].T.astype(np.float64)
+        dot += ap[t * dil:t * dil + M] @ wt
+        mag += np.abs(ap[t * dil:t * dil + M]) @ np.abs(wt)
+    mag = np.maximum(mag, 1e-30)
+    w3, w32 = (np.abs(y3 - dot) / mag).max(), (np.abs(y32 - dot) / mag).max()
+    assert w3 <= 2.0 * w32 + 2.0 ** -23, (w3, w32)
+
+
+@pytest.mark.parametrize("cfg", [91, 93])
+def test_gemm_x3h_range_guard_and_corner_cases(rt, cfg):
+    """The fp16 form's range behaviour, documented in gemm_x3h.hip: (1) activations up to 6e4 and weights of any magnitude (1e-30
+    ... 1e+30 rows: the row scale) are exact to f32 class and leave the guard quiet; (2) an activation at or beyond 65504 raises
+    the guard word - the caller repeats on x6, which has f32's exponent range (checked here: x6 on the same data is accurate);
+    (3) tiny activations keep ABSOLUTE accuracy 2^-36 per element - normwise f32 class in a row that also holds O(1) values, and
+    exact zeros stay exact; f32-subnormal inputs count as zeros, as they effectively do in the f32 chain at these magnitudes;
+    (4) inf / NaN inputs give non-finite outputs in the rows they touch (as the f32 chain does), never finite garbage, and inf
+    raises the guard."""
+    rng = np.random.default_rng(cfg)
+    M, N, K = 256, 256, 512
+    W = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    W[:64] *= np.float32(1e-30)                          # rows far below / above fp16's range: the power-of-two row scale
+    W[64:128] *= np.float32(1e30)
+    W[128] = 0.0
+    X = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-3, 3, (M, K)))).astype(np.float32)
+    X[0, :] = rng.uniform(3e4, 6e4, K).astype(np.float32)        # large but inside the range
+    X[1, :] = 0.0
+    ref = X.astype(np.float64) @ W.T.astype(np.float64)
+    y, flag = rt.op_conv_x3h(dev(X), dev(W), force_cfg=cfg, want_flag=True)
+    y = y.cpu().numpy()
+    y32 = rt.op_gemm(dev(X), dev(W), force_cfg=16).cpu().numpy()
+    assert flag == 0
+    for rows in (slice(0, 64), slice(64, 128), slice(128, 256)):          # each magnitude class on its own scale
+        e3, e32 = rel(y[:, rows], ref[:, rows]), rel(y32[:, rows], ref[:, rows])
+        assert e3 <= 2.0 * e32 + 1e-7, (rows, e3, e32)
+    assert not y[1].any() and not y[:, 128].any()
+    # (2) the guard
+    for big in (65504.0, 7e4, 1e30):
+        Xb = X.copy()
+        Xb[17, 33] = big
+        _, flag = rt.op_conv_x3h(dev(Xb), dev(W[128:]), force_cfg=cfg, want_flag=True)
+        assert flag == 1, big
+        y6 = rt.op_conv_x6(dev(Xb), dev(W[128:]), force_cfg=55).cpu().numpy()
+        refb = Xb.astype(np.float64) @ W[128:].T.astype(np.float64)
+        assert rel(y6, refb) < 1e-6
+    Xq = X.copy()
+    Xq[17, 33] = 65000.0
+    yq, flag = rt.op_conv_x3h(dev(Xq), dev(W[128:]), force_cfg=cfg, want_flag=True)
+    assert flag == 0 and rel(yq.cpu().numpy(), Xq.astype(np.float64) @ W[128:].T.astype(np.float64)) < 1e-6
+    # (3) the small end
+    Xs = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-30, -12, (M, K)))).astype(np.float32)      # everything below 2^-14
+    Xs[:, ::16] = rng.standard_normal((M, K // 16)).astype(np.float32)                                # ... except some O(1) values
+    Wn = W[129:]
+    refs = Xs.astype(np.float64) @ Wn.T.astype(np.float64)
+    ys = rt.op_conv_x3h(dev(Xs), dev(Wn), force_cfg=cfg).cpu().numpy()
+    y32s = rt.op_gemm(dev(Xs), dev(Wn), force_cfg=16).cpu().numpy()
+    assert rel(ys, refs) <= 2.0 * rel(y32s, refs) + 1e-7
+    Xt = (rng.standard_normal((M, K)) * 1e-6).astype(np.float32)                                       # a whole operand of tiny values:
+    yt = rt.op_conv_x3h(dev(Xt), dev(Wn), force_cfg=cfg).cpu().numpy()                                 # absolute accuracy 2^-36 per element
+    reft = Xt.astype(np.float64) @ Wn.T.astype(np.float64)
+    bound = 2.0 ** -36 * np.abs(Wn.astype(np.float64)).sum(1)[None, :] + 1e-6 * np.abs(reft)
+    assert (np.abs(yt - reft) <= bound).all()
+    Xd = np.full((M, K), 1e-41, np.float32)                                                            # f32 subnormals
+    yd = rt.op_conv_x3h(dev(Xd), dev(Wn), force_cfg=cfg).cpu().numpy()
+    assert np.isfinite(yd).all() and np.abs(yd).max() < 1e-35
+    # (4) non-finite inputs
+    Xn = X.copy()
+    Xn[5, 100] = np.nan
+    Xn[9, 200] = np.inf
+    yn, flag = rt.op_conv_x3h(dev(Xn), dev(Wn), force_cfg=cfg, want_flag=True)
+    yn = yn.cpu().numpy()
+    assert flag == 1
+    assert not np.isfinite(yn[5]).any() and not np.isfinite(yn[9]).any()
+    ok = np.ones(M, bool)
+    ok[[5, 9]] = False
+    assert rel(yn[ok], (X.astype(np.float64) @ Wn.T.astype(np.float64))[ok]) < 1e-6
+
+
 @pytest.mark.parametrize("cfg", [79, 80, 82, 84, 85, 86])
 @pytest.mark.parametrize("M,N,K", [(300, 512, 256), (77, 96, 512), (448, 3072, 1024), (33, 200, 768), (224, 1024, 4096),
                                    (16, 1024, 1024)])
@@ -580,7 +699,7 @@ def test_gemm_with_algebraic_layernorm(rt, cfg, M, N, K):
         assert rel(out2, ref[2::3][:Ms]) < 2e-5
 
 
-@pytest.mark.parametrize("cfg", [55, 84, 85, 86, -1])
+@pytest.mark.parametrize("cfg", [55, 84, 85, 86, -1, 91, 92])
 @pytest.mark.parametrize("M,d,N2", [(200, 768, 1024), (1120, 768, 2304), (333, 1024, 4096), (97, 1024, 1024)])
 def test_gemm_layernorm_statistics_handed_from_gemm_to_gemm(rt, cfg, M, d, N2):
     """The AR layers' stand-alone LayerNorm launches (round 5; modules/transformer.py:88-102: `x = x + out_proj(att)` then
@@ -589,13 +708,16 @@ def test_gemm_layernorm_statistics_handed_from_gemm_to_gemm(rt, cfg, M, d, N2):
     Producer: x_new and every pair against float64; consumer: against float64 LayerNorm + linear, with the error of the
     two-launch form (LayerNorm kernel + the same tile) as the yardstick; the strided last-row gather; rows with a common offset."""
     rng = np.random.default_rng(cfg + 7 * M + d)
+    import functools
+    x3h = cfg >= 91 or cfg == -1                         # 91 / 92: the fp16-pipe forms of tile 55; -1: what the model runs (planes of both kinds)
+    rt_op = functools.partial(rt.op_gemm_x6_ln, x3h=x3h)
     att = rng.standard_normal((M, d)).astype(np.float32)
     x = (rng.standard_normal((M, d)) * 2.0 + 0.5).astype(np.float32)
     x[::5] += 6.0                                        # |mean| / std ~ 3 on some rows (production: <= 1)
     Wo = (rng.standard_normal((d, d)) / math.sqrt(d)).astype(np.float32)
     bo = rng.standard_normal(d).astype(np.float32)
     try:
-        xn, pairs, pw = rt.op_gemm_x6_ln(dev(att), dev(Wo), dev(bo), R=dev(x), force_cfg=cfg, want_stats=True)
+        xn, pairs, pw = rt_op(dev(att), dev(Wo), dev(bo), R=dev(x), force_cfg=cfg, want_stats=True)
     except rt.NativeError as e:                          # K-split tile whose K granularity does not divide d
         pytest.skip(str(e)[:80])
     xn = xn.cpu().numpy()
@@ -619,9 +741,9 @@ def test_gemm_layernorm_statistics_handed_from_gemm_to_gemm(rt, cfg, M, d, N2):
     ln = (x64 - x64.mean(1, keepdims=True)) / np.sqrt(x64.var(1, keepdims=True) + 1e-5) * g + b
     ref = np.maximum(ln @ W.T.astype(np.float64) + bias, 0)
     dxn = dev(xn)
-    out = rt.op_gemm_x6_ln(dxn, dev(W), dev(bias), epi_act=rt.ACT_RELU, force_cfg=cfg, ln=(dev(g), dev(b), pairs, pw)).cpu().numpy()
+    out = rt_op(dxn, dev(W), dev(bias), epi_act=rt.ACT_RELU, force_cfg=cfg, ln=(dev(g), dev(b), pairs, pw)).cpu().numpy()
     h = rt.op_layernorm(dxn, dev(g), dev(b))             # the two-launch form on the same tile: the yardstick
-    two = rt.op_gemm_x6_ln(h, dev(W), dev(bias), epi_act=rt.ACT_RELU, force_cfg=cfg).cpu().numpy()
+    two = rt_op(h, dev(W), dev(bias), epi_act=rt.ACT_RELU, force_cfg=cfg).cpu().numpy()
     e1, e2 = rel(out, ref), rel(two, ref)
     assert e1 < 4e-6 and e1 < 4 * e2 + 2e-7, (e1, e2)
     plain = np.ones(M, bool)
@@ -629,7 +751,7 @@ def test_gemm_layernorm_statistics_handed_from_gemm_to_gemm(rt, cfg, M, d, N2):
     assert rel(out[plain], ref[plain]) < 2e-6
     # K | V of all rows and Q of the last row of each sequence read the same pairs: strided gather m -> 3 m + 2
     Ms = (M - 3) // 3 + 1
-    out2 = rt.op_gemm_x6_ln(dxn, dev(W[:d]), dev(bias[:d]), M=Ms, a_mul=3, shift0=2, force_cfg=cfg,
+    out2 = rt_op(dxn, dev(W[:d]), dev(bias[:d]), M=Ms, a_mul=3, shift0=2, force_cfg=cfg,
                             ln=(dev(g), dev(b), pairs, pw)).cpu().numpy()
     ref2 = (ln @ W[:d].T.astype(np.float64) + bias[:d])[2::3][:Ms]
     assert rel(out2, ref2) < 4e-6

@@ -161,6 +161,12 @@ sweep_x6)
   echo "sweep_x6 rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x6.txt
   timeout 600 python tools/gemm_sweep.py x6win > gpurun_out/gemm_sweep_x6win.txt 2>&1
   echo "sweep_x6win rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x6win.txt ;;
+sweep_x3h)
+  timeout 900 python tools/gemm_sweep.py x3h > gpurun_out/gemm_sweep_x3h.txt 2>&1
+  echo "sweep_x3h rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x3h.txt ;;
+ubench_f16)
+  timeout 120 variants/ubench/mfma_f16_denorm > gpurun_out/ubench_mfma_f16.txt 2>&1
+  echo "ubench_f16 rc=$?"; cat gpurun_out/ubench_mfma_f16.txt ;;
 sweep_ar)
   timeout 600 python tools/gemm_sweep.py ar > gpurun_out/gemm_sweep_ar.txt 2>&1
   echo "sweep_ar rc=$?"; cat gpurun_out/gemm_sweep_ar.txt ;;

@@ -251,9 +251,12 @@ def sub_c3_inflight(make_model, model, inputs, frames, n, steps, warmup):
             i = cnt[0]
             cnt[0] += 1
             with torch.cuda.stream(lanes[i % n]):
+                # asynchronous calls: the fp16 range guard of each handle is read after the timed region instead of per call
                 return models[i % n].synthesize_batch(phone, pl, mel_in, ml, forced_dur=dur, run_plm=True, vocoder=True,
-                                                      tm_cap=tm, prompt_vqpe=True)
+                                                      tm_cap=tm, prompt_vqpe=True, check_range=False)
         ms = _timed(step, steps, warmup)
+        if any(m_.range_guard() for m_ in models):
+            raise RuntimeError("fp16 range guard tripped on synthetic inputs: the in-flight measurement is invalid")
     finally:
         for m_ in models[1:]:
             m_.close()

@@ -2285,6 +2285,17 @@ static void x3h_variant_exists(GemmP) {}
       { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr,                               \
         (HAS_LNX_) ? x3h_variant_exists : nullptr }, 0, true, 0, (HAS_LNX_) ? (BN_) / (WN_) : 0, ID_ }
 
+#define MT2_X3HK(ID_, BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                           \
+    { BM_, BN_, (WM_* WN_ * KS_ + NL_) * 64, (size_t)KS_ * NST_ * ((size_t)BM_ * BK * 4 + (size_t)(2 * BN_ / 16) * 1024), \
+      "x3hks" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "+" #NL_ "_s" #NST_,                                        \
+      { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr, x3h_variant_exists }, 0, true, KS_, 32, ID_ }
+
+#define MT2_X3HW(ID_, QS_, BM_, BN_, WM_, WN_, NST_, NL_)                                                           \
+    { BM_, BN_, (WM_* WN_ + NL_) * 64,                                                                               \
+      (size_t)NST_ * (((2 * BN_ / 16 + ((NL_) > 0 ? (NL_) : WM_ * WN_) - 1) / ((NL_) > 0 ? (NL_) : WM_ * WN_)) * ((NL_) > 0 ? (NL_) : WM_ * WN_) * 1024), \
+      "x3hwin" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
+      { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr, nullptr }, QS_, true, 0, 0, ID_ }
+
 static const TileCfg kCfgs[] = {
     // v1: register-staged double buffer (kept for A/B runs and as the reference implementation)
     MT2_CFG(128, 128, 2, 2),   // 0
@@ -2403,6 +2414,14 @@ static const TileCfg kCfgs[] = {
     MT2_X3HL(X3H_LDR_128x128_S4, 128, 128, 4, 2, 4, 4, true),     // 92: ... with a 4-deep ring (128 KiB)
     MT2_X3HL(X3H_LDR_128x128_W4, 128, 128, 2, 2, 4, 3, false),    // 93: one compute wave per SIMD (64x64 per wave) + 4 loaders
     MT2_X3HL(X3H_LDR_128x128_W4_S4, 128, 128, 2, 2, 4, 4, false), // 94: ... with a 4-deep ring
+    // ... and the K-split tiles of the AR steps (gemm_x3h_ks_kernel; + PRO_LNX)
+    MT2_X3HK(X3H_KS_32x64_K4, 32, 64, 1, 2, 4, 8, 2),             // 95: the 84 tile, 96 KiB
+    MT2_X3HK(X3H_KS_64x64_K2, 64, 64, 2, 2, 2, 8, 3),             // 96: the 85 tile, 96 KiB
+    MT2_X3HK(X3H_KS_32x32_K8, 32, 32, 1, 1, 8, 8, 2),             // 97: the 86 tile, 128 KiB
+    // ... and the window convolutions of the vocoder's resblocks (conv_win_x3h_kernel)
+    MT2_X3HW(X3H_WIN_256x32, 1, 256, 32, 8, 1, 3, 0),             // 98: the 34 tile
+    MT2_X3HW(X3H_WIN_256x64, 2, 256, 64, 8, 1, 3, 4),             // 99: the 58 tile
+    MT2_X3HW(X3H_WIN_128x128, 4, 128, 128, 4, 2, 2, 4),           // 100: the 59 tile
 };
 constexpr int kSkinny32 = 87, kSkinny64 = 88, kSkinnyTm32 = 89, kSkinnyTm64 = 90;
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -2517,6 +2536,7 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
             bi += 4;                                                    // the bf16-pipe form of the same tile
             if (o.x6_loaders && bi == 35) bi = 58;                      // ... with loader waves (+5..14 %, sweep v2 of x6win)
             if (o.x6_loaders && bi == 36) bi = 59;                      // (+2..6 %)
+            if (o.x3h >= 3 && p.Wh && p.wh_inv) bi = bi == 34 ? 98 : (bi == 58 ? 99 : (bi == 59 ? 100 : bi));      // the fp16-pipe forms
         }
         *idx_out = bi;
         return &kCfgs[bi];
@@ -2573,6 +2593,7 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     // 146 TF/s at 864x4096x1024, 245 vs 188 at 4096^3 - and with long K chains and enough tiles to keep every CU busy for more than
     // one round the one-compute-wave-per-SIMD form, 64x64 per wave, is a few per cent ahead: 238 vs 221 on the decoder stack)
     if (o.x3h && p.Wh && p.wh_inv && (bi == 55 || bi == 51)) bi = (p.K >= o.x3h_w4_mink && t128 >= o.t_x3h_w4) ? 94 : 91;
+    if (o.x3h >= 2 && p.Wh && p.wh_inv && bi >= 84 && bi <= 86) bi += 11;                  // K-split tiles: 84 / 85 / 86 -> 95 / 96 / 97
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;
     *idx_out = bi;
     return &kCfgs[bi];

@@ -43,6 +43,10 @@ constexpr float kX3hLoScale = 2048.0f, kX3hLoInv = 1.0f / 2048.0f, kX3hMaxIn = 6
 // the range guard; the bf16 split of x6 takes 11 per pair.
 template <int PRO>
 __device__ __forceinline__ void split2_f16(const f32x4& lo, const f32x4& hi, float slope, u32x4& ph, u32x4& pl, float& amax) {
+#if defined(MT2_X3H_ABLATE) && MT2_X3H_ABLATE == 3     // ablation: no split arithmetic (wrong numbers, same MFMA / LDS / DMA work)
+    ph = __builtin_bit_cast(u32x4, lo); pl = __builtin_bit_cast(u32x4, hi);
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float x = apply_act<PRO>(i < 2 ? lo[2 * i] : hi[2 * i - 4], slope);
@@ -175,7 +179,11 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
             if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();       // this wave's pieces of chunk c have landed
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                            // chunk c complete; chunk c-1's stage is free
+#if defined(MT2_X3H_ABLATE) && MT2_X3H_ABLATE == 2                           // ablation: no operand ingest inside the K loop
+            if (c + NST - 1 < nk && c < 1) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+#else
             if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+#endif
             st = st + 1 == NST ? 0 : st + 1;
         }
         return;
@@ -261,6 +269,12 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     // column tiles innermost so that consecutive MFMAs never wait on each other's accumulator
     auto products = [&](int b, int i, const u32x4* pp) {
         const f16x8 Ah = __builtin_bit_cast(f16x8, pp[0]), Al = __builtin_bit_cast(f16x8, pp[1]);
+#if defined(MT2_X3H_ABLATE) && MT2_X3H_ABLATE == 4     // ablation: fetch + split, no matrix instructions (operands kept live)
+        asm volatile("" :: "v"(Ah), "v"(Al));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(rb[b][0][j]), "v"(rb[b][1][j]));
+        if (Kt >= 0) return;
+#endif
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][1][j]), acl[i][j], 0, 0, 0);
@@ -299,6 +313,13 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     }
     for (int c = 0; c < nk; ++c) {
         const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
+#if defined(MT2_X3H_ABLATE) && MT2_X3H_ABLATE == 1                                   // ablation: ingest only - the compute waves just keep the
+        if (c + 1 < nk) {                                                    // barrier cadence (the last chunk runs the real body so
+            __builtin_amdgcn_s_barrier();                                    // that the accumulators stay live)
+            st = st + 1 == NST ? 0 : st + 1;
+            continue;
+        }
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         fetch(0, sa, sb);
@@ -374,6 +395,455 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     }
 }
 
+// ===================================================================================================
+// x3h arithmetic on the K-SPLIT tiles of the autoregressive steps (gemm_x6_ks_kernel's decomposition, gemm_f32.hip): KS groups of
+// WGM x WGN waves, one 32x32 tile per wave, group kg walking chunks kg, kg + KS, ... through its OWN ring, NL loader waves own
+// the whole refill, one barrier per round; the partial tiles (acc_hi + 2^-11 acc_lo of each group) are summed through LDS in a
+// fixed order and each group finishes 16 / KS accumulator elements in the fused epilogue.  Per wave and k block: 3 MFMAs and one
+// 28-VALU split instead of 6 and 44.  Linear layers only (taps = 1, K a multiple of 32 KS).
+template <int BM, int BN, int WGM, int WGN, int KS, int NL, int NST, int PRO>
+__global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel(GemmP p) {
+    constexpr int NW = WGM * WGN;                         // waves of one K group
+    constexpr int NWC = NW * KS;                          // compute waves
+    constexpr int PA = BM / 8, PB = 2 * BN / 16;          // 1-KiB pieces of one group's chunk: f32 A rows, fp16 plane rows
+    constexpr int PG = PA + PB, PT = PG * KS;             // pieces per round (all groups)
+    constexpr int LW = PT / NL;                           // pieces per loader wave and round
+    constexpr int STAGE_A = BM * BK * 4, STAGE_B = PB * 1024, STAGE = STAGE_A + STAGE_B;   // bytes, one group's stage
+    constexpr int EPG = 16 / KS;
+    static_assert(BM == 32 * WGM && BN == 32 * WGN, "one 32x32 tile per wave");
+    static_assert(PT % NL == 0 && 16 % KS == 0 && NST >= 2 && (NST - 2) * LW < 64 && NWC + NL <= 16, "config");
+    static_assert(KS * NST * STAGE >= NWC * 16 * 64 * 4 || KS == 1, "the K-group reduction reuses the ring");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* ring = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.z;
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const bool nmajor = p.M < p.N;
+    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
+    const int nr = p.K / (BK * KS);                       // rounds (launch_gemm guarantees K % (32 KS) == 0)
+
+    if (wave_all >= NWC) {
+        // ------------------------------------------------------------------ loader wave lw: pieces lw, lw + NL, ... of a round
+        loader_priority(p.ldr_prio);
+        const int lw = wave_all - NWC;
+        const char* __restrict__ Xb = reinterpret_cast<const char*>(p.X + (long long)g * p.strideX);
+        const char* __restrict__ Wb = reinterpret_cast<const char*>(reinterpret_cast<const unsigned short*>(p.Wh) + (long long)g * p.strideW);
+        const char* zero = reinterpret_cast<const char*>(g_zero16);
+        const char* base[LW];            // operand base of the piece (X or Wh)
+        long long rowb[LW];              // byte offset of the lane's row + its k slot inside a chunk, < 0: zero row
+        int kmul[LW], ldsoff[LW];        // bytes per k element (4: A, 2: B); LDS byte offset of the piece inside its group's stage
+        int grp[LW];
+#pragma unroll
+        for (int j = 0; j < LW; ++j) {
+            const int pi = j * NL + lw, kg = pi / PG, w = pi - kg * PG;
+            grp[j] = kg;
+            if (w < PA) {                                  // A piece: rows w*8 .. +7, 8 lanes per 128-byte row
+                const int m = m0 + w * 8 + (lane >> 3);
+                int src = kInvalidRow;
+                if (m < p.M) src = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
+                const int kl = ((lane & 7) ^ ((w * 4 + (lane >> 4)) & 7)) * 4;
+                base[j] = Xb; kmul[j] = 4; ldsoff[j] = w * 1024;
+                rowb[j] = (unsigned)src < (unsigned)p.Rx ? ((long long)src * p.ldx + kl) * 4 : -1;
+            } else {                                       // B piece: plane pl, rows rb*16 .. +15, 4 lanes per 64-byte row
+                const int bp = w - PA, pl = bp / (BN / 16), rb = bp - pl * (BN / 16);
+                const int nl = rb * 16 + (lane >> 2), n = n0 + nl;
+                const int kl = ((lane & 3) ^ ((nl >> 2) & 3)) * 8;
+                base[j] = Wb; kmul[j] = 2; ldsoff[j] = STAGE_A + bp * 1024;
+                rowb[j] = n < p.N ? (pl * p.wh_plane + (long long)n * p.ldw + kl) * 2 : -1;
+            }
+        }
+        wait_vmcnt<0>();                                   // the rowbase loads
+        auto issue = [&](int rd, int st) {
+#pragma unroll
+            for (int j = 0; j < LW; ++j) {
+                const long long kb = (long long)(rd * KS + grp[j]) * BK * kmul[j];
+                const char* src = rowb[j] >= 0 ? base[j] + rowb[j] + kb : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(ring + (grp[j] * NST + st) * STAGE + ldsoff[j]),
+                                                 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nr) issue(st, st);
+        int st = 0;
+        for (int rd = 0; rd < nr; ++rd) {
+            if (rd + NST - 2 < nr) wait_vmcnt<(NST - 2) * LW>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                  // round rd complete in LDS; round rd-1's stages are free
+            if (rd + NST - 1 < nr) issue(rd + NST - 1, st == 0 ? NST - 1 : st - 1);
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute wave: K group kg, tile (wm, wn)
+    const int kg = wave_all / NW, wave = wave_all % NW;
+    const int wm = wave / WGN, wn = wave % WGN;
+    EpiPre<EPG> pre;
+    epi_prefetch<EPG>(p, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
+    float inv_s;
+    {
+        const int n = n0 + wn * 32 + (lane & 31);
+        inv_s = (p.wh_inv + (long long)g * p.wh_inv_stride)[n < p.N ? n : 0];
+    }
+    float ln_mu = 0.0f, ln_rs = 0.0f;
+    const bool lnx = PRO == PRO_LNX && p.pro_act == PRO_LNX;
+    if (lnx) lnx_row_stats<2>(p, m0 + wm * 32 + (lane & 31), lane >> 5, 32, ln_mu, ln_rs);      // lanes l and l ^ 32 share a row
+    f32x16 acc, acl;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.0f; acl[e] = 0.0f; }
+    const float pro_slope = p.pro_slope;
+    const int half = lane >> 5;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring + (unsigned)(kg * NST) * STAGE;
+    const int swza = (lane >> 1) & 7;
+    const unsigned a_lane = lds0 + ((wm * 32 + (lane & 31)) * BK) * 4;
+    const int nrow = wn * 32 + (lane & 31);
+    const int swzb = (nrow >> 2) & 3;
+    const unsigned b_lane = lds0 + STAGE_A + nrow * 64;
+    unsigned koffa[2][2], koffb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        koffa[b][0] = (unsigned)(((b * 4 + half * 2) ^ swza) * 16);
+        koffa[b][1] = (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
+        koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+    }
+    float amax = 0.0f;
+    f32x4 ra[2][2];
+    u32x4 rb[2][2], pln[2];
+    auto fetch = [&](int b, unsigned sa, unsigned sb) {
+        ra[b][0] = lds_read_b128(sa + koffa[b][0]);
+        ra[b][1] = lds_read_b128(sa + koffa[b][1]);
+        const unsigned vb = sb + koffb[b];                 // the plane offset is a constant of the tile: offset field
+        rb[b][0] = __builtin_bit_cast(u32x4, lds_read_b128_imm<0>(vb));
+        rb[b][1] = __builtin_bit_cast(u32x4, lds_read_b128_imm<BN * 64>(vb));
+    };
+    auto wait_block = [&](int b) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(ra[b][0]), "+v"(ra[b][1]), "+v"(rb[b][0]), "+v"(rb[b][1]));
+    };
+    auto products = [&](int b) {
+        const f16x8 Ah = __builtin_bit_cast(f16x8, pln[0]), Al = __builtin_bit_cast(f16x8, pln[1]);
+        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][1]), acl, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][0]), acc, 0, 0, 0);
+        acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8, rb[b][0]), acl, 0, 0, 0);
+    };
+    int st = 0;
+    for (int rd = 0; rd < nr; ++rd) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
+        fetch(0, sa, sb);
+        fetch(1, sa, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        // one tile per wave: a split does not fit in the shadow of its three MFMAs - split and multiply in turn, the other
+        // waves of the SIMD (another K group) fill the gaps
+        wait_block(0);
+        wait_block(1);
+        __builtin_amdgcn_sched_barrier(0);
+        split2_f16<PRO>(ra[0][0], ra[0][1], pro_slope, pln[0], pln[1], amax);
+        products(0);
+        __builtin_amdgcn_sched_barrier(0);
+        split2_f16<PRO>(ra[1][0], ra[1][1], pro_slope, pln[0], pln[1], amax);
+        products(1);
+        __builtin_amdgcn_sched_barrier(0);
+        st = st + 1 == NST ? 0 : st + 1;
+    }
+    if (p.x3h_flag != nullptr && __builtin_amdgcn_ballot_w64(amax >= kX3hMaxIn) != 0ull && lane == 0) atomicOr(p.x3h_flag, 1);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = __builtin_fmaf(acl[e], kX3hLoInv, acc[e]);
+    // ---- sum the KS partial tiles through LDS (every DMA has been waited for; the barrier orders the last operand reads),
+    // fixed order kg = 0..KS-1; group kg finishes elements e = kg*EPG .. kg*EPG+EPG-1
+    if constexpr (KS > 1) {
+        __syncthreads();                                  // (the loader waves have left: the barrier counts live waves only)
+        float* red = smem + ((kg * NW + wave) * 16) * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[e * 64] = acc[e];
+        __syncthreads();
+        float out[EPG];
+#pragma unroll
+        for (int i = 0; i < EPG; ++i) {
+            const int e = kg * EPG + i;
+            float v = 0.0f;
+#pragma unroll
+            for (int g2 = 0; g2 < KS; ++g2) v += smem[(((g2 * NW + wave) * 16) + e) * 64 + lane];
+            out[i] = v * inv_s;
+        }
+        if (lnx) {                                        // rstd_r * (acc - mean_r * s_n); the bias operand is c
+            const int n = n0 + wn * 32 + (lane & 31);
+            const float s_n = n < p.N ? p.ln_g[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < EPG; ++i) {
+                const int e = kg * EPG + i, rr = (e & 3) + 8 * (e >> 2) + 4 * half;
+                out[i] = __shfl(ln_rs, rr) * (out[i] - __shfl(ln_mu, rr) * s_n);
+            }
+        }
+        if (PRO == PRO_LNX && p.stat_out) epilogue_pre<EPG, PRO == PRO_LNX>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
+        else epilogue_pre<EPG>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, kg * EPG);
+    } else {
+        float out[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[e] = acc[e] * inv_s;
+        if (lnx) {
+            const int n = n0 + wn * 32 + (lane & 31);
+            const float s_n = n < p.N ? p.ln_g[n] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2) + 4 * half;
+                out[e] = __shfl(ln_rs, rr) * (out[e] - __shfl(ln_mu, rr) * s_n);
+            }
+        }
+        if (PRO == PRO_LNX && p.stat_out) epilogue_pre<16, PRO == PRO_LNX>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, 0);
+        else epilogue_pre<16>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, 0);
+    }
+}
+
+// ===================================================================================================
+// The WINDOW convolution (conv_win_x6_kernel, gemm_f32.hip: narrow square "same" convolutions of the vocoder's resblocks, Cin =
+// Cout = 32 QS; the f32 input window of the row tile sits in LDS once, the weights stream through the ring) in the x3h form: the
+// weights arrive as two fp16 planes (2 x BN x 64 B per chunk), every A fragment is split into two fp16 planes in registers.
+// NL > 0: NL loader waves refill the weight ring (and help load the window).
+template <int QS, int BM, int BN, int WGM, int WGN, int NST, int PRO, int NL>
+__global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(GemmP p) {
+    constexpr int NW = WGM * WGN;
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int BPIECES = 2 * BN / 16;                  // 1-KiB pieces of one weight chunk: 2 planes x BN rows x 64 B
+    constexpr int NI = NL > 0 ? NL : NW;                  // waves that issue the ring refill
+    constexpr int B_IT = (BPIECES + NI - 1) / NI;
+    constexpr int STAGE_B = B_IT * NI * 1024;             // BYTES per ring stage (dummy slots included)
+    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * B_IT < 64 && BN == 32 * QS, "config");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = NL > 0 && wave_all >= NW;
+    const int wave = loader ? wave_all - NW : wave_all;   // index among the loaders / among the compute waves
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int taps = p.taps, dil = p.dil;
+    const int WR = BM + (taps - 1) * dil, WRp = (WR + 7) & ~7;
+    char* ring = reinterpret_cast<char*>(smem);
+    float* win = smem + NST * STAGE_B / 4;                          // [QS][WRp][32] f32, slot-swizzled rows
+
+    const int ntm = (p.M + BM - 1) / BM;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, qq = ntm >> 3, rr = ntm & 7;
+    const int tile = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int m0 = tile * BM;
+
+    const float* __restrict__ X = p.X;
+    const unsigned short* __restrict__ Wh = reinterpret_cast<const unsigned short*>(p.Wh);
+    const long long zoff_x = (const float*)g_zero16 - X;
+    const long long zoff_w = (const unsigned short*)g_zero16 - Wh;
+    const int ldx = p.ldx, Rx = p.Rx, Kt = p.K;
+    const long long plane = p.wh_plane;                             // elements between the weight planes
+
+    {   // ---- the f32 input window, once
+        const int lrow = lane >> 3;
+        const int ppq = WRp >> 3, pieces = QS * ppq;
+        const int row_first = m0 + p.shift0;
+        for (int pc = wave_all; pc < pieces; pc += NW + NL) {
+            const int q = pc / ppq, r8 = pc - q * ppq;
+            const int row = r8 * 8 + lrow;
+            const int grow = row_first + row;
+            const int slot = (lane & 7) ^ ((row >> 1) & 7);
+            const bool ok = (row < WR) & ((unsigned)grow < (unsigned)Rx);
+            const long long off = ok ? (long long)grow * ldx + q * 32 + slot * 4 : zoff_x;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                             (__attribute__((address_space(3))) void*)(win + (q * WRp + r8 * 8) * 32), 16, 0, 0);
+        }
+    }
+    // ---- weight chunks (2 fp16 planes x BN rows x 32 k = 64-byte rows) through the ring; piece = 16 rows of one plane;
+    // lane -> row lane >> 2, physical 16-B slot lane & 3, logical slot = phys ^ ((row >> 2) & 3)
+    const int nk = Kt / 32;
+    long long wofs[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+        const int pc = j * NI + wave;                    // piece = plane * (BN / 16) + row block
+        const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
+        const int n = rb * 16 + (lane >> 2);
+        const int sl = (lane & 3) ^ ((n >> 2) & 3);
+        wofs[j] = (pc < BPIECES && n < p.N) ? pl * plane + (long long)n * p.ldw + sl * 8 : -1;
+    }
+    auto issue = [&](int c, int st) {
+        char* Bs = ring + st * STAGE_B + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) {
+            const long long off = wofs[j] >= 0 ? wofs[j] + c * 32 : zoff_w;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wh + off),
+                                             (__attribute__((address_space(3))) void*)(Bs + j * NI * 1024), 16, 0, 0);
+        }
+    };
+    if (NL > 0 && loader) {        // ---- loader wave: window pieces above, then nothing but the ring
+        loader_priority(p.ldr_prio);
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nk) issue(st, st);
+        int st = 0;
+        for (int c = 0; c < nk; ++c) {
+            if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * B_IT>();   // window pieces (older) and chunk c have landed
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+            st = st + 1 == NST ? 0 : st + 1;
+        }
+        return;
+    }
+    constexpr bool PRET = TM * TN <= 2;
+    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
+    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, 0, m0 + wm * WTM, wn * WTN, lane);
+    float inv_s[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = wn * WTN + j * 32 + (lane & 31);
+        inv_s[j] = p.wh_inv[n < p.N ? n : 0];
+    }
+
+    f32x16 acc[TM][TN], acl[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; acl[i][j][e] = 0.0f; }
+
+    if constexpr (NL == 0) {
+#pragma unroll
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nk) issue(st, st);
+    } else {
+        wait_vmcnt<0>();               // this compute wave's window pieces, before the first barrier
+    }
+
+    const float pro_slope = p.pro_slope;
+    const int half = lane >> 5;
+    const unsigned lds_ring = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
+    const unsigned lds_win = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)win;
+    // B fragment of k block b (16 k): logical slot b*2 + half of row n = wn*WTN + j*32 + (lane & 31), plane pl
+    const int nrow = wn * WTN + (lane & 31);
+    const unsigned b_lane = lds_ring + nrow * 64;
+    const int swzb = (nrow >> 2) & 3;
+    unsigned koffb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+    const int arow0 = wm * WTM + (lane & 31);
+    float amax = 0.0f;
+
+    int st = 0, tap = 0, q = 0;
+    for (int c = 0; c < nk; ++c) {
+        if constexpr (NL == 0) {
+            if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * B_IT>();
+            else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int arow = arow0 + tap * dil;
+        const int swza = (arow >> 1) & 7;
+        const unsigned sa = lds_win + (unsigned)((q * WRp + arow) * BK) * 4;
+        const unsigned sb = b_lane + (unsigned)st * STAGE_B;
+        // the stage consumed in the previous iteration is free once everyone has passed the barrier: refill it first
+        if (NL == 0 && c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+        f32x4 ra[2][TM][2];
+        u32x4 rb[2][2][TN];
+        auto fetch = [&](int b) {
+            const unsigned va0 = sa + (unsigned)(((b * 4 + half * 2) ^ swza) * 16), va1 = sa + (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
+            const unsigned vb = sb + koffb[b];
+            static_for(std::make_integer_sequence<int, TM>{}, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                ra[b][i][0] = lds_read_b128_imm<i * 32 * BK * 4>(va0);
+                ra[b][i][1] = lds_read_b128_imm<i * 32 * BK * 4>(va1);
+            });
+            static_for(std::make_integer_sequence<int, 2 * TN>{}, [&](auto ic) {
+                constexpr int pl = decltype(ic)::value / TN, j = decltype(ic)::value % TN;
+                rb[b][pl][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<(pl * BN + j * 32) * 64>(vb));
+            });
+        };
+        constexpr int F = 2 * TM, NMF = 3 * TN, SPLIT_VALU = 28 + (PRO == ACT_RELU || PRO == ACT_LRELU ? 8 : 0);
+        constexpr int VPM = (SPLIT_VALU + NMF - 1) / NMF;
+        u32x4 pln[2][2];
+        auto products = [&](int b, int i, const u32x4* pp) {
+            const f16x8 Ah = __builtin_bit_cast(f16x8, pp[0]), Al = __builtin_bit_cast(f16x8, pp[1]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][1][j]), acl[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][0][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8, rb[b][0][j]), acl[i][j], 0, 0, 0);
+        };
+        auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
+        auto wait_block = [&](int b) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < TM; ++i) tie(b, i);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
+        };
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_block(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(1);
+        if constexpr (TM * TN == 1) {
+            // one tile per wave: split and multiply in turn and let the other wave of the SIMD fill the gaps
+            __builtin_amdgcn_sched_barrier(0);
+            split2_f16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], amax);
+            products(0, 0, pln[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_block(1);
+            __builtin_amdgcn_sched_barrier(0);
+            split2_f16<PRO>(ra[1][0][0], ra[1][0][1], pro_slope, pln[1][0], pln[1][1], amax);
+            products(1, 0, pln[1]);
+        } else {
+            split2_f16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], amax);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < F; ++s) {
+                const int b = s / TM, i = s % TM;
+                if (s + 1 < F) {
+                    const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
+                    if (b2 != b) {                   // block 1's fragments were requested a whole step ago
+                        wait_block(b2);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        tie(b2, i2);                 // keeps this split inside this step's scheduling region
+                    }
+                    split2_f16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], amax);
+                }
+                products(b, i, pln[s & 1]);
+                if (s + 1 < F) {
+#pragma unroll
+                    for (int k = 0; k < NMF; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        st = st + 1 == NST ? 0 : st + 1;
+        if (++q == QS) { q = 0; ++tap; }
+    }
+    if (p.x3h_flag != nullptr && __builtin_amdgcn_ballot_w64(amax >= kX3hMaxIn) != 0ull && lane == 0) atomicOr(p.x3h_flag, 1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = __builtin_fmaf(acl[i][j][e], kX3hLoInv, acc[i][j][e]) * inv_s[j];
+    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, 0, m0 + wm * WTM, wn * WTN, lane);
+    else epilogue<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // host side: the kernels of this unit by tile id and prologue (the tile table lives in gemm_f32.hip)
 #define MT2_X3H_LDR(BM_, BN_, WM_, WN_, NL_, NST_)                                                                          \
@@ -384,6 +854,15 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
       gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr, nullptr }
 
+#define MT2_X3H_KS(BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                                          \
+    { gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_NONE>, gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_RELU>, \
+      gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr,                                           \
+      gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, PRO_LNX> }
+
+#define MT2_X3H_WIN(QS_, BM_, BN_, WM_, WN_, NST_, NL_)                                                                         \
+    { conv_win_x3h_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_NONE, NL_>, conv_win_x3h_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_RELU, NL_>, \
+      conv_win_x3h_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_LRELU, NL_>, nullptr, nullptr, nullptr }
+
 X3hKernel x3h_kernel(int tile, int variant) {
     static void (*const kTable[kX3hTiles][6])(GemmP) = {
         MT2_X3H_LDR(128, 128, 4, 2, 4, 3),          // X3H_LDR_128x128: 8 compute + 4 loader waves, 3 x 32 KiB
@@ -392,6 +871,12 @@ X3hKernel x3h_kernel(int tile, int variant) {
         // spills inside the K loop) - ONE compute wave per SIMD + 4 loaders = 8 waves, 211 registers, no spill
         MT2_X3H_LDR_PLAIN(128, 128, 2, 2, 4, 3),    // X3H_LDR_128x128_W4
         MT2_X3H_LDR_PLAIN(128, 128, 2, 2, 4, 4),    // X3H_LDR_128x128_W4_S4: 4-deep ring (128 KiB)
+        MT2_X3H_KS(32, 64, 1, 2, 4, 8, 2),          // X3H_KS_32x64_K4: the 84 tile (8 compute + 8 loader waves)
+        MT2_X3H_KS(64, 64, 2, 2, 2, 8, 3),          // X3H_KS_64x64_K2: the 85 tile
+        MT2_X3H_KS(32, 32, 1, 1, 8, 8, 2),          // X3H_KS_32x32_K8: the 86 tile
+        MT2_X3H_WIN(1, 256, 32, 8, 1, 3, 0),        // X3H_WIN_256x32: the 34 tile (8 waves, one 32x32 tile each, no loader waves)
+        MT2_X3H_WIN(2, 256, 64, 8, 1, 3, 4),        // X3H_WIN_256x64: the 58 tile (8 compute + 4 loader waves)
+        MT2_X3H_WIN(4, 128, 128, 4, 2, 2, 4),       // X3H_WIN_128x128: the 59 tile
     };
     if (tile < 0 || tile >= kX3hTiles || variant < 0 || variant >= 6) return nullptr;
     return kTable[tile][variant];

@@ -201,6 +201,7 @@ class NativeModel:
             raise
         self.has_g, self.has_plm, self.has_adm = sd_g is not None, sd_plm is not None, sd_adm is not None
         self.has_vocoder = sd_hifigan is not None
+        self.range_fallbacks = 0        # calls repeated on the bf16 path because the fp16 range guard tripped (_guarded)
 
     # ---- lifetime
     def _push_one(self, name: str, arr) -> None:
@@ -246,6 +247,28 @@ class NativeModel:
         assert a.shape == (B,)
         return a
 
+    # ---- range guard of the fp16-pipe GEMMs (csrc/gemm_x3h.hip; option "x3h")
+    def range_guard(self) -> bool:
+        """Waits for this handle's last call; True when one of its fp16-pipe GEMMs saw an activation outside the fp16 range (the
+        guard is re-armed).  The outputs of that call are then to be discarded and the call repeated with option x3h = 0."""
+        t = C.c_int(0)
+        _check(self.lib.mt2_x3h_guard(self.h, C.byref(t)))
+        return bool(t.value)
+
+    def _guarded(self, call, check_range: bool = True):
+        """Run one native call (a callable returning its status); with check_range, wait for it and - should the range guard have
+        tripped - repeat it on the bf16 six-product path, which has f32's exponent range.  Costs one event wait per call;
+        check_range = False leaves the call asynchronous and the check (`range_guard()`) to the caller."""
+        _check(call())
+        if check_range and self.range_guard():
+            prev = self.get_option("x3h")
+            self.set_option("x3h", 0)
+            try:
+                _check(call())
+                self.range_fallbacks += 1
+            finally:
+                self.set_option("x3h", prev)
+
     # ---- stages (C ABI one-to-one)
     def tc_latent(self, phone, mel, phone_lens=None, mel_lens=None):
         import torch
@@ -255,7 +278,7 @@ class NativeModel:
         mel = self._f32(mel)
         pl, ml = self._lens(phone_lens, B, Np), self._lens(mel_lens, B, Tp)
         out = torch.empty(B, Np, self.g_cfg.mrte.hidden_size, device=mel.device, dtype=torch.float32)
-        _check(self.lib.mt2_mrte_tc_latent(self.h, _stream(), _ptr(phone), _iptr(pl), Np, _ptr(mel), _iptr(ml), Tp, B,
+        self._guarded(lambda: self.lib.mt2_mrte_tc_latent(self.h, _stream(), _ptr(phone), _iptr(pl), Np, _ptr(mel), _iptr(ml), Tp, B,
                                            _ptr(out)))
         return out
 
@@ -267,7 +290,7 @@ class NativeModel:
         s = self.g_cfg.mrte.mel_stride
         Tc = (int(ml.max()) - 1) // s + 1
         out = torch.empty(B, Tc, self.g_cfg.mrte.hidden_size, device=mel.device, dtype=torch.float32)
-        _check(self.lib.mt2_mrte_mel_context(self.h, _stream(), _ptr(mel), _iptr(ml), Tp, B, _ptr(out), Tc))
+        self._guarded(lambda: self.lib.mt2_mrte_mel_context(self.h, _stream(), _ptr(mel), _iptr(ml), Tp, B, _ptr(out), Tc))
         return out
 
     def adm_infer(self, tc_latent, lens=None, return_float=False, p_prefix=None, max_steps: int = 0):
@@ -283,7 +306,7 @@ class NativeModel:
         if p_prefix is not None:
             p_prefix = self._f32(p_prefix).reshape(B, -1)
             P = p_prefix.shape[1]
-        _check(self.lib.mt2_adm_infer_forced(self.h, _stream(), _ptr(tc), _iptr(ln), Np, B, _ptr(p_prefix), P,
+        self._guarded(lambda: self.lib.mt2_adm_infer_forced(self.h, _stream(), _ptr(tc), _iptr(ln), Np, B, _ptr(p_prefix), P,
                                              int(max_steps), _ptr(dur), _ptr(flt)))
         return (dur, flt) if return_float else dur
 
@@ -325,7 +348,7 @@ class NativeModel:
         ln = self._lens(lens, B, Tq)
         codes = torch.empty(B, Tq, device=cond.device, dtype=torch.int64)
         logits = torch.zeros(B, Tq, self.plm_cfg.vq_bins, device=cond.device, dtype=torch.float32) if return_logits else None
-        _check(self.lib.mt2_plm_infer_prompted(self.h, _stream(), _ptr(cond), _iptr(ln), Tq, B, _ptr(prefix_codes), P,
+        self._guarded(lambda: self.lib.mt2_plm_infer_prompted(self.h, _stream(), _ptr(cond), _iptr(ln), Tq, B, _ptr(prefix_codes), P,
                                                int(max_steps), _ptr(codes), _ptr(logits)))
         return (codes, logits) if return_logits else codes
 
@@ -343,7 +366,7 @@ class NativeModel:
         x = self._f32(x)
         M = x.shape[0]
         idx = torch.empty(M, device=x.device, dtype=torch.int64)
-        _check(self.lib.mt2_vq_quantize(self.h, _stream(), _ptr(x), M, _ptr(idx)))
+        self._guarded(lambda: self.lib.mt2_vq_quantize(self.h, _stream(), _ptr(x), M, _ptr(idx)))
         return idx
 
     def vqpe_forward(self, mel, lens=None, return_ze=False):
@@ -356,7 +379,7 @@ class NativeModel:
         zq = torch.empty(B, T, self.g_cfg.vqpe.vq_dim, device=mel.device, dtype=torch.float32)
         codes = torch.empty(1, B, Tq, device=mel.device, dtype=torch.int64)
         ze = torch.empty(B, Tq, self.g_cfg.vqpe.vq_dim, device=mel.device, dtype=torch.float32) if return_ze else None
-        _check(self.lib.mt2_vqpe_forward(self.h, _stream(), _ptr(mel), _iptr(ln), T, ld, B, _ptr(zq), _ptr(codes), Tq,
+        self._guarded(lambda: self.lib.mt2_vqpe_forward(self.h, _stream(), _ptr(mel), _iptr(ln), T, ld, B, _ptr(zq), _ptr(codes), Tq,
                                          _ptr(ze)))
         return (zq, codes, ze) if return_ze else (zq, codes)
 
@@ -366,7 +389,7 @@ class NativeModel:
         x = self._f32(x)
         ln = self._lens(lens, B, T)
         mel = torch.empty(B, self.g_cfg.mrte.mel_bins, T, device=x.device, dtype=torch.float32)
-        _check(self.lib.mt2_mel_decoder(self.h, _stream(), _ptr(x), _iptr(ln), T, B, _ptr(mel)))
+        self._guarded(lambda: self.lib.mt2_mel_decoder(self.h, _stream(), _ptr(x), _iptr(ln), T, B, _ptr(mel)))
         return mel
 
     def hifigan(self, mel, lens=None):
@@ -376,12 +399,12 @@ class NativeModel:
         ln = self._lens(lens, B, T)
         pad = int(getattr(self.hg_cfg, "inference_padding", 0))
         wav = torch.empty(B, 1, self.hg_cfg.hop * (T + 2 * pad), device=mel.device, dtype=torch.float32)
-        _check(self.lib.mt2_hifigan(self.h, _stream(), _ptr(mel), _iptr(ln), T, B, _ptr(wav)))
+        self._guarded(lambda: self.lib.mt2_hifigan(self.h, _stream(), _ptr(mel), _iptr(ln), T, B, _ptr(wav)))
         return wav
 
     def synthesize_batch(self, phone, phone_lens, prompt_mel, prompt_lens, forced_dur=None, forced_codes=None,
                          run_plm=True, vocoder=False, skip_adm=False, tm_cap: Optional[int] = None,
-                         return_aux=False, prompt_vqpe=False, mel_out=None):
+                         return_aux=False, prompt_vqpe=False, mel_out=None, check_range=True):
         """Megatts.forward's no_grad block for a batch; returns (mel [B, Tm_cap, 80], mel_lens[, aux]).
         `mel_out`: a caller-owned contiguous f32 [B, tm_cap, mel_bins] device tensor the mels are written into (the native call
         zero-fills it first) - e.g. `dist.MelExchange.mel_view(B)`, so that a multi-GPU step gathers without a copy."""
@@ -424,15 +447,15 @@ class NativeModel:
         flags = ((MT2_RUN_PLM if run_plm else 0) | (MT2_RUN_VOCODER if vocoder else 0) | (MT2_SKIP_ADM if skip_adm else 0)
                  | (MT2_PROMPT_VQPE if prompt_vqpe else 0))
         pcodes = torch.empty(B, -(-Tp // st), device=dev, dtype=torch.int64) if prompt_vqpe else None
-        _check(self.lib.mt2_synthesize_batch(self.h, _stream(), _ptr(phone), _iptr(pl), Np, _ptr(prompt_mel), _iptr(ml),
-                                             Tp, B, _iptr(fd), _ptr(forced_codes), tq_cap, flags, _ptr(mel), tm_cap,
-                                             _iptr(mel_lens), _ptr(dur_out), _ptr(codes_out), _ptr(wav), _ptr(pcodes)))
+        self._guarded(lambda: self.lib.mt2_synthesize_batch(
+            self.h, _stream(), _ptr(phone), _iptr(pl), Np, _ptr(prompt_mel), _iptr(ml), Tp, B, _iptr(fd), _ptr(forced_codes), tq_cap,
+            flags, _ptr(mel), tm_cap, _iptr(mel_lens), _ptr(dur_out), _ptr(codes_out), _ptr(wav), _ptr(pcodes)), check_range)
         if return_aux:
             return mel, mel_lens, {"dur": dur_out, "codes": codes_out, "wav": wav, "prompt_codes": pcodes}
         return mel, mel_lens
 
     def synthesize_prompt_conditioned(self, phone, phone_lens, prompt_mel, prompt_lens, prompt_phone, prompt_phone_lens,
-                                      prompt_dur, forced_dur=None, vocoder=False, tm_cap: Optional[int] = None):
+                                      prompt_dur, forced_dur=None, vocoder=False, tm_cap: Optional[int] = None, check_range=True):
         """mt2_synthesize_prompt_conditioned: prompt-conditioned synthesis (the PLM continued from the prompt's prosody codes,
         modules/datamodule.py:161-177,196-212) as ONE native call -> (mel, mel_lens, aux) with aux["dur"] the ADM's own
         durations, aux["codes"] the decoded target codes, aux["prompt_codes"] [B, P] the prompt's VQ-PE codes."""
@@ -465,10 +488,10 @@ class NativeModel:
         pad = int(getattr(self.hg_cfg, "inference_padding", 0))
         wav = torch.empty(B, self.hg_cfg.hop * (tm_cap + 2 * pad), device=dev, dtype=torch.float32) if vocoder else None
         pcodes = torch.empty(B, -(-Tp // st), device=dev, dtype=torch.int64)
-        _check(self.lib.mt2_synthesize_prompt_conditioned(
+        self._guarded(lambda: self.lib.mt2_synthesize_prompt_conditioned(
             self.h, _stream(), _ptr(phone), _iptr(pl), Np, _ptr(prompt_mel), _iptr(ml), Tp, B, _ptr(prompt_phone), _iptr(ppl), Npp,
             _iptr(pd), _iptr(fd), tq_cap, MT2_RUN_VOCODER if vocoder else 0, _ptr(mel), tm_cap, _iptr(mel_lens), _ptr(dur_out),
-            _ptr(codes_out), _ptr(wav), _ptr(pcodes)))
+            _ptr(codes_out), _ptr(wav), _ptr(pcodes)), check_range)
         P = -(-int(ml[0]) // st)
         return mel, mel_lens, {"dur": dur_out, "codes": codes_out, "wav": wav, "prompt_codes": pcodes[:, :P]}
 

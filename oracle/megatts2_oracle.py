@@ -713,7 +713,14 @@ def enable_torch_kernels(threads: Optional[int] = None) -> None:
             x = same(Fn.leaky_relu(x, 0.01), w["conv_post.weight"], w["conv_post.bias"], 7)
             return torch.tanh(x[0, 0]).numpy()
 
-    g.update(linear=linear_t, conv1d=conv1d_t, layer_norm=layer_norm_t, mha=mha_t, hifigan=hifigan_t)
+    def vq_quantize_t(embed, x):        # core_vq.py:175-183 as written, evaluated by ATen
+        with torch.no_grad():
+            e = t(embed).t()
+            xt = t(x)
+            dist = -(xt.pow(2).sum(1, keepdim=True) - 2 * xt @ e + e.pow(2).sum(0, keepdim=True))
+            return dist.max(dim=-1).indices.numpy().astype(np.int64)
+
+    g.update(linear=linear_t, conv1d=conv1d_t, layer_norm=layer_norm_t, mha=mha_t, hifigan=hifigan_t, vq_quantize=vq_quantize_t)
 
 
 def disable_torch_kernels() -> None:

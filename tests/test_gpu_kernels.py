@@ -206,7 +206,9 @@ def test_gemm_with_layernorm_prologue(rt, cfg, M, N, K):
 @pytest.mark.parametrize("k,dil,C,cfg", [(3, 1, 32, 34), (7, 3, 32, 34), (11, 5, 32, -1), (3, 5, 64, 35), (7, 1, 64, -1),
                                          (11, 5, 64, 35), (3, 3, 128, 36), (7, 5, 128, -1), (11, 1, 128, 36),
                                          (3, 5, 64, 58), (11, 5, 64, 58), (7, 1, 64, 58), (3, 3, 128, 59), (11, 5, 128, 59),
-                                         (7, 5, 128, 59), (11, 1, 128, 59)])
+                                         (7, 5, 128, 59), (11, 1, 128, 59),
+                                         (3, 1, 32, 98), (7, 3, 32, 98), (11, 5, 32, 98), (3, 5, 64, 99), (11, 5, 64, 99), (7, 1, 64, 99),
+                                         (3, 3, 128, 100), (11, 5, 128, 100), (7, 5, 128, 100), (11, 1, 128, 100)])
 @pytest.mark.parametrize("pro", ["none", "lrelu"])
 def test_window_conv_x6_is_f32_equivalent(rt, k, dil, C, cfg, pro):
     """The window convolution on the bf16 matrix pipe (weights as three bf16 planes, activations split in registers,
@@ -234,7 +236,8 @@ def test_window_conv_x6_is_f32_equivalent(rt, k, dil, C, cfg, pro):
     wp = np.ascontiguousarray(w.transpose(0, 2, 1).reshape(C, k * C))
     act = {"none": rt.ACT_NONE, "lrelu": rt.ACT_LRELU}[pro]
     kw = dict(valid=dev(valid), shift0=-G, taps=k, dil=dil, Cin=C, pro_act=act, pro_slope=0.1)
-    x6 = rt.op_conv_x6(dev(X), dev(wp), dev(b), dev(R), force_cfg=cfg, **kw).cpu().numpy()
+    # 98 / 99 / 100 (round 6): the same tiles on the fp16 pipe in the three-product form (conv_win_x3h_kernel) - same bar
+    x6 = (rt.op_conv_x3h if cfg >= 91 else rt.op_conv_x6)(dev(X), dev(wp), dev(b), dev(R), force_cfg=cfg, **kw).cpu().numpy()
     f32 = rt.op_gemm(dev(X), dev(wp), dev(b), dev(R), force_cfg={32: 30, 64: 31, 128: 32}[C], **kw).cpu().numpy()
     f = (lambda v: v) if pro == "none" else (lambda v: np.where(v >= 0, v, v * np.float32(0.1)).astype(np.float32))
     err6 = err32 = 0.0
@@ -333,7 +336,7 @@ def test_gemm_x3h_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
     assert w3 <= 2.0 * w32 + 2.0 ** -23, (w3, w32)
 
 
-@pytest.mark.parametrize("cfg", [91, 93])
+@pytest.mark.parametrize("cfg", [91, 93, 96])
 def test_gemm_x3h_range_guard_and_corner_cases(rt, cfg):
     """The fp16 form's range behaviour, documented in gemm_x3h.hip: (1) activations up to 6e4 and weights of any magnitude (1e-30
     ... 1e+30 rows: the row scale) are exact to f32 class and leave the guard quiet; (2) an activation at or beyond 65504 raises
@@ -402,7 +405,7 @@ def test_gemm_x3h_range_guard_and_corner_cases(rt, cfg):
     assert rel(yn[ok], (X.astype(np.float64) @ Wn.T.astype(np.float64))[ok]) < 1e-6
 
 
-@pytest.mark.parametrize("cfg", [79, 80, 82, 84, 85, 86])
+@pytest.mark.parametrize("cfg", [79, 80, 82, 84, 85, 86, 95, 96, 97])
 @pytest.mark.parametrize("M,N,K", [(300, 512, 256), (77, 96, 512), (448, 3072, 1024), (33, 200, 768), (224, 1024, 4096),
                                    (16, 1024, 1024)])
 def test_gemm_x6_ks_is_f32_equivalent(rt, cfg, M, N, K):
@@ -416,7 +419,8 @@ def test_gemm_x6_ks_is_f32_equivalent(rt, cfg, M, N, K):
     R = rng.standard_normal((M, N)).astype(np.float32)
     valid = (rng.random(M) > 0.1).astype(np.int32)
     kw = dict(valid=dev(valid), shift0=0, taps=1, dil=1, Cin=K, pro_act=rt.ACT_RELU, epi_act=rt.ACT_NONE)
-    x6 = rt.op_conv_x6(dev(X), dev(W), dev(b), dev(R), force_cfg=cfg, **kw).cpu().numpy()
+    # 95 / 96 / 97 (round 6): the same tiles on the fp16 pipe in the three-product form (gemm_x3h_ks_kernel) - same bar
+    x6 = (rt.op_conv_x3h if cfg >= 91 else rt.op_conv_x6)(dev(X), dev(W), dev(b), dev(R), force_cfg=cfg, **kw).cpu().numpy()
     f32 = rt.op_gemm(dev(X), dev(W), dev(b), dev(R), force_cfg=22, **kw).cpu().numpy()
     ref = (np.maximum(X, 0).astype(np.float64) @ W.T.astype(np.float64) + b + R) * valid[:, None]
     e6, e32 = rel(x6, ref), rel(f32, ref)
@@ -699,7 +703,7 @@ def test_gemm_with_algebraic_layernorm(rt, cfg, M, N, K):
         assert rel(out2, ref[2::3][:Ms]) < 2e-5
 
 
-@pytest.mark.parametrize("cfg", [55, 84, 85, 86, -1, 91, 92])
+@pytest.mark.parametrize("cfg", [55, 84, 85, 86, -1, 91, 92, 95, 96, 97])
 @pytest.mark.parametrize("M,d,N2", [(200, 768, 1024), (1120, 768, 2304), (333, 1024, 4096), (97, 1024, 1024)])
 def test_gemm_layernorm_statistics_handed_from_gemm_to_gemm(rt, cfg, M, d, N2):
     """The AR layers' stand-alone LayerNorm launches (round 5; modules/transformer.py:88-102: `x = x + out_proj(att)` then

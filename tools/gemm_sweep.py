@@ -40,6 +40,19 @@ elif mode == "x3h":    # round 6: the fp16-pipe three-product tiles (91-94) agai
               ("adm_qkv", 1120, 2304, 768, 1), ("adm_ff0", 2240, 1024, 768, 1), ("adm_out", 2240, 768, 768, 1),
               ("mrte_stack", 14064, 512, 1536, 3), ("decoder", 13858, 512, 2560, 5), ("vqpe", 13858, 384, 1920, 5),
               ("hifi_s1", 111000, 256, 1792, 7), ("hifi_s1k11", 111000, 256, 2816, 11)]
+elif mode == "x3hk":   # round 6: the K-split tiles on the fp16 pipe (95-97) against their x6 forms (84-86) and the 128x128 tiles
+    cfgs = [84, 95, 85, 96, 86, 97, 55, 91]
+    shapes = [("plm_qkv", 96, 3072, 1024, 1), ("plm_qkv", 224, 3072, 1024, 1), ("plm_qkv", 448, 3072, 1024, 1), ("plm_qkv", 672, 3072, 1024, 1),
+              ("plm_ff0", 224, 4096, 1024, 1), ("plm_ff0", 448, 4096, 1024, 1), ("plm_ff0", 672, 4096, 1024, 1),
+              ("plm_ff1", 224, 1024, 4096, 1), ("plm_ff1", 448, 1024, 4096, 1), ("plm_ff1", 864, 1024, 4096, 1),
+              ("plm_out", 224, 1024, 1024, 1), ("plm_out", 448, 1024, 1024, 1), ("plm_out", 864, 1024, 1024, 1),
+              ("adm_qkv", 280, 2304, 768, 1), ("adm_qkv", 560, 2304, 768, 1), ("adm_qkv", 840, 2304, 768, 1), ("adm_ff0", 560, 1024, 768, 1),
+              ("adm_ff0", 1120, 1024, 768, 1), ("adm_out", 560, 768, 768, 1), ("adm_out", 1120, 768, 768, 1), ("adm_ff1", 1120, 768, 1024, 1)]
+elif mode == "x3hwin":
+    cfgs = [34, 98, 58, 99, 59, 100]
+    shapes = [("hifi_s4k3", 3552000, 32, 96, 3), ("hifi_s4k11", 3552000, 32, 352, 11), ("hifi_s3k3", 1776000, 64, 192, 3),
+              ("hifi_s3k11", 1776000, 64, 704, 11), ("hifi_s2k3", 888000, 128, 384, 3), ("hifi_s2k7", 888000, 128, 896, 7),
+              ("hifi_s2k11", 888000, 128, 1408, 11)]
 elif mode == "x6k":    # the AR steps' K-split launches: f32-MFMA tiles (22, 20, 18, 28) against their x6 forms (79-83) and the loader tile
     cfgs = [22, 79, 84, 20, 80, 85, 28, 82, 86, 55]
     shapes = [("plm_qkv", 32, 3072, 1024, 1), ("plm_qkv", 96, 3072, 1024, 1), ("plm_qkv", 224, 3072, 1024, 1),

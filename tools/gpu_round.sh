@@ -164,6 +164,11 @@ sweep_x6)
 sweep_x3h)
   timeout 900 python tools/gemm_sweep.py x3h > gpurun_out/gemm_sweep_x3h.txt 2>&1
   echo "sweep_x3h rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x3h.txt ;;
+sweep_x3hk)
+  timeout 900 python tools/gemm_sweep.py x3hk > gpurun_out/gemm_sweep_x3hk.txt 2>&1
+  echo "sweep_x3hk rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x3hk.txt
+  timeout 900 python tools/gemm_sweep.py x3hwin > gpurun_out/gemm_sweep_x3hwin.txt 2>&1
+  echo "sweep_x3hwin rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x3hwin.txt ;;
 ubench_f16)
   timeout 120 variants/ubench/mfma_f16_denorm > gpurun_out/ubench_mfma_f16.txt 2>&1
   echo "ubench_f16 rc=$?"; cat gpurun_out/ubench_mfma_f16.txt ;;
@@ -212,6 +217,14 @@ ablate)
     [ -d variants/$v ] && cp tools/*.py variants/$v/tools/ && (cd variants/$v && timeout 300 python tools/x6_ablate.py $v 2>&1 | grep -v amdgpu.ids) >> gpurun_out/x6_ablate.txt
   done
   echo "ablate rc=$?"; cat gpurun_out/x6_ablate.txt ;;
+ablate3h)
+  # the same for the x3h tile (tools/x3h_ablate.py; variants h_abl1..h_abl4)
+  : > gpurun_out/x3h_ablate.txt
+  timeout 300 python tools/x3h_ablate.py prod 2>&1 | grep -v amdgpu.ids >> gpurun_out/x3h_ablate.txt
+  for v in ${ABL_LIST:-h_abl1 h_abl2 h_abl3 h_abl4}; do
+    [ -d variants/$v ] && cp tools/*.py variants/$v/tools/ && (cd variants/$v && timeout 300 python tools/x3h_ablate.py $v 2>&1 | grep -v amdgpu.ids) >> gpurun_out/x3h_ablate.txt
+  done
+  echo "ablate3h rc=$?"; cat gpurun_out/x3h_ablate.txt ;;
 clock)
   # phase timer + clock probe (s_memtime vs s_memrealtime) in the MT2_PHASE_TIMING variant
   cp tools/*.py variants/phase/tools/

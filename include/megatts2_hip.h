@@ -300,14 +300,6 @@ int mt2_op_gemm_tm(void* stream, const float* X, long long x_gstride, int ldx, i
 int mt2_op_gemm_tm_pairs(void* stream, const float* X, int ldx, int Rx, int a_mul, int shift0, const float* Wtm, int Kw,
                          const float* bias, const float* R, int ldr, float* C, int ldc, int M, int N, int K, int epi_act,
                          const float* ln_gamma, const float* ln_beta, float ln_eps, float* stat_out, const float* ln_stat, int ln_nt);
-/* C[M,N] = act(LayerNorm(X rows m*a_mul + shift0; gamma, beta, eps) @ W^T + bias) in one launch (AR steps: LN1 -> QKV,
- * LN2 -> ff.0).  K <= 1024.  algebraic = 0: fragments normalised on the fly (force_cfg -1 or a 2-deep-ring config);
- * algebraic = 1 (what the model runs): W must be the gamma-scaled weights W'[n,k] = gamma[k] W[n,k], `bias` the vector
- * c[n] = sum_k beta[k] W[n,k] + b[n], `gamma` the vector s[n] = sum_k W'[n,k] (beta unused): the kernel computes the row
- * statistics in its prologue and rstd * (X W'^T - mean * s) + c in its epilogue; any LDS-DMA tile configuration. */
-int mt2_op_ln_gemm(void* stream, const float* X, int ldx, int Rx, int a_mul, int shift0, const float* gamma,
-                   const float* beta, float eps, const float* W, const float* bias, float* C, int ldc, int M, int N, int K,
-                   int epi_act, int force_cfg, int algebraic);
 int mt2_op_layernorm(void* stream, const float* x, int ldx, const float* gamma, const float* beta, const float* R1,
                      int ldr1, const int32_t* valid, float* out, int ldo, int M, int C, float eps, int act);
 int mt2_op_attention(void* stream, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,

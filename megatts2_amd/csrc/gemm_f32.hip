@@ -188,11 +188,9 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW);   // 1-KiB DMA pieces per wave per chunk
     constexpr int L = A_IT + B_IT;
-    constexpr bool LNP = PRO == PRO_LN;                         // LayerNorm prologue (see below)
-    constexpr bool LNA = PRO == PRO_LNA;                        // algebraic LayerNorm (see below)
-    constexpr int GBF = LNP ? 256 : 0;                          // + one 1-KiB piece per stage: gamma | beta chunk
-    constexpr int STAGE = (BM + BN) * BK + GBF;                 // floats per ring stage (of one K group)
-    static_assert(!LNP || (NST == 2 && TM == 1 && TN == 1), "LayerNorm prologue: 2-deep ring, one tile per wave");
+    constexpr int STAGE = (BM + BN) * BK;                       // floats per ring stage (of one K group)
+    static_assert(PRO == ACT_NONE || PRO == ACT_RELU || PRO == ACT_LRELU, "prologue activations only (the LayerNorm-prologue forms "
+                  "PRO_LN / PRO_LNA of rounds 1-2 were retired in round 6: profiles/r06_retired_kernel_forms_and_options.patch)");
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "piece/wave mismatch");
     static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64, "config");
     static_assert(KS == 1 || (TM == 1 && TN == 1 && 16 % KS == 0), "K split: one 32x32 tile per wave");
@@ -246,68 +244,6 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     // retire the rowbase loads HERE: once DMAs are in flight hipcc can only wait for an ordinary load
     // with vmcnt(0), which would drain the ring in the prologue
     wait_vmcnt<0>();
-    // ---- LayerNorm prologue (PRO_LN): C = LN(X) W^T without a separate LayerNorm launch.  Every workgroup first
-    // computes mean / rstd of ITS BM rows (two passes in registers, like layernorm_kernel; the rows come from L2,
-    // the other column tiles read the same ones), keeps them in LDS, and the K loop then normalises the A
-    // fragments on the fly: a' = (a - mean) * (rstd * gamma_k) + beta_k, gamma / beta travelling through the ring
-    // as one extra DMA piece per chunk.  Linear layers only (taps = 1), K <= 1024.
-    float ln_mu = 0.0f, ln_rs = 0.0f;
-    auto row_stats = [&]() {       // mean / rstd of this workgroup's BM rows -> LDS stat[BM][2] (two passes in registers)
-        float* stat = smem + KS * NST * STAGE;                  // [BM][2]
-        constexpr int NWALL = NW * KS;
-        constexpr int RB = 4;                                   // rows in flight per wave: ONE memory round trip per batch
-        const int Kf = p.K;
-        const float inv_k = 1.0f / (float)Kf;
-        for (int rb = wave_all * RB; rb < BM; rb += NWALL * RB) {
-            float4 xv[RB][4];
-            bool ok[RB];
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                const int m = m0 + rb + u;
-                int src = -1;
-                if (rb + u < BM && m < p.M) src = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
-                ok[u] = (unsigned)src < (unsigned)Rx;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int c = (v * 64 + lane) * 4;
-                    xv[u][v] = (ok[u] && c < Kf) ? *reinterpret_cast<const float4*>(X + (long long)src * ldx + c)
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                float sum = 0.0f;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) sum += (xv[u][v].x + xv[u][v].y) + (xv[u][v].z + xv[u][v].w);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-                const float mean = sum * inv_k;
-                float q2 = 0.0f;
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int c = (v * 64 + lane) * 4;
-                    if (c < Kf) {
-                        const float a = xv[u][v].x - mean, b = xv[u][v].y - mean, cc = xv[u][v].z - mean, d = xv[u][v].w - mean;
-                        q2 += (a * a + b * b) + (cc * cc + d * d);
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
-                if (lane == 0 && rb + u < BM) {
-                    stat[2 * (rb + u)] = ok[u] ? mean : 0.0f;
-                    stat[2 * (rb + u) + 1] = ok[u] ? 1.0f / sqrtf(q2 * inv_k + p.ln_eps) : 0.0f;
-                }
-            }
-        }
-    };
-    if constexpr (LNP) {
-        row_stats();
-        __syncthreads();
-        const float* stat = smem + KS * NST * STAGE;
-        ln_mu = stat[2 * (wm * WTM + (lane & 31))];
-        ln_rs = stat[2 * (wm * WTM + (lane & 31)) + 1];
-        wait_vmcnt<0>();
-    }
     constexpr bool PRE = TM * TN == 1;          // epilogue operands in flight during the K loop
     constexpr int EPGK = 16 / KS;
     EpiPre<PRE ? EPGK : 1> pre;
@@ -317,7 +253,6 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     else if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 
     float* ring = smem + kg * (NST * STAGE);
-    const bool w_nt = p.w_nt != 0;
     auto issue = [&](int rd, int st) {
         const int kchunk = (rd * KS + kg) * BK;
         float* As = ring + st * STAGE + wave * 256;            // + j*NW*256 floats per piece
@@ -339,21 +274,8 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
             const int k = kchunk + kslot_of(NW % 2 == 0 ? 0 : j);
             const bool ok = (k < Kt) & (wofs[j] >= 0);
             const long long off = ok ? wofs[j] + k : zoff_w;
-            if (w_nt)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + off),
-                                                 (__attribute__((address_space(3))) void*)(Bs + j * NW * 256), 16, 0, 2);
-            else
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + off),
-                                                 (__attribute__((address_space(3))) void*)(Bs + j * NW * 256), 16, 0, 0);
-        }
-        if constexpr (LNP) {   // piece rows 0 / 1 = gamma / beta of this chunk (rows 0,1 have swizzle 0), rest zero
-            if (wave == 0) {
-                const int k = kchunk + (lane & 7) * 4;
-                const float* srcp = (lrow < 2 && k < Kt) ? (lrow == 0 ? p.ln_g : p.ln_b) + k : g_zero16;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)srcp,
-                                                 (__attribute__((address_space(3))) void*)(ring + st * STAGE + (BM + BN) * BK),
-                                                 16, 0, 0);
-            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + off),
+                                             (__attribute__((address_space(3))) void*)(Bs + j * NW * 256), 16, 0, 0);
         }
     };
 
@@ -368,18 +290,6 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
 #pragma unroll
     for (int st = 0; st < NST - 1; ++st)
         if (st < nr) issue(st, st);
-
-    // ---- algebraic LayerNorm (PRO_LNA): C = LN(X; gamma, beta) W^T + b WITHOUT touching the K loop.  With
-    //   W'[n,k] = gamma[k] W[n,k],  s[n] = sum_k W'[n,k],  c[n] = sum_k beta[k] W[n,k] + b[n]   (prepared once at load)
-    //   LN(x) W^T + b = rstd * (x W'^T - mean * s) + c
-    // so the GEMM runs on the RAW rows against W' and only the epilogue differs.  The row statistics (same two-pass
-    // arithmetic as layernorm_kernel) are computed HERE, while the first ring stages are in flight - their latency
-    // hides the pass - and kept in LDS for the epilogue.  p.W = W', p.bias = c, p.ln_g = s.  Linear layers, K <= 1024.
-    if constexpr (LNA) {
-        row_stats();
-        wait_vmcnt<0>();            // the statistic loads share the counter with the DMAs: everything issued so far landed
-        __syncthreads();
-    }
 
     const float pro_slope = p.pro_slope;
     // MFMA operand fetch: inline-asm ds_read_b128 (a compiler-visible LDS load would make hipcc drain the
@@ -417,13 +327,11 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
         // first operand fetch of this round goes out BEFORE the address arithmetic of the next DMA issue, so
         // its LDS latency is covered by that VALU work instead of adding to it
         const unsigned sa = a_lane + (unsigned)st * (STAGE * 4), sb = b_lane + (unsigned)st * (STAGE * 4);
-        const unsigned sg = lds0 + (unsigned)st * (STAGE * 4) + (BM + BN) * BK * 4 + half * 16;   // gamma row; beta +128
-        f32x4 fa[2][TM], fb[2][TN], fg[2], fbt[2];
+        f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) fa[0][i] = lds_read_b128(sa + koff[0] + i * 32 * BK * 4);
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb[0][j] = lds_read_b128(sb + koff[0] + j * 32 * BK * 4);
-        if constexpr (LNP) { fg[0] = lds_read_b128(sg); fbt[0] = lds_read_b128(sg + 128); }
         if (rd + NST - 1 < nr) issue(rd + NST - 1, st == 0 ? NST - 1 : st - 1);
         MT2_T(2);                                   // first fragment reads issued + refill issue (drains those reads)
 #pragma unroll
@@ -439,18 +347,11 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
                 for (int i = 0; i < TM; ++i) fa[nxt][i] = lds_read_b128(sa + koff[kk + 1] + i * 32 * BK * 4);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[nxt][j] = lds_read_b128(sb + koff[kk + 1] + j * 32 * BK * 4);
-                if constexpr (LNP) {
-                    fg[nxt] = lds_read_b128(sg + (kk + 1) * 32);
-                    fbt[nxt] = lds_read_b128(sg + 128 + (kk + 1) * 32);
-                }
             }
             // pin the fetch of group kk+1 ABOVE the MFMAs of group kk (hipcc otherwise sinks the asm reads below
             // them and the s_waitcnt of the next group then exposes the whole LDS latency, every group)
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (LNP) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) fa[cur][0][e] = (fa[cur][0][e] - ln_mu) * (ln_rs * fg[cur][e]) + fbt[cur][e];
-            } else if (PRO != ACT_NONE && !LNA) {
+            if (PRO != ACT_NONE) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -477,11 +378,6 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
     }
 #endif
 #undef MT2_T
-    // LN-A correction of an accumulator element of row r (tile-local), column n: rstd_r * (acc - mean_r * s_n)
-    auto lna_fix = [&](float acc_v, int row_local, float s_n) {
-        const float* stat = smem + KS * NST * STAGE;
-        return stat[2 * row_local + 1] * (acc_v - stat[2 * row_local] * s_n);
-    };
     if constexpr (KS > 1) {
         // sum the KS partial tiles through LDS (ring memory is free: every DMA has been waited for and the
         // barrier below orders the last operand reads), fixed order kg = 0..KS-1; group kg finishes elements
@@ -501,29 +397,8 @@ __global__ __launch_bounds__(WGM* WGN * KS * 64) void gemm_f32_dma_kernel(GemmP 
             for (int g2 = 0; g2 < KS; ++g2) v += smem[(((g2 * NW + wave) * 16) + e) * 64 + lane];
             out[i] = v;
         }
-        if constexpr (LNA) {
-            const int n = n0 + wn * WTN + (lane & 31);
-            const float s_n = n < p.N ? p.ln_g[n] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < EPG; ++i) {
-                const int e = kg * EPG + i;
-                out[i] = lna_fix(out[i], wm * WTM + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), s_n);
-            }
-        }
         epilogue_pre<EPG>(p, out, pre, g, m0 + wm * WTM, n0 + wn * WTN, lane, kg * EPG);
     } else {
-        if constexpr (LNA) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WTN + j * 32 + (lane & 31);
-                const float s_n = n < p.N ? p.ln_g[n] : 0.0f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        acc[i][j][e] = lna_fix(acc[i][j][e], wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), s_n);
-            }
-        }
         if constexpr (PRE) {
             float out[16];
 #pragma unroll
@@ -981,352 +856,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x6_kernel(Gemm
 
 
 // ===================================================================================================
-// v2b: the implicit-GEMM engine on the bf16 matrix pipe, f32-equivalent ("x6", see conv_win_x6_kernel for the
-// arithmetic).  Same operand path as gemm_f32_dma_kernel - A chunks (f32, conv taps / row gathers / zero fill) and B
-// chunks through an LDS-DMA ring, XOR-swizzled, counted vmcnt - except that B travels as three bf16 planes
-// (3 x BN x 32 bf16 per chunk, 64-byte rows) and every A fragment is split into its planes in registers.  Used for
-// the throughput-bound launches (big tiles: conv stacks, vocoder stage 1, the large-M AR GEMMs); the latency-bound
-// K-split tiles stay on the f32 kernel.
-template <int BM, int BN, int WGM, int WGN, int NST, int PRO>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
-    constexpr int NW = WGM * WGN;
-    constexpr int WTM = BM / WGM, WTN = BN / WGN;
-    constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int A_IT = BM / (8 * NW);                   // f32 pieces: 8 rows x 128 B
-    constexpr int BPIECES = 3 * BN / 16;                  // bf16 plane pieces: 16 rows x 64 B
-    constexpr int B_IT = (BPIECES + NW - 1) / NW;
-    constexpr int L = A_IT + B_IT;
-    constexpr int STAGE_A = BM * BK * 4, STAGE_B = B_IT * NW * 1024, STAGE = STAGE_A + STAGE_B;   // bytes
-    static_assert(BM % (8 * NW) == 0 && WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64, "config");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    char* ring = reinterpret_cast<char*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int g = blockIdx.z;
-
-    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const bool nmajor = p.M < p.N;
-    const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
-
-    const float* __restrict__ X = p.X + (long long)g * p.strideX;
-    const unsigned short* __restrict__ W3 = reinterpret_cast<const unsigned short*>(p.W3) + (long long)g * p.strideW;
-    const long long zoff_x = (const float*)g_zero16 - X;
-    const long long zoff_w = (const unsigned short*)g_zero16 - W3;
-    const long long plane = p.w3_plane;
-
-    const int lrow = lane >> 3;
-    auto kslot_of = [&](int j) { return ((lane & 7) ^ (((j * NW + wave) * 4 + (lane >> 4)) & 7)) * 4; };
-    int abase[A_IT];
-#pragma unroll
-    for (int j = 0; j < A_IT; ++j) {
-        const int m = m0 + (j * NW + wave) * 8 + lrow;
-        int b = kInvalidRow;
-        if (m < p.M) b = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
-        abase[j] = b;
-    }
-    const int Kt = p.K, ldw = p.ldw;
-    long long wofs[B_IT];
-    int wk[B_IT];
-#pragma unroll
-    for (int j = 0; j < B_IT; ++j) {
-        const int pc = j * NW + wave;                    // piece = plane * (BN / 16) + row block
-        const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
-        const int nl = rb * 16 + (lane >> 2);
-        const int n = n0 + nl;
-        wk[j] = ((lane & 3) ^ ((nl >> 2) & 3)) * 8;     // k offset of this lane's 16-byte slot inside a chunk
-        wofs[j] = (pc < BPIECES && n < p.N) ? pl * plane + (long long)n * ldw : -1;
-    }
-    const int nk = (Kt + BK - 1) / BK;
-    const int ldx = p.ldx, Rx = p.Rx, Cin = p.Cin, dil = p.dil;
-    const bool multi_tap = p.taps > 1;
-    wait_vmcnt<0>();
-    constexpr bool PRET = TM * TN <= 2;
-    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
-    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-
-    // Fast path (every production launch): K is a whole number of chunks and a chunk never straddles a tap, so the tap
-    // and the channel offset of a chunk are wave-uniform and advance on the scalar unit - no per-lane division, the
-    // per-piece address is one multiply-add and one select.
-    const bool fast = (Kt % BK == 0) && (!multi_tap || Cin % BK == 0);
-    const bool w_nt = p.w_nt != 0;
-    int s_tap = 0, s_cc = 0;                              // of the next chunk to be issued (chunks are issued in order)
-    const int kl0 = kslot_of(0);
-    auto issue = [&](int c, int st) {
-        const int kchunk = c * BK;
-        float* As = reinterpret_cast<float*>(ring + st * STAGE) + wave * 256;
-        char* Bs = ring + st * STAGE + STAGE_A + wave * 1024;
-        if (fast) {
-            const int dsrc = s_tap * dil;
-#pragma unroll
-            for (int j = 0; j < A_IT; ++j) {
-                const int src = abase[j] + dsrc;
-                const int cc = s_cc + (NW % 2 == 0 ? kl0 : kslot_of(j));
-                const long long off = (unsigned)src < (unsigned)Rx ? (long long)src * ldx + cc : zoff_x;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
-                                                 (__attribute__((address_space(3))) void*)(As + j * NW * 256), 16, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < B_IT; ++j) {
-                const long long off = wofs[j] >= 0 ? wofs[j] + (kchunk + wk[j]) : zoff_w;
-                if (w_nt)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
-                                                     (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 2);
-                else
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
-                                                     (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
-            }
-            s_cc += BK;
-            if (multi_tap && s_cc == Cin) { s_cc = 0; ++s_tap; }
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < A_IT; ++j) {
-            const int k = kchunk + kslot_of(NW % 2 == 0 ? 0 : j);
-            int tap = 0, cc = k;
-            if (multi_tap) { tap = k / Cin; cc = k - tap * Cin; }
-            const int src = abase[j] + tap * dil;
-            const bool ok = (k < Kt) & ((unsigned)src < (unsigned)Rx);
-            const long long off = ok ? (long long)src * ldx + cc : zoff_x;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
-                                             (__attribute__((address_space(3))) void*)(As + j * NW * 256), 16, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < B_IT; ++j) {
-            const int k = kchunk + wk[j];
-            const bool ok = (k < Kt) & (wofs[j] >= 0);
-            const long long off = ok ? wofs[j] + k : zoff_w;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
-                                             (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
-        }
-    };
-
-    // One piece of the refill (fast path), so that the K loop can spread a chunk's L LDS-DMA instructions over its MFMA
-    // steps: measured with s_memtime (tools/x6_phase_timing.py), issuing all of them at the top of the chunk stalls every
-    // wave ~140 cycles per instruction (the CU's address path takes the 8 waves' 56 KB at ~58 B/clk) - 970 of a 256x128
-    // chunk's 5270 cycles with the matrix pipe idle.  r_dsrc / r_cc: tap row offset and channel offset of that chunk.
-    auto issue_piece = [&](int idx, int c, int st, int r_dsrc, int r_cc) {
-        if (idx < A_IT) {
-            const int j = idx;
-            float* As = reinterpret_cast<float*>(ring + st * STAGE) + wave * 256;
-            const int src = abase[j] + r_dsrc;
-            const int cc = r_cc + (NW % 2 == 0 ? kl0 : kslot_of(j));
-            const long long off = (unsigned)src < (unsigned)Rx ? (long long)src * ldx + cc : zoff_x;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
-                                             (__attribute__((address_space(3))) void*)(As + j * NW * 256), 16, 0, 0);
-        } else {
-            const int j = idx - A_IT;
-            char* Bs = ring + st * STAGE + STAGE_A + wave * 1024;
-            const long long off = wofs[j] >= 0 ? wofs[j] + (c * BK + wk[j]) : zoff_w;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W3 + off),
-                                             (__attribute__((address_space(3))) void*)(Bs + j * NW * 1024), 16, 0, 0);
-        }
-    };
-    // MEASURED SLOWER, so compiled out: with the pieces placed one behind an MFMA the refill phase at the chunk top
-    // disappears (968 -> 72 cycles) but every piece then stalls its wave ~230 cycles INSIDE the MFMA phase (2098 -> 3710
-    // cycles), 256x128: 178 -> 167 TF/s, 128x128: 153 -> 136 (profiles/r02_x6_phase_timing.txt).  An LDS-DMA instruction
-    // costs its issuing wave 140-230 cycles wherever it sits; only loader waves of their own would take it off the
-    // compute waves.
-    constexpr bool SPREAD = false;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-#pragma unroll
-    for (int st = 0; st < NST - 1; ++st)
-        if (st < nk) issue(st, st);
-
-    const float pro_slope = p.pro_slope;
-    const int half = lane >> 5;
-    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
-    const int swza = (lane >> 1) & 7;
-    const unsigned a_lane = lds0 + ((wm * WTM + (lane & 31)) * BK) * 4;
-    const int nrow = wn * WTN + (lane & 31);
-    const int swzb = (nrow >> 2) & 3;
-    const unsigned b_lane = lds0 + STAGE_A + nrow * 64;
-    unsigned koffa[2][2], koffb[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        koffa[b][0] = (unsigned)(((b * 4 + half * 2) ^ swza) * 16);
-        koffa[b][1] = (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
-        koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
-    }
-
-#ifdef MT2_PHASE_TIMING
-    // per-phase cycle sums of wave 0 of one workgroup in the middle of the grid (s_memtime; each stamp also drains lgkmcnt,
-    // so stamps sit only where the kernel waits anyway)
-    const bool timing = p.dbg != nullptr && bid == (int)(gridDim.x / 2) && wave == 0;
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-#define MT2_T(i_) do { if (timing) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i_] += t_ - tprev; tprev = t_; } } while (0)
-    if (timing) tprev = __builtin_readcyclecounter();
-#else
-#define MT2_T(i_) do { } while (0)
-#endif
-    int st = 0;
-    // one chunk; SP: refill spread over the MFMA steps (fast path), RF: this chunk refills (compile-time in the spread
-    // loops, so that a step stays ONE basic block and the sched_group_barrier pattern can place the pieces)
-    auto chunk = [&](int c, auto sp_c, auto rf_c) {
-        constexpr bool SP = decltype(sp_c)::value, RF = decltype(rf_c)::value;
-        MT2_T(5);                                   // rest of the previous chunk (MFMA steps)
-        if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();
-        else wait_vmcnt<0>();
-        MT2_T(0);                                   // DMA wait
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        MT2_T(1);                                   // barrier
-        const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
-        // refill of the stage freed by the barrier: as one block (general path), or piece by piece between the MFMA steps
-        const int rst = st == 0 ? NST - 1 : st - 1;
-        int r_dsrc = 0, r_cc = 0;
-        if constexpr (!SP) {
-            if (c + NST - 1 < nk) issue(c + NST - 1, rst);
-        } else if constexpr (RF) {
-            r_dsrc = s_tap * dil;
-            r_cc = s_cc;
-            s_cc += BK;
-            if (multi_tap && s_cc == Cin) { s_cc = 0; ++s_tap; }
-        }
-        MT2_T(2);                                   // refill issue
-        f32x4 ra[2][TM][2];
-        u32x4 rb[2][3][TN];
-        auto fetch = [&](int b) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ra[b][i][0] = lds_read_b128(sa + koffa[b][0] + i * 32 * BK * 4);
-                ra[b][i][1] = lds_read_b128(sa + koffa[b][1] + i * 32 * BK * 4);
-            }
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const f32x4 v = lds_read_b128(sb + koffb[b] + (unsigned)((pl * BN + j * 32) * 64));
-                    rb[b][pl][j] = __builtin_bit_cast(u32x4, v);
-                }
-        };
-        // Fragment-level software pipeline: the three planes of fragment s+1 are split on the vector pipe WHILE the
-        // matrix pipe works through the 6*TN products of fragment s (sched_group_barrier pins the interleave: hipcc
-        // otherwise issues the 44 VALU of a split as one block in front of its MFMAs and the matrix pipe idles).
-        constexpr int F = 2 * TM, NMF = 6 * TN;
-        u32x4 pln[2][3];
-        auto products = [&](int b, int i, const u32x4* pp) {
-            const bf16x8 A1 = __builtin_bit_cast(bf16x8, pp[0]), A2 = __builtin_bit_cast(bf16x8, pp[1]),
-                         A3 = __builtin_bit_cast(bf16x8, pp[2]);
-            // smallest terms first (they meet an accumulator increment of their own size before the big one lands);
-            // column tiles innermost, so that consecutive MFMAs never wait on each other's accumulator
-            constexpr int PA[6] = {3, 1, 2, 2, 1, 1}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                const bf16x8 At = PA[t] == 1 ? A1 : (PA[t] == 2 ? A2 : A3);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const bf16x8 Bt = __builtin_bit_cast(bf16x8, rb[b][PB[t]][j]);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(At, Bt, acc[i][j], 0, 0, 0);
-                }
-            }
-        };
-        // The LDS reads are inline asm, so the compiler sees no dependency between "s_waitcnt" and the consumers of the
-        // fragments: instruction selection may linearise a split in front of the wait that makes its input valid
-        // (sched_barrier only binds the machine scheduler).  Passing the registers through an empty asm after the wait
-        // gives every consumer a data dependency on it.
-        auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
-        auto wait_block = [&](int b) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < TM; ++i) tie(b, i);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
-        };
-        fetch(0);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_block(0);
-        __builtin_amdgcn_sched_barrier(0);
-        MT2_T(3);                                   // first fragment fetch (LDS latency)
-        fetch(1);
-        if constexpr (TM * TN == 1) {
-            // one tile per wave: 44 VALU per 6 MFMAs is more than fits in the MFMA shadow (measured: interleaving costs
-            // 20 %); split and multiply in turn and let the other wave of the SIMD fill the gaps
-            __builtin_amdgcn_sched_barrier(0);
-            split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
-            products(0, 0, pln[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            wait_block(1);
-            __builtin_amdgcn_sched_barrier(0);
-            split3_bf16<PRO>(ra[1][0][0], ra[1][0][1], pro_slope, pln[1][0], pln[1][1], pln[1][2]);
-            products(1, 0, pln[1]);
-        } else {
-        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
-        __builtin_amdgcn_sched_barrier(0);
-        MT2_T(4);                                   // second fetch issued + first split (drains the second fetch too)
-#pragma unroll
-        for (int s = 0; s < F; ++s) {
-            const int b = s / TM, i = s % TM;
-            if (s + 1 < F) {
-                const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
-                if (b2 != b) {                   // block 1's fragments were requested a whole step ago
-                    wait_block(b2);
-                    __builtin_amdgcn_sched_barrier(0);
-                } else {
-                    tie(b2, i2);                 // keeps this split inside this step's scheduling region
-                }
-                split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
-            }
-            constexpr int PPS = (L + F - 1) / F;          // refill pieces issued in this step
-            if constexpr (SP && RF) {
-#pragma unroll
-                for (int q = 0; q < PPS; ++q)
-                    if (s * PPS + q < L) issue_piece(s * PPS + q, c + NST - 1, rst, r_dsrc, r_cc);
-            }
-            products(b, i, pln[s & 1]);
-            if (SP || s + 1 < F) {
-                constexpr int VPM2 = (44 + (SP && RF ? 10 * PPS : 0) + NMF - 1) / NMF;     // + the pieces' address arithmetic
-#pragma unroll
-                for (int k = 0; k < NMF; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, VPM2, 0);
-                    if (SP && RF && k >= 1 && k <= PPS) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // one LDS-DMA piece behind an MFMA
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        }
-        st = st + 1 == NST ? 0 : st + 1;
-    };
-    {
-        using T_ = std::integral_constant<bool, true>;
-        using F_ = std::integral_constant<bool, false>;
-        int c = 0;
-        if (SPREAD && fast) {
-            for (; c + NST - 1 < nk; ++c) chunk(c, T_{}, T_{});
-            for (; c < nk; ++c) chunk(c, T_{}, F_{});
-        } else {
-            for (; c < nk; ++c) chunk(c, F_{}, F_{});
-        }
-    }
-#ifdef MT2_PHASE_TIMING
-    MT2_T(5);
-    if (timing && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) p.dbg[i] = tacc[i];
-        p.dbg[6] = (unsigned long long)nk;
-    }
-#endif
-#undef MT2_T
-    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-    else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-}
-
-// ===================================================================================================
 // v2d: the x6 engine with LOADER WAVES.  Measured with s_memtime (profiles/r02_x6_phase_timing.txt): an LDS-DMA
 // instruction costs the wave that issues it 140-230 cycles wherever it is placed - 970 of a 256x128 chunk's 5270 cycles
 // when the 8 compute waves issue the refill themselves, with the matrix pipe idle meanwhile.  Here NL extra waves do
@@ -1335,28 +864,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_x6_dma_kernel(GemmP p) {
 // chunk have landed (counted vmcnt), a compute wave once it has finished the previous chunk - then the loaders refill
 // the stage that barrier freed while the compute waves fetch, split and multiply.  Arithmetic, LDS layout and fragment
 // pipeline are gemm_x6_dma_kernel's.
-// MP (mid-chunk barrier, round 3): profiles/r03_x6_ablate.txt shows a chunk of this kernel costing the SUM of its matrix
-// time and of its serial head (barrier, first fragment fetch at LDS latency, first split): 1 622 ns = 902 (everything but
-// the MFMAs) + 720 (the MFMAs) at 864x4096x1024, with the operand ingest (973 ns alone) hidden.  The head is exposed
-// because every wave meets the barrier with an empty pipeline.  With MP the chunk's ONE barrier sits in the MIDDLE of the
-// chunk - right after the last LDS read of the chunk has been waited for (so the stage is free for the loaders exactly
-// as before) - and the products of every fragment are issued in two halves: the first half covers the LDS latency of the
-// NEXT fragment's fetch (which may be the first fragment of the next chunk: it has landed, the barrier just said so), the
-// second half is interleaved with that fragment's split.  No wave ever waits with the matrix pipe idle except at the
-// barrier itself, where its own MFMAs of the previous half are still draining.  Loader side, ring depth and chunks in
-// flight are unchanged (XP needed the next chunk one barrier earlier and lost a chunk in flight); same arithmetic order.
-// FR (free-running compute waves, round 3).  tools/ubench/x6_issue.hip (profiles/r03_ubench_x6_issue_v3_barriers.txt): two
-// waves on a SIMD, each with this loop's instruction mix (12 MFMAs : 1 split : 8 ds_read_b128), keep the matrix pipe at
-// 32.0-35.1 cycles per MFMA when they run FREE - and at 42.9 when they meet at a barrier every 24 MFMAs (= every chunk): the
-// pipe's arbiter serves the older wave first, so after every barrier the two waves run one after the other instead of
-// filling each other's fetch / split phases.  A compute wave never needs its SIMD partner: it needs "chunk c has landed"
-// from the loaders and the loaders need "stage free" from the compute waves.  With FR those two facts travel through LDS
-// counters instead of s_barrier: a loader adds 1 to ready[stage] once its pieces of the chunk have landed (counted vmcnt,
-// then ds_add), a compute wave adds 1 to done[stage] once its last LDS read of the chunk has returned; a compute wave
-// starts chunk c at ready[c % NST] >= NL * (c / NST + 1), a loader refills a stage for chunk cn at done >= NW * (cn / NST).
-// The counters are monotonic (zeroed once per launch), every wait is a bounded spin, the K loop has no s_barrier at all,
-// and the waves drift into the complementary phases the ubench shows.  Arithmetic and its order are unchanged.
-template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO, bool XP = false, bool MP = false, bool FR = false>
+// (The mid-chunk-barrier, cross-chunk-prefetch and free-running pipeline forms of rounds 2-3 - measured equal or slower, DESIGN 4.5 -
+// were retired in round 6: profiles/r06_retired_kernel_forms_and_options.patch.)
+template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(GemmP p) {
     constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -1367,12 +877,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     constexpr int L = A_IT + B_IT;
     constexpr int STAGE_A = BM * BK * 4, STAGE_B = PB * 1024, STAGE = STAGE_A + STAGE_B;   // bytes
     static_assert(PA % NL == 0 && PB % NL == 0 && WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64, "config");
-    // XP (cross-chunk prefetch, 3-deep ring): the loaders run one chunk further ahead (chunks <= c+1 are in LDS at the
-    // barrier in front of chunk c, chunk c+2 in flight), so a compute wave fetches and splits the FIRST fragments of chunk
-    // c+1 beside the last MFMAs of chunk c - the fetch latency (~400 cycles) and the first split (~270) leave the serial
-    // phase at the top of every chunk; only the barrier remains there.
-    static_assert(!XP || NST == 3, "cross-chunk prefetch needs the 3-deep ring");
-    static_assert(!(XP && MP) && !(FR && (XP || MP)), "one pipeline form at a time");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ring = reinterpret_cast<char*>(smem);
@@ -1389,28 +893,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
     const int Kt = p.K;
     const int nk = (Kt + BK - 1) / BK;
-    // FR: ready[NST] | done[NST] behind the ring (LDS byte addresses), zeroed before anything is in flight
-    const unsigned fr_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring + NST * STAGE;
-    if constexpr (FR) {
-        if (tid < 16) reinterpret_cast<unsigned*>(ring + NST * STAGE)[tid] = 0u;
-        __syncthreads();
-    }
-    // counter += 1 from ONE lane, branch-free (a divergent `if (lane == 0)` would cut the K loop into scheduling regions and
-    // the split would leave its MFMA group): exec is narrowed to lane 0 around the ds_add inside one asm statement
-    auto fr_signal = [&](unsigned addr) {
-        unsigned long long keep;
-        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %1, %2\n\ts_mov_b64 exec, %0"
-                     : "=&s"(keep) : "v"(addr), "v"(1u) : "memory");
-    };
-    auto fr_wait = [&](unsigned addr, unsigned need, int nap) {      // bounded spin until counter >= need
-#pragma nounroll
-        for (int spin = 0; spin < (1 << 16); ++spin) {      // >= 6 ms before giving up (a real wait is microseconds)
-            unsigned v;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
-            if ((unsigned)__builtin_amdgcn_readfirstlane((int)v) >= need) break;
-            if (nap) __builtin_amdgcn_s_sleep(2);
-        }
-    };
 
     if (wave_all >= NW) {
         // ------------------------------------------------------------------ loader wave lw: pieces lw, lw + NL, ...
@@ -1496,19 +978,8 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
             if (st < nk) issue(st, st);
         int st = 0;
         for (int c = 0; c < nk; ++c) {
-            if (!XP && c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();   // this wave's pieces of chunk c have landed
-            else wait_vmcnt<0>();                                        // XP: of chunk c+1 as well
-            if constexpr (FR) {
-                fr_signal(fr_base + (unsigned)st * 4u);              // this wave's pieces of chunk c are in LDS
-                const int cn = c + NST - 1, sp = st == 0 ? NST - 1 : st - 1;
-                if (cn < nk) {
-                    // stage sp held chunk c-1 (and cn / NST chunks in all): refill once every compute wave has read it
-                    if (c >= 1) fr_wait(fr_base + (unsigned)(NST + sp) * 4u, (unsigned)(NW * (cn / NST)), 1);
-                    issue(cn, sp);
-                }
-                st = st + 1 == NST ? 0 : st + 1;
-                continue;
-            }
+            if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();       // this wave's pieces of chunk c have landed
+            else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                            // chunk c complete; chunk c-1's stage is free
 #if defined(MT2_ABLATE) && MT2_ABLATE == 2                           // ablation: no operand ingest inside the K loop
             if (c + NST - 1 < nk && c < 1) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
@@ -1523,15 +994,14 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
     // ---------------------------------------------------------------------- compute wave
     const int wave = wave_all;
     const int wm = wave / WGN, wn = wave % WGN;
-    // epilogue operands in flight during the K loop (49 registers) - not in the MP form, whose two fragment sets in
-    // flight need them (its launches - the AR steps' QKV / feed-forward GEMMs, split-K slabs - have no residual operand)
-    constexpr bool PRET = TM * TN <= 2 && !MP;
+    // epilogue operands in flight during the K loop (49 registers)
+    constexpr bool PRET = TM * TN <= 2;
     EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
     if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     // pair-fed algebraic LayerNorm and row-statistics epilogue (GemmP::ln_stat / stat_out): the plain 128x128 tile only
     // (one 32-row block per wave, epilogue operands prefetched) in its PRO_LNX instantiation - the K loop of ACT_NONE, a
     // kernel of its own so that the plain launches keep their register allocation (the tile sits at its 168-VGPR cap)
-    constexpr bool LNXOK = PRET && TM == 1 && PRO == PRO_LNX && !XP && !FR;
+    constexpr bool LNXOK = PRET && TM == 1 && PRO == PRO_LNX;
     const bool lnx = LNXOK && p.pro_act == PRO_LNX;
     // [BM][2] (mean, rstd) behind the ring: the NW compute waves share the merge - 64 NW / BM adjacent lanes per row, <= 16 / LPR
     // float4 loads each (this tile sits at its 168-register cap with the epilogue operands in flight) - and every wave reads
@@ -1650,184 +1120,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
         if (lane == 0) p.dbg[9] = treal0 - t_entry;        // ticks from kernel entry to the start of the K loop
     }
 #endif
-    if constexpr (XP) {       // first fragments of chunk 0 (the only exposed fetch + split)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        fetch(0, a_lane, b_lane);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_block(0);
-        __builtin_amdgcn_sched_barrier(0);
-        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (FR) {
-        bool landed = false;                           // "the chunk about to start is known to have landed"
-        for (int c = 0; c < nk; ++c) {
-            const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
-            const int stn = st + 1 == NST ? 0 : st + 1;
-            if (!landed) fr_wait(fr_base + (unsigned)st * 4u, (unsigned)(NL * (c / NST + 1)), 0);
-            fetch(0, sa, sb);
-            __builtin_amdgcn_sched_barrier(0);
-            wait_block(0);
-            __builtin_amdgcn_sched_barrier(0);
-            fetch(1, sa, sb);
-            unsigned nflag = 0u;                       // the next chunk's ready counter rides on the same LDS wait
-            asm volatile("ds_read_b32 %0, %1" : "=v"(nflag) : "v"(fr_base + (unsigned)stn * 4u) : "memory");
-            split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < F; ++s) {
-                const int b = s / TM, i = s % TM;
-                if (s + 1 < F) {
-                    const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
-                    if (b2 != b) {
-                        wait_block(b2);                // the last LDS read of this chunk has returned:
-                        asm volatile("" : "+v"(nflag));
-                        __builtin_amdgcn_sched_barrier(0);
-                        fr_signal(fr_base + (unsigned)(NST + st) * 4u);        // the stage may be refilled
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else {
-                        tie(b2, i2);
-                    }
-                    split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
-                    products(b, i, pln[s & 1], 0, 6);
-                    pattern(NMF);
-                    __builtin_amdgcn_sched_barrier(0);
-                } else {
-                    products(b, i, pln[s & 1], 0, 6);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            landed = (unsigned)__builtin_amdgcn_readfirstlane((int)nflag) >= (unsigned)(NL * ((c + 1) / NST + 1));
-            st = stn;
-        }
-    } else if constexpr (MP) {
-        constexpr int VPH = (44 + NMF / 2 - 1) / (NMF / 2);        // VALU per MFMA when a split rides on HALF a fragment's products
-        auto half_pattern = [&]() {
-#pragma unroll
-            for (int k = 0; k < NMF / 2; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VPH, 0);
-            }
-        };
-        // one chunk; MORE = another chunk follows.  No branch inside: a conditional barrier / prefetch splits the body into
-        // scheduling regions (the split then sinks out of its MFMA group) and makes the register allocator copy the
-        // accumulators between blocks - the last chunk is a second, straight-line instance instead.
-        auto chunk = [&](auto more_tag, unsigned sa, unsigned sb, unsigned san, unsigned sbn) {
-            constexpr bool MORE = decltype(more_tag)::value;
-            MT2_T(5);                                              // (loop overhead)
-            fetch(1, sa, sb);                                      // block 1's registers: every reader was issued last chunk
-            __builtin_amdgcn_sched_barrier(0);
-            MT2_T(2);                                              // fetch issue
-            if constexpr (TM >= 2) {
-                // two or more fragments per k-block: a fetch is always requested a whole fragment (>= 12 MFMAs, ~400 cycles)
-                // before its first use, so the wait costs nothing and EVERY fragment's products carry exactly one split
-                // (1 MFMA : 44 / NMF VALU throughout - profiles/r03_ubench_x6_issue_v2.txt: 35.7 cycles per MFMA for a
-                // lone wave at that mix, 44 at twice the VALU density)
-#pragma unroll
-                for (int s = 0; s < F; ++s) {
-                    const int b = s / TM, i = s % TM;
-                    const int b2 = ((s + 1) / TM) & 1, i2 = (s + 1) % TM;
-                    u32x4* nxt = pln[(s + 1) & 1];
-                    const bool last = s + 1 == F;
-                    if (!last || MORE) {
-                        if (i2 == 0) {                             // the next fragment opens a k-block: its fetch has landed by now
-                            wait_block(b2);
-                            __builtin_amdgcn_sched_barrier(0);
-                        } else {
-                            tie(b2, i2);
-                        }
-                        split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, nxt[0], nxt[1], nxt[2]);
-                        products(b, i, pln[s & 1], 0, 6);
-                        pattern(NMF);
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else {
-                        products(b, i, pln[s & 1], 0, 6);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (MORE && s == TM - 1) {
-                        // k-block 0 is done and block 1 has been waited for: every LDS read of this chunk is complete - the
-                        // chunk's barrier (stage free, next chunk landed), then the request for the next chunk's block 0
-                        __builtin_amdgcn_s_barrier();
-                        asm volatile("" ::: "memory");
-                        fetch(0, san, sbn);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                return;
-            }
-#pragma unroll
-            for (int s = 0; s < F; ++s) {
-                const int b = s / TM, i = s % TM;
-                const int b2 = ((s + 1) / TM) & 1, i2 = (s + 1) % TM;
-                u32x4* nxt = pln[(s + 1) & 1];
-                if (i + 1 < TM) {
-                    // the next fragment belongs to the same k-block: already in registers
-                    tie(b2, i2);
-                    split3_bf16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, nxt[0], nxt[1], nxt[2]);
-                    products(b, i, pln[s & 1], 0, 6);
-                    pattern(NMF);
-                    __builtin_amdgcn_sched_barrier(0);
-                } else if (b == 0) {
-                    // last fragment of k-block 0: first half of its products over the LDS latency of block 1, the split of
-                    // block 1's first fragment beside the second half; THEN the chunk's barrier (every LDS read of this
-                    // chunk has been waited for: the stage is free; the next chunk has landed) and the request for the next
-                    // chunk's block 0 into registers whose readers have all been issued
-                    products(b, i, pln[s & 1], 0, 3);
-                    __builtin_amdgcn_sched_barrier(0);
-                    MT2_T(3);                                      // first half of the products (MFMA issue)
-                    wait_block(1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    MT2_T(0);                                      // LDS wait left over behind them
-                    split3_bf16<PRO>(ra[1][0][0], ra[1][0][1], pro_slope, nxt[0], nxt[1], nxt[2]);
-                    products(b, i, pln[s & 1], 3, 6);
-                    half_pattern();
-                    __builtin_amdgcn_sched_barrier(0);
-                    MT2_T(4);                                      // split beside the second half
-                    if constexpr (MORE) {
-                        __builtin_amdgcn_s_barrier();
-                        asm volatile("" ::: "memory");
-                        MT2_T(1);                                  // barrier
-                        fetch(0, san, sbn);
-                        __builtin_amdgcn_sched_barrier(0);
-                        MT2_T(2);
-                    }
-                } else if constexpr (MORE) {
-                    // last fragment of the chunk: the same two halves around the next chunk's first fragment
-                    products(b, i, pln[s & 1], 0, 3);
-                    __builtin_amdgcn_sched_barrier(0);
-                    MT2_T(3);
-                    wait_block(0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    MT2_T(0);
-                    split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, nxt[0], nxt[1], nxt[2]);
-                    products(b, i, pln[s & 1], 3, 6);
-                    half_pattern();
-                    __builtin_amdgcn_sched_barrier(0);
-                    MT2_T(4);
-                } else {
-                    products(b, i, pln[s & 1], 0, 6);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        };
-        // prologue: chunk 0 has landed (barrier #0); its first fragment is the only one fetched and split in the open
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        fetch(0, a_lane, b_lane);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_block(0);
-        __builtin_amdgcn_sched_barrier(0);
-        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
-        __builtin_amdgcn_sched_barrier(0);
-        for (int c = 0; c + 1 < nk; ++c) {
-            const int stn = st + 1 == NST ? 0 : st + 1;
-            chunk(std::true_type{}, a_lane + (unsigned)st * STAGE, b_lane + (unsigned)st * STAGE,
-                  a_lane + (unsigned)stn * STAGE, b_lane + (unsigned)stn * STAGE);
-            st = stn;
-        }
-        chunk(std::false_type{}, a_lane + (unsigned)st * STAGE, b_lane + (unsigned)st * STAGE, 0u, 0u);
-    } else
     for (int c = 0; c < nk; ++c) {
         const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
         const int stn = st + 1 == NST ? 0 : st + 1;
@@ -1838,30 +1130,19 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
             continue;
         }
 #endif
-        if constexpr (!XP) {
-            MT2_T(5);                               // MFMA steps of the previous chunk
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-#if defined(MT2_SETPRIO_HEAD)                // measurement builds: issue priority of a compute wave in the head of a chunk
-            __builtin_amdgcn_s_setprio(MT2_SETPRIO_HEAD);      // (fetch + first split) and in its product phase
-#endif
-            MT2_T(1);                               // barrier (loaders' landing wait included)
-            fetch(0, sa, sb);
-            __builtin_amdgcn_sched_barrier(0);
-            wait_block(0);
-            __builtin_amdgcn_sched_barrier(0);
-            MT2_T(3);                               // first fragment fetch
-            fetch(1, sa, sb);
-            split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
-            __builtin_amdgcn_sched_barrier(0);
-#if defined(MT2_SETPRIO_HEAD)
-            __builtin_amdgcn_s_setprio(MT2_SETPRIO_BODY);
-#endif
-            MT2_T(4);                               // second fetch + first split
-        } else {
-            fetch(1, sa, sb);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        MT2_T(5);                               // MFMA steps of the previous chunk
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        MT2_T(1);                               // barrier (loaders' landing wait included)
+        fetch(0, sa, sb);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_block(0);
+        __builtin_amdgcn_sched_barrier(0);
+        MT2_T(3);                               // first fragment fetch
+        fetch(1, sa, sb);
+        split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], pln[0][2]);
+        __builtin_amdgcn_sched_barrier(0);
+        MT2_T(4);                               // second fetch + first split
 #pragma unroll
         for (int s = 0; s < F; ++s) {
             const int b = s / TM, i = s % TM;
@@ -1878,32 +1159,12 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
                 products(b, i, pln[s & 1], 0, 6);
                 pattern(NMF);
                 __builtin_amdgcn_sched_barrier(0);
-            } else if (XP && c + 1 < nk) {
-                // last fragment of the chunk: block 0's registers are dead (every MFMA that reads them has been issued;
-                // the LDS data arrive long after those have read their operands) - request chunk c+1's block 0 into
-                // them, run the first half of the products, then split the next chunk's first fragment beside the rest
-                fetch(0, a_lane + (unsigned)stn * STAGE, b_lane + (unsigned)stn * STAGE);
-                __builtin_amdgcn_sched_barrier(0);
-                products(b, i, pln[s & 1], 0, 3);
-                __builtin_amdgcn_sched_barrier(0);
-                wait_block(0);
-                __builtin_amdgcn_sched_barrier(0);
-                split3_bf16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], pln[(s + 1) & 1][2]);
-                products(b, i, pln[s & 1], 3, 6);
-                pattern(NMF / 2);
-                __builtin_amdgcn_sched_barrier(0);
             } else {
                 products(b, i, pln[s & 1], 0, 6);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if constexpr (XP) {
-            if (c + 1 < nk) {                      // stage st is free for the loaders; chunk c+2 has landed
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-        }
-        st = st + 1 == NST ? 0 : st + 1;
+        st = stn;
     }
 #ifdef MT2_PHASE_TIMING
     MT2_T(5);
@@ -1942,10 +1203,10 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x6_ldr_kernel(Gemm
         if (p.stat_out) epilogue_pre_t<TM, TN, true>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
         else epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     } else if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-    // the 16-byte-store epilogue only where the variant has registers to spare (<= 8 waves: 256 VGPRs; MP: <= 127 in use):
+    // the 16-byte-store epilogue only where the variant has registers to spare (<= 8 waves: 256 VGPRs):
     // in the 12-wave 256x128 tile, which sits at its 168-VGPR cap, the extra code made the allocator spill an in-flight
     // ds_read destination inside the K loop (tools/asm_audit.py; NaNs at production size) - that tile keeps `epilogue`
-    else if ((NW + NL <= 8 || (MP && TM * TN <= 2)) && p.epi_t4 && epilogue_t4_ok(p))
+    else if (NW + NL <= 8 && p.epi_t4 && epilogue_t4_ok(p))
         epilogue_t4<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
 #ifndef MT2_PHASE_TIMING
@@ -2198,21 +1459,18 @@ struct TileCfg {
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (BM_ + BN_) * BK * sizeof(float),          \
       "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                   \
       { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_RELU>, \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_LRELU>, nullptr,                             \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, PRO_LNA> } }
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, 1, NST_, ACT_LRELU>, nullptr, nullptr } }
 #define MT2_DMAK(BM_, BN_, WM_, WN_, KS_, NST_)                                                        \
     { BM_, BN_, WM_* WN_ * KS_ * 64, (size_t)KS_ * NST_ * (BM_ + BN_) * BK * sizeof(float),              \
       "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "_s" #NST_,                                        \
       { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_RELU>, \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_LRELU>, nullptr,                           \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, PRO_LNA> } }
-// 2-deep ring, one 32x32 tile per wave: also built with the LayerNorm prologue
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, NST_, ACT_LRELU>, nullptr, nullptr } }
+// 2-deep ring, one 32x32 tile per wave
 #define MT2_DMAL(BM_, BN_, WM_, WN_, KS_)                                                               \
     { BM_, BN_, WM_* WN_ * KS_ * 64, (size_t)KS_ * 2 * (BM_ + BN_) * BK * sizeof(float),                 \
       "dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "_s2",                                             \
       { gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_NONE>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_RELU>, \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_LRELU>, gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, PRO_LN>, \
-        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, PRO_LNA> } }
+        gemm_f32_dma_kernel<BM_, BN_, WM_, WN_, KS_, 2, ACT_LRELU>, nullptr, nullptr } }
 
 #define MT2_WIN(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((BN_ / 8 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 256) * sizeof(float), \
@@ -2220,12 +1478,6 @@ struct TileCfg {
       { conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_NONE>, conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
         conv_win_f32_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, QS_ }
 
-#define MT2_GX6(BM_, BN_, WM_, WN_, NST_)                                                                      \
-    { BM_, BN_, WM_* WN_ * 64,                                                                                    \
-      (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024), \
-      "x6dma" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                          \
-      { gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_NONE>, gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_RELU>, \
-        gemm_x6_dma_kernel<BM_, BN_, WM_, WN_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true }
 #define MT2_GX6L(BM_, BN_, WM_, WN_, NL_, NST_)                                                                \
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),       \
       "x6ldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
@@ -2249,28 +1501,6 @@ struct TileCfg {
       "x6winl" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                           \
       { conv_win_x6_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_NONE, NL_>, conv_win_x6_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_RELU, NL_>, \
         conv_win_x6_kernel<QS_, BM_, BN_, WM_, WN_, NST_, ACT_LRELU, NL_>, nullptr, nullptr }, QS_, true }
-#define MT2_GX6LX(BM_, BN_, WM_, WN_, NL_)                                                                     \
-    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)3 * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),          \
-      "x6ldrx" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s3",                                                      \
-      { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_NONE, true>, gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_RELU, true>, \
-        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, 3, ACT_LRELU, true>, nullptr, nullptr }, 0, true }
-#define MT2_GX6LM(BM_, BN_, WM_, WN_, NL_, NST_)                                                               \
-    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024),       \
-      "x6ldm" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
-      { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, false, true>,                                   \
-        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, false, true>,                                   \
-        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, false, true>, nullptr, nullptr }, 0, true }
-#define MT2_GX6LF(BM_, BN_, WM_, WN_, NL_, NST_)                                                               \
-    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024) + 64,  \
-      "x6ldf" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                  \
-      { gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, false, false, true>,                            \
-        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, false, false, true>,                            \
-        gemm_x6_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, false, false, true>, nullptr, nullptr }, 0, true }
-#define MT2_GX6K(BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                           \
-    { BM_, BN_, (WM_* WN_ * KS_ + NL_) * 64, (size_t)KS_ * NST_ * ((size_t)BM_ * BK * 4 + (size_t)(3 * BN_ / 16) * 1024), \
-      "x6ks" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "+" #NL_ "_s" #NST_,                                         \
-      { gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_NONE>, gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_RELU>, \
-        gemm_x6_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr }, 0, true, KS_ }
 #define MT2_WX6(QS_, BM_, BN_, WM_, WN_, NST_)                                                               \
     { BM_, BN_, WM_* WN_ * 64, (size_t)NST_ * (((3 * BN_ / 16 + WM_ * WN_ - 1) / (WM_ * WN_)) * WM_ * WN_ * 1024),   \
       "x6win" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_s" #NST_,                                                     \
@@ -2298,52 +1528,52 @@ static void x3h_variant_exists(GemmP) {}
 
 static const TileCfg kCfgs[] = {
     // v1: register-staged double buffer (kept for A/B runs and as the reference implementation)
-    MT2_CFG(128, 128, 2, 2),   // 0
-    MT2_CFG(64, 128, 2, 2),    // 1
-    MT2_CFG(128, 64, 2, 2),    // 2
+    MT2_RETIRED("128x128_2x2"),                             // 0
+    MT2_RETIRED("64x128_2x2"),                              // 1
+    MT2_RETIRED("128x64_2x2"),                              // 2
     MT2_CFG(64, 64, 2, 2),     // 3
-    MT2_CFG(32, 128, 1, 4),    // 4
-    MT2_CFG(32, 64, 1, 2),     // 5
-    MT2_CFG(128, 32, 4, 1),    // 6
-    MT2_CFG(64, 32, 2, 1),     // 7
+    MT2_RETIRED("32x128_1x4"),                              // 4
+    MT2_RETIRED("32x64_1x2"),                               // 5
+    MT2_RETIRED("128x32_4x1"),                              // 6
+    MT2_RETIRED("64x32_2x1"),                               // 7
     // v2: LDS-DMA ring
-    MT2_DMA(128, 128, 2, 2, 3),   // 8
-    MT2_DMA(128, 128, 2, 2, 4),   // 9
-    MT2_DMA(64, 128, 2, 2, 4),    // 10
-    MT2_DMA(64, 64, 2, 2, 4),     // 11
+    MT2_RETIRED("dma128x128_2x2_s3"),                       // 8
+    MT2_RETIRED("dma128x128_2x2_s4"),                       // 9
+    MT2_RETIRED("dma64x128_2x2_s4"),                        // 10
+    MT2_RETIRED("dma64x64_2x2_s4"),                         // 11
     MT2_DMA(64, 64, 2, 2, 3),     // 12
-    MT2_DMA(32, 128, 1, 4, 4),    // 13
-    MT2_DMA(32, 64, 1, 2, 4),     // 14
+    MT2_RETIRED("dma32x128_1x4_s4"),                        // 13
+    MT2_RETIRED("dma32x64_1x2_s4"),                         // 14
     MT2_DMA(128, 32, 4, 1, 4),    // 15
     MT2_DMA(256, 128, 4, 2, 3),   // 16: 8 waves (2 per SIMD), 64x64 per wave, 43 FLOP per operand byte
     MT2_DMA(128, 128, 4, 2, 4),   // 17: 8 waves, 32x64 per wave
     // v2 + in-workgroup K split (one 32x32 tile per wave, KS waves per SIMD)
     MT2_DMAL(64, 64, 2, 2, 2),      // 18:  8 waves,  64 KiB LDS (2 workgroups per CU)
-    MT2_DMAK(64, 64, 2, 2, 2, 4),   // 19:  8 waves, 128 KiB
+    MT2_RETIRED("dma64x64_2x2_k2_s4"),                      // 19:  8 waves, 128 KiB
     MT2_DMAL(64, 64, 2, 2, 4),      // 20: 16 waves, 128 KiB
-    MT2_DMAK(32, 64, 1, 2, 4, 3),   // 21:  8 waves, 144 KiB, 32-row tiles for the first AR steps
+    MT2_RETIRED("dma32x64_1x2_k4_s3"),                      // 21:  8 waves, 144 KiB, 32-row tiles for the first AR steps
     MT2_DMAL(32, 64, 1, 2, 4),      // 22:  8 waves,  96 KiB
     // 64-wide outputs (HiFi-GAN stage 3): a 128-wide tile would idle half of its MFMAs
     MT2_DMA(256, 64, 4, 2, 3),      // 23: 8 waves, 64x32 per wave, 120 KiB
-    MT2_DMA(128, 64, 4, 2, 4),      // 24: 8 waves, 32x32 per wave,  96 KiB
-    MT2_DMA(128, 64, 4, 2, 2),      // 25: the same with a 2-deep ring: 48 KiB -> 3 workgroups per CU
-    MT2_DMAL(64, 64, 2, 2, 1),      // 26: 4 waves, 2-deep ring: 32 KiB -> 5 workgroups per CU
-    MT2_DMAK(128, 64, 4, 2, 2, 2),  // 27: 16 waves (2 K groups of 4x2), 96 KiB
+    MT2_RETIRED("dma128x64_4x2_s4"),                        // 24: 8 waves, 32x32 per wave,  96 KiB
+    MT2_RETIRED("dma128x64_4x2_s2"),                        // 25: the same with a 2-deep ring: 48 KiB -> 3 workgroups per CU
+    MT2_RETIRED("dma64x64_2x2_k1_s2"),                      // 26: 4 waves, 2-deep ring: 32 KiB -> 5 workgroups per CU
+    MT2_RETIRED("dma128x64_4x2_k2_s2"),                     // 27: 16 waves (2 K groups of 4x2), 96 KiB
     MT2_DMAL(32, 32, 1, 1, 8),      // 28: 8 waves = 8 K groups of one wave, 128 KiB: the shortest K chain (M*N <= 256 tiles)
-    MT2_DMAK(32, 32, 1, 1, 4, 3),   // 29: 4 waves, 96 KiB
+    MT2_RETIRED("dma32x32_1x1_k4_s3"),                      // 29: 4 waves, 96 KiB
     // v3: window convolutions (Cin = Cout in {32, 64, 128}); ring = 3 stages of max(BN / 8, waves) KiB
     MT2_WIN(1, 256, 32, 8, 1, 3),    // 30: 8 waves, one 32x32 tile each; 24 + 40 KiB -> 2 workgroups per CU
     MT2_WIN(2, 256, 64, 8, 1, 3),    // 31: 8 waves, 32x64 each; 24 + 80 KiB
     MT2_WIN(4, 128, 128, 4, 2, 3),   // 32: 8 waves, 32x64 each; 48 + 92 KiB
-    MT2_WIN(2, 128, 64, 4, 2, 3),    // 33: 8 waves, 32x32 each; 24 + 46 KiB -> 2 workgroups per CU
+    MT2_RETIRED("win128x64_4x2_s3"),                        // 33: 8 waves, 32x32 each; 24 + 46 KiB -> 2 workgroups per CU
     // v3b: window convolutions on the bf16 pipe, f32-equivalent (6 products); ring stage = 3 planes x BN x 64 B
     MT2_WX6(1, 256, 32, 8, 1, 3),    // 34: 8 waves, 32x32 each; 24 + 40 KiB
-    MT2_WX6(2, 256, 64, 8, 1, 3),    // 35: 8 waves, 32x64 each; 48 + 80 KiB
-    MT2_WX6(4, 128, 128, 4, 2, 2),   // 36: 8 waves, 32x64 each; 48 + 92 KiB
+    MT2_RETIRED("x6win256x64_8x1_s3"),                      // 35: 8 waves, 32x64 each; 48 + 80 KiB
+    MT2_RETIRED("x6win128x128_4x2_s2"),                     // 36: 8 waves, 32x64 each; 48 + 92 KiB
     // v2b: implicit GEMM on the bf16 pipe, f32-equivalent; stage = BM x 128 B (A, f32) + 3 x BN x 64 B (B planes)
-    MT2_GX6(256, 128, 4, 2, 2),      // 37: 8 waves, 64x64 each; 2 x 56 KiB
-    MT2_GX6(128, 128, 4, 2, 3),      // 38: 8 waves, 32x64 each; 3 x 40 KiB
-    MT2_GX6(128, 128, 4, 2, 2),      // 39: the same with a 2-deep ring: 80 KiB (LDS would admit two workgroups per CU, its 197 VGPRs one)
+    MT2_RETIRED("x6dma256x128_4x2_s2"),                     // 37: 8 waves, 64x64 each; 2 x 56 KiB
+    MT2_RETIRED("x6dma128x128_4x2_s3"),                     // 38: 8 waves, 32x64 each; 3 x 40 KiB
+    MT2_RETIRED("x6dma128x128_4x2_s2"),                     // 39: the same with a 2-deep ring: 80 KiB (LDS would admit two workgroups per CU, its 197 VGPRs one)
     MT2_RETIRED("x6dma128x256_2x4_s2"),      // 40: 8 waves, 64x64 each; 2 x 64 KiB (wide N: the AR feed-forward / QKV)
     MT2_RETIRED("x6dma256x128_8x2_s2"),      // 41: 16 waves, 32x64 each; 2 x 56 KiB (4 waves per SIMD)
     MT2_RETIRED("x6dma256x128_8x1_s2"),      // 42: 8 waves, 32x128 each: every A fragment is split ONCE per workgroup, 24 MFMAs per split
@@ -2358,7 +1588,7 @@ static const TileCfg kCfgs[] = {
     MT2_RETIRED("x6areg128x256_4x2_s2"),     // 50: 8 waves, 32x128 each; ring 2 x 48 KiB
     // v2d: x6 with loader waves (the compute waves issue no vector-memory instruction inside the K loop)
     MT2_GX6L(256, 128, 4, 2, 4, 2),  // 51: 8 compute + 4 loader waves
-    MT2_GX6L(256, 128, 4, 2, 2, 2),  // 52: 8 + 2
+    MT2_RETIRED("x6ldr256x128_4x2+2_s2"),                   // 52: 8 + 2
     MT2_RETIRED("x6ldr128x128_4x2+4_s2"),  // 53: 8 + 4
     MT2_RETIRED("x6ldr128x128_4x2+2_s2"),  // 54: 8 + 2
     MT2_GX6L_S(128, 128, 4, 2, 4, 3),  // 55: 8 + 4, 3-deep ring (120 KiB); + the PRO_LNX variant
@@ -2373,13 +1603,13 @@ static const TileCfg kCfgs[] = {
     MT2_RETIRED("x6ldrd128x128_4x2+4_s3"),       // 62
     // v2d, small tiles for launches that cannot fill the chip with 128x128 tiles (the AR steps' mid-size GEMMs): one
     // 32x32 tile per compute wave, 3-deep ring
-    MT2_GX6L(64, 128, 2, 4, 4, 3),      // 63: 8 + 4 waves, 96 KiB
-    MT2_GX6L(128, 64, 4, 2, 4, 3),      // 64: 8 + 4 waves, 84 KiB (less operand ingest per FLOP than 63: the A panel is the cheap one)
+    MT2_RETIRED("x6ldr64x128_2x4+4_s3"),                    // 63: 8 + 4 waves, 96 KiB
+    MT2_RETIRED("x6ldr128x64_4x2+4_s3"),                    // 64: 8 + 4 waves, 84 KiB (less operand ingest per FLOP than 63: the A panel is the cheap one)
     MT2_RETIRED("x6ldr64x128_2x4+2_s3"),      // 65: 8 + 2 waves
     MT2_RETIRED("x6ldr128x64_4x2+2_s3"),      // 66: 8 + 2 waves
     // v2f: loader waves + mid-chunk barrier (MP): fragment fetch and split never wait with an empty matrix pipe
-    MT2_GX6LM(128, 128, 4, 2, 4, 3),    // 67: the 55 tile
-    MT2_GX6LM(256, 128, 4, 2, 4, 2),    // 68: the 51 tile
+    MT2_RETIRED("x6ldm128x128_4x2+4_s3"),                   // 67: the 55 tile
+    MT2_RETIRED("x6ldm256x128_4x2+4_s2"),                   // 68: the 51 tile
     MT2_RETIRED("x6ldm128x64_4x2+4_s3"),     // 69: the 64 tile
     MT2_RETIRED("x6ldm64x128_2x4+4_s3"),     // 70: the 63 tile
     MT2_RETIRED("x6ldm128x128_4x2+4_s2"),    // 71: 128x128 with a 2-deep ring (80 KiB)
@@ -2387,19 +1617,19 @@ static const TileCfg kCfgs[] = {
     // the other (the matrix pipe's arbiter serves the older wave first, profiles/r03_ubench_x6_issue_v2.txt), each at a
     // lone wave's efficiency and each with its own exposed head; one wave with twice the tile has the same MFMA count per
     // SIMD, 37 % less LDS traffic, half the splits per MFMA, and 256 registers for the MP pipeline
-    MT2_GX6LM(128, 128, 2, 2, 4, 3),    // 72: 4 + 4 waves, 120 KiB
+    MT2_RETIRED("x6ldm128x128_2x2+4_s3"),                   // 72: 4 + 4 waves, 120 KiB
     MT2_RETIRED("x6ldm128x128_2x2+2_s3"),    // 73: 4 + 2 waves
     MT2_RETIRED("x6ldr128x128_2x2+4_s3"),     // 74: the same tile without the MP pipeline (A/B)
     // v2g: loader waves + FREE-RUNNING compute waves (LDS counters instead of s_barrier in the K loop)
-    MT2_GX6LF(128, 128, 4, 2, 4, 3),    // 75: the 55 tile
+    MT2_RETIRED("x6ldf128x128_4x2+4_s3"),                   // 75: the 55 tile
     MT2_RETIRED("x6ldf256x128_4x2+4_s2"),    // 76: the 51 tile
     MT2_RETIRED("x6ldf128x64_4x2+4_s3"),     // 77: the 64 tile
     MT2_RETIRED("x6ldf128x128_4x2+2_s3"),    // 78: 55 with 2 loader waves
     // v2h: x6 arithmetic on the K-split tiles of the AR steps, loader waves own the refill
-    MT2_GX6K(32, 64, 1, 2, 4, 4, 2),    // 79: 8 compute (4 K groups of 1x2) + 4 loader waves, 128 KiB: the 22 tile
-    MT2_GX6K(64, 64, 2, 2, 2, 4, 3),    // 80: 8 compute (2 K groups of 2x2) + 4 loader waves, 120 KiB: the 18 / 20 tile
+    MT2_RETIRED("x6ks32x64_1x2_k4+4_s2"),                   // 79: 8 compute (4 K groups of 1x2) + 4 loader waves, 128 KiB: the 22 tile
+    MT2_RETIRED("x6ks64x64_2x2_k2+4_s3"),                   // 80: 8 compute (2 K groups of 2x2) + 4 loader waves, 120 KiB: the 18 / 20 tile
     MT2_RETIRED("x6ks32x64_1x2_k4+2_s2"),    // 81: 79 with 2 loader waves
-    MT2_GX6K(32, 32, 1, 1, 8, 4, 2),    // 82: 8 K groups of one wave + 4 loader waves, 112 KiB: the 28 tile
+    MT2_RETIRED("x6ks32x32_1x1_k8+4_s2"),                   // 82: 8 K groups of one wave + 4 loader waves, 112 KiB: the 28 tile
     MT2_RETIRED("x6ks64x64_2x2_k2+4_s2"),    // 83: 80 with a 2-deep ring (80 KiB)
     MT2_GX6K_S(32, 64, 1, 2, 4, 8, 2),  // 84 (+ PRO_LNX): 79 with EIGHT loader waves (16 waves: a round's 64 pieces are 8 per loader)
     MT2_GX6K_S(64, 64, 2, 2, 2, 8, 3),  // 85 (+ PRO_LNX): 80 with eight loader waves (5 pieces per loader and round)
@@ -2411,15 +1641,15 @@ static const TileCfg kCfgs[] = {
     { 64, 32, 512, 0, "skinnytm64_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },  // 90   (+ LayerNorm prologue)
     // v4: the loader-wave tiles on the fp16 pipe, f32-equivalent THREE-product form (gemm_x3h.hip)
     MT2_X3HL(X3H_LDR_128x128, 128, 128, 4, 2, 4, 3, true),        // 91: the 55 tile (+ PRO_LNX), 3 x 32 KiB
-    MT2_X3HL(X3H_LDR_128x128_S4, 128, 128, 4, 2, 4, 4, true),     // 92: ... with a 4-deep ring (128 KiB)
-    MT2_X3HL(X3H_LDR_128x128_W4, 128, 128, 2, 2, 4, 3, false),    // 93: one compute wave per SIMD (64x64 per wave) + 4 loaders
+    MT2_RETIRED("x3hldr128x128_4x2+4_s4"),                  // 92: ... with a 4-deep ring (128 KiB)
+    MT2_RETIRED("x3hldr128x128_2x2+4_s3"),                  // 93: one compute wave per SIMD (64x64 per wave) + 4 loaders
     MT2_X3HL(X3H_LDR_128x128_W4_S4, 128, 128, 2, 2, 4, 4, false), // 94: ... with a 4-deep ring
     // ... and the K-split tiles of the AR steps (gemm_x3h_ks_kernel; + PRO_LNX)
     MT2_X3HK(X3H_KS_32x64_K4, 32, 64, 1, 2, 4, 8, 2),             // 95: the 84 tile, 96 KiB
     MT2_X3HK(X3H_KS_64x64_K2, 64, 64, 2, 2, 2, 8, 3),             // 96: the 85 tile, 96 KiB
     MT2_X3HK(X3H_KS_32x32_K8, 32, 32, 1, 1, 8, 8, 2),             // 97: the 86 tile, 128 KiB
     // ... and the window convolutions of the vocoder's resblocks (conv_win_x3h_kernel)
-    MT2_X3HW(X3H_WIN_256x32, 1, 256, 32, 8, 1, 3, 0),             // 98: the 34 tile
+    MT2_RETIRED("x3hwin256x32_8x1+0_s3"),                   // 98: the 34 tile
     MT2_X3HW(X3H_WIN_256x64, 2, 256, 64, 8, 1, 3, 4),             // 99: the 58 tile
     MT2_X3HW(X3H_WIN_128x128, 4, 128, 128, 4, 2, 2, 4),           // 100: the 59 tile
 };
@@ -2530,13 +1760,16 @@ static bool win_eligible(const GemmP& p) {
 }
 static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_out) {
     int bi = 12;                                                        // dma64x64_2x2_s3
+    const bool x3h_ok = p.Wh && p.wh_inv;
     if (o.win_conv && win_eligible(p) && !(o.force_cfg >= 0 && o.force_cfg < kNumCfgs)) {
         bi = p.Cin == 32 ? 30 : (p.Cin == 64 ? 31 : 32);
         if (o.x6_conv && p.W3) {
-            bi += 4;                                                    // the bf16-pipe form of the same tile
-            if (o.x6_loaders && bi == 35) bi = 58;                      // ... with loader waves (+5..14 %, sweep v2 of x6win)
-            if (o.x6_loaders && bi == 36) bi = 59;                      // (+2..6 %)
-            if (o.x3h >= 3 && p.Wh && p.wh_inv) bi = bi == 34 ? 98 : (bi == 58 ? 99 : (bi == 59 ? 100 : bi));      // the fp16-pipe forms
+            // the bf16-pipe forms: 34 (32 channels), and with loader waves 58 / 59 (64 / 128 channels: +5..14 % / +2..6 % over the
+            // self-refilling forms 35 / 36, retired in round 6)
+            bi = bi == 30 ? 34 : (bi == 31 ? 58 : 59);
+            // the fp16-pipe forms of the 64- and 128-channel tiles (profiles/r06_gemm_sweep_x3hwin_v1.txt: +19..37 % and +35..40 %; the
+            // 32-channel convolutions are HBM-side launches - 98 measured 3..19 % SLOWER than 34 - and stay on x6)
+            if ((o.x3h & 4) && x3h_ok) bi = bi == 58 ? 99 : (bi == 59 ? 100 : bi);
         }
         *idx_out = bi;
         return &kCfgs[bi];
@@ -2555,45 +1788,28 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     else if (t32 <= o.t32) bi = 22;                                     // dma32x64_1x2_k4_s2
     else if (t64 <= o.t_ks4) bi = 20;                                   // dma64x64_2x2_k4_s2
     else if (t64 <= o.t_ks2) bi = 18;                                   // dma64x64_2x2_k2_s2
-    // Throughput-bound launches move to the bf16 pipe (f32-equivalent x6 form) when the weights come with planes.
-    // profiles/r02_gemm_sweep_x6.txt: the x6 256x128 tile does 138-142 TF/s where the f32 tiles do 91-97 once it has
-    // >= ~160 tiles (conv stacks, vocoder stage 1, the PLM / ADM QKV and ff.0 at full batch); the x6 128x128 tile
-    // (2 workgroups per CU) wins from ~140 tiles on in isolation (90-126 vs 67-84 TF/s: QKV / ff.0 of one AR stream
-    // group, VQ-PE) and from ~100 tiles on inside the model, where two AR chains share the chip (C3 step 297.2 ->
-    // 295.2 ms, profiles/r02_opts_ab.txt); below that the K-split f32 tiles keep their latency advantage
-    // (out-projection, ff.3, early AR steps).
+    // Launches whose weights come with planes leave the f32 MFMA for the 16-bit matrix pipe in an f32-equivalent form: the
+    // loader-wave tiles (256x128 from t_x6_256 tiles on, 128x128 from t_x6_128 / t_x3h_128 on - conv stacks, vocoder stage 1, the
+    // PLM / ADM QKV and ff.0 at full batch) and, below that, the K-split tiles of the AR steps (out-projection, ff.3, early steps).
     if (o.x6_gemm && p.W3 && (p.K & 7) == 0 && (p.ldw & 7) == 0 && (p.pro_act < PRO_LN || p.pro_act == PRO_LNX) && p.N > 64) {
-        // loader-wave variants (profiles/r02_gemm_sweep_x6_v5_ldr.txt: +10..12 % over 37, +16..20 % over 39)
-        if (t256 >= o.t_x6_256) bi = o.x6_loaders ? 51 : 37;
-        else if (t128 >= o.t_x6_128) bi = o.x6_loaders ? 55 : 39;
-        // small x6 tiles (x6_small_cfg = 63..66) for launches whose 128x128 tiles would leave most of the chip idle
-        if (o.x6_small_cfg >= 63 && o.x6_small_cfg <= 64 && t256 < o.t_x6_256 && t128 <= o.t_x6_small_max) {
-            const TileCfg& sc = kCfgs[o.x6_small_cfg];
-            const long long ts = (long long)((p.M + sc.bm - 1) / sc.bm) * ((p.N + sc.bn - 1) / sc.bn) * p.groups;
-            if (ts >= o.t_x6_small_min) bi = o.x6_small_cfg;
+        const bool h1 = (o.x3h & 1) && x3h_ok;      // the 128x128 tile will run in its x3h form: its own crossover against the K-split tiles
+        if (t256 >= o.t_x6_256) bi = 51;
+        else if (t128 >= (h1 ? o.t_x3h_128 : o.t_x6_128)) bi = 55;
+        // K-split tiles on the bf16 pipe, eight loader waves (x6_ks: 0 off; 1, 3: the 32x64 k4 and 64x64 k2 tiles; 2, 4: + the 32x32
+        // k8 tile; 5: the 64x64 tile only)
+        if (o.x6_ks && p.taps == 1) {
+            if (bi == 22 && p.K % (BK * 4) == 0 && o.x6_ks != 5) bi = 84;
+            else if ((bi == 20 || bi == 18) && p.K % (BK * 2) == 0) bi = 85;
+            else if ((o.x6_ks == 2 || o.x6_ks == 4) && bi == 28 && p.K % (BK * 8) == 0) bi = 86;
         }
-        // MP form of the loader-wave tiles (mid-chunk barrier, fragment fetch / split behind the previous products)
-        // K-split tiles on the bf16 pipe (x6_ks: 1 = the 32x64 k4 and 64x64 k4/k2 tiles, 2 = the 32x32 k8 tile too)
-        if (o.x6_ks && p.taps == 1 && p.groups >= 1) {
-            const bool l8 = true;                         // the eight-loader forms (the four-loader ones, 79 / 80 / 82, stay for A/B via force)
-            // the 64x64 K-split x6 tile also beats the 128x128 loader tile while the launch has few 64x64 tiles
-            // (profiles/r03_gemm_sweep_x6k.txt: 448x3072x1024 82 vs 64 TF/s, 448x4096x1024 106 vs 82)
-            if (bi == 55 && t64 <= o.t_x6_ks_over128 && p.K % (BK * 2) == 0) bi = 20;
-            if ((bi == 22 || bi == 21) && p.K % (BK * 4) == 0 && o.x6_ks != 5) bi = l8 ? 84 : 79;
-            else if ((bi == 20 || bi == 18 || bi == 19) && p.K % (BK * 2) == 0) bi = l8 ? 85 : 80;
-            else if ((o.x6_ks == 2 || o.x6_ks == 4) && bi == 28 && p.K % (BK * 8) == 0) bi = l8 ? 86 : 82;
-        }
-        if (o.x6_mp256 && bi == 51) bi = 68;             // MP form of the 256x128 tile only (+2..7 % on the conv-stack shapes)
-        if (o.x6_mp == 4) bi = bi == 55 ? 75 : bi;            // free-running compute waves (128x128)
-        else if (o.x6_mp == 3) bi = bi == 55 ? 72 : bi;       // one compute wave per SIMD, MP pipeline
-        else if (o.x6_mp) bi = bi == 55 ? 67 : (bi == 51 && o.x6_mp >= 2 ? 68 : bi);
     }
     // the fp16-pipe form of the tile (three products instead of six) where one exists and the weights come with fp16 planes
     // (profiles/r06_gemm_sweep_x3h_v1_gate.txt: the 128x128 x3h tile beats BOTH x6 loader tiles on every shape of the model - 199 vs
     // 146 TF/s at 864x4096x1024, 245 vs 188 at 4096^3 - and with long K chains and enough tiles to keep every CU busy for more than
     // one round the one-compute-wave-per-SIMD form, 64x64 per wave, is a few per cent ahead: 238 vs 221 on the decoder stack)
-    if (o.x3h && p.Wh && p.wh_inv && (bi == 55 || bi == 51)) bi = (p.K >= o.x3h_w4_mink && t128 >= o.t_x3h_w4) ? 94 : 91;
-    if (o.x3h >= 2 && p.Wh && p.wh_inv && bi >= 84 && bi <= 86) bi += 11;                  // K-split tiles: 84 / 85 / 86 -> 95 / 96 / 97
+    if ((o.x3h & 1) && x3h_ok && (bi == 55 || bi == 51)) bi = (p.K >= o.x3h_w4_mink && t128 >= o.t_x3h_w4) ? 94 : 91;
+    // K-split tiles 84 / 85 / 86 -> 95 / 96 / 97 (profiles/r06_gemm_sweep_x3hk_v1.txt: +13..20 %, +25..50 %, +20..30 % per launch)
+    if ((o.x3h & 2) && x3h_ok && bi >= 84 && bi <= 86) bi += 11;
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;
     *idx_out = bi;
     return &kCfgs[bi];
@@ -2641,7 +1857,6 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     }
     if (sk_forced || (o.skinny_rows > 0 && o.force_cfg < 0 && p.groups >= o.skinny_groups && gemm_skinny_eligible(p, o.skinny_rows))) {
         if (!gemm_skinny_eligible(p, 64)) return hipErrorInvalidValue;
-        p.w_nt = o.skinny_nt ? 1 : 0;
         const int sidx = p.M <= 32 ? kSkinny32 : kSkinny64;
         if (opts) opts->last_cfg = kCfgs[sidx].name;
         if (opts && opts->trace_on) {
@@ -2672,29 +1887,12 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     }
     // variant index: pair statistics (consumer and / or producer side) run the PRO_LNX instantiation - the K loop of ACT_NONE
     const int fi = (p.pro_act == PRO_LNX || p.stat_out) ? PRO_LNX : p.pro_act;
-    if (p.pro_act == PRO_LNA) {     // algebraic LayerNorm: every LDS-DMA configuration has the variant
-        if (p.taps != 1 || p.K > 1024 || !p.ln_g || p.groups != 1) return hipErrorInvalidValue;
-        if (!c->fn[PRO_LNA]) return hipErrorNotSupported;
-        // Measured (profiles/r02_lnalg_ab.txt): the statistics pass costs one memory round trip per 4 rows of a wave.
-        // Tiles whose waves own <= 4 rows each (the K-split configurations of the latency-bound AR launches) hide it
-        // behind the ring prefetch; a 256-row tile with 8 waves (32 rows per wave) pays ~20 us for it - slower than
-        // the LayerNorm launch it replaces.  Big tiles keep LayerNorm + GEMM as two launches.
-        if (o.force_cfg < 0 && c->bm / (c->threads / 64) > o.lnalg_rows) return hipErrorNotSupported;
-    }
+    // LayerNorm as a prologue of the f32 tiles (pro_act 3 / 4: rounds 1-2, measured slower than LayerNorm + GEMM) is retired: callers
+    // fall back on NotSupported; the <= 64-row weight-streaming kernel (above) keeps its own LayerNorm prologue
+    if (p.pro_act == PRO_LN || p.pro_act == PRO_LNA) return hipErrorNotSupported;
     size_t lds = c->lds, lds_attr = 0;
-    if (p.pro_act == PRO_LN) {
-        if (p.taps != 1 || p.K > 1024 || !p.ln_g || !p.ln_b) return hipErrorInvalidValue;
-        // Measured (C2 / C3, profiles/r01_lnfuse_ab.txt): the prologue costs ~2 us of row statistics plus ~30 % of the
-        // K loop (12 VALU per 4 MFMAs, one more DMA piece) - a win only while a launch sits at its latency floor,
-        // i.e. for the two smallest tile configurations; everything larger runs LN + GEMM as two launches.
-        if (o.force_cfg < 0 && idx != 28 && idx != 22) return hipErrorNotSupported;
-        if (!c->fn[PRO_LN]) return hipErrorNotSupported;
-        const int ks = c->threads / 64 / ((c->bm / 32) * (c->bn / 32));     // one 32x32 tile per wave
-        lds = c->lds + (size_t)ks * 2 * 256 * sizeof(float) + (size_t)c->bm * 2 * sizeof(float);
-    }
-    if (p.pro_act == PRO_LNA) lds = c->lds + (size_t)c->bm * 2 * sizeof(float);     // + row statistics [BM][2]
-    // likewise (loader-wave tiles); the PRO_LNX instantiation also serves stat_out-only producers: the same size for both, so that
-    // the cached MaxDynamicSharedMemorySize attribute of the variant covers either use
+    // pair-fed LayerNorm on the loader-wave tiles: + row statistics [BM][2] behind the ring.  The PRO_LNX instantiation also serves
+    // stat_out-only producers: the same size for both, so that the cached MaxDynamicSharedMemorySize attribute covers either use
     if (fi == PRO_LNX && !c->x6_ks) lds = c->lds + (size_t)c->bm * 2 * sizeof(float);
     if (c->x3h >= 0) {
         if (!p.Wh || !p.wh_inv || (p.K & 7) || (p.ldw & 7) || (p.pro_act >= PRO_LN && p.pro_act != PRO_LNX)) return hipErrorInvalidValue;
@@ -2719,7 +1917,6 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     }
     if (opts) { opts->last_stat_nt = p.stat_nt; opts->last_stat_w = p.stat_w; }
     const int tiles = ((p.M + c->bm - 1) / c->bm) * ((p.N + c->bn - 1) / c->bn);
-    p.w_nt = (o.nt_weights && (p.M + c->bm - 1) / c->bm <= o.nt_row_tiles) ? 1 : 0;
     p.epi_t4 = o.epi_t4 ? 1 : 0;
     p.ldr_prio = o.ldr_prio;
     dim3 grid(tiles, 1, p.groups), block(c->threads);

@@ -35,7 +35,7 @@ __device__ __forceinline__ float sk_act(int act, float v, float slope) {
 }
 
 // RT: row tiles of 32; NW: waves (K shares); U: 32-wide K steps whose loads are issued together
-template <int RT, int NW, int U, bool NT>
+template <int RT, int NW, int U>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(GemmP p) {
     extern __shared__ float sk_red[];                       // [NW][RT][16][64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -74,13 +74,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(GemmP p) {
         for (int u = 0; u < U; ++u) {
             if (sb + u < NS) {
                 const int k = (sb + u) * 32;
-                if (NT) {     // weights are streamed once per launch: keep them out of the way of the activations in L2
+                // (non-temporal weight loads measured SLOWER here - C1 65.2 vs 56.8 ms, round 3 - and were retired in round 6)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w[u][j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp + k + 4 * j));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) w[u][j] = *reinterpret_cast<const f32x4*>(wp + k + 4 * j);
-                }
+                for (int j = 0; j < 4; ++j) w[u][j] = *reinterpret_cast<const f32x4*>(wp + k + 4 * j);
 #pragma unroll
                 for (int i = 0; i < RT; ++i)
 #pragma unroll
@@ -149,11 +145,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(GemmP p) {
 
 template <int RT, int NW, int U>
 hipError_t sk_launch(const GemmP& p, hipStream_t s) {
-    static std::atomic<unsigned long long> attr_done[2];      // per device and variant (dyn_lds_once; zero-initialised)
-    void (*fn)(GemmP) = p.w_nt ? gemm_skinny_f32_kernel<RT, NW, U, true> : gemm_skinny_f32_kernel<RT, NW, U, false>;
+    static std::atomic<unsigned long long> attr_done;         // per device (dyn_lds_once; zero-initialised)
+    void (*fn)(GemmP) = gemm_skinny_f32_kernel<RT, NW, U>;
     const size_t lds = NW > 1 ? (size_t)NW * RT * 16 * 64 * sizeof(float) : 0;
     if (lds > 48 * 1024) {
-        hipError_t e = dyn_lds_once(attr_done[p.w_nt ? 1 : 0], reinterpret_cast<const void*>(fn), lds);
+        hipError_t e = dyn_lds_once(attr_done, reinterpret_cast<const void*>(fn), lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(fn, dim3((p.N + 31) / 32, 1, p.groups), dim3(NW * 64), lds, s, p);
@@ -407,7 +403,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_tm_kernel(GemmP p) {
 template <int RT, int U, bool LNP, int NW = 8>
 hipError_t sk_tm_launch(const GemmP& p, hipStream_t s) {
     void (*fn)(GemmP) = gemm_skinny_tm_kernel<RT, NW, U, LNP>;
-    const size_t lds = ((size_t)NW * RT * 4 * 64 + (size_t)RT * 16 * 2) * sizeof(float);      // <= 33 KiB
+    const size_t lds = ((size_t)NW * RT * 4 * 64 + (size_t)RT * 16 * 2) * sizeof(float);      // <= 33 KiB with 8 waves; the sixteen-wave
+    if (lds > 48 * 1024) {                                                                    // form with RT = 3 (M in 33..48) is 48.4 KiB
+        static std::atomic<unsigned long long> done{0};                                       // (one per instantiation)
+        const hipError_t e = dyn_lds_once(done, reinterpret_cast<const void*>(fn), lds);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(fn, dim3(p.N / 16, 1, p.groups), dim3(NW * 64), lds, s, p);
     return hipGetLastError();
 }

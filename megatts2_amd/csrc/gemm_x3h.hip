@@ -865,18 +865,17 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
 
 X3hKernel x3h_kernel(int tile, int variant) {
     static void (*const kTable[kX3hTiles][6])(GemmP) = {
-        MT2_X3H_LDR(128, 128, 4, 2, 4, 3),          // X3H_LDR_128x128: 8 compute + 4 loader waves, 3 x 32 KiB
-        MT2_X3H_LDR(128, 128, 4, 2, 4, 4),          // X3H_LDR_128x128_S4: the same with a 4-deep ring (128 KiB)
+        MT2_X3H_LDR(128, 128, 4, 2, 4, 3),          // X3H_LDR_128x128: 8 compute + 4 loader waves, 3 x 32 KiB (+ PRO_LNX)
         // 64x64 per wave needs 2 x 64 accumulator registers: more than the 168 of a 12-wave workgroup (a 256x128 tile of 8 + 4 waves
-        // spills inside the K loop) - ONE compute wave per SIMD + 4 loaders = 8 waves, 211 registers, no spill
-        MT2_X3H_LDR_PLAIN(128, 128, 2, 2, 4, 3),    // X3H_LDR_128x128_W4
-        MT2_X3H_LDR_PLAIN(128, 128, 2, 2, 4, 4),    // X3H_LDR_128x128_W4_S4: 4-deep ring (128 KiB)
+        // spills inside the K loop) - ONE compute wave per SIMD + 4 loaders = 8 waves, 211 registers, no spill; 4-deep ring (128 KiB)
+        MT2_X3H_LDR_PLAIN(128, 128, 2, 2, 4, 4),    // X3H_LDR_128x128_W4_S4
         MT2_X3H_KS(32, 64, 1, 2, 4, 8, 2),          // X3H_KS_32x64_K4: the 84 tile (8 compute + 8 loader waves)
         MT2_X3H_KS(64, 64, 2, 2, 2, 8, 3),          // X3H_KS_64x64_K2: the 85 tile
         MT2_X3H_KS(32, 32, 1, 1, 8, 8, 2),          // X3H_KS_32x32_K8: the 86 tile
-        MT2_X3H_WIN(1, 256, 32, 8, 1, 3, 0),        // X3H_WIN_256x32: the 34 tile (8 waves, one 32x32 tile each, no loader waves)
         MT2_X3H_WIN(2, 256, 64, 8, 1, 3, 4),        // X3H_WIN_256x64: the 58 tile (8 compute + 4 loader waves)
         MT2_X3H_WIN(4, 128, 128, 4, 2, 2, 4),       // X3H_WIN_128x128: the 59 tile
+        // (measured and not kept, round 6: the 8 + 4 tile with a 4-deep ring - no gain; the 4 + 4 tile with a 3-deep ring - the
+        // 4-deep one is never slower; the 32-channel window convolution - 3..19 % slower than its x6 form)
     };
     if (tile < 0 || tile >= kX3hTiles || variant < 0 || variant >= 6) return nullptr;
     return kTable[tile][variant];

@@ -13,10 +13,8 @@
 
 namespace mt2 {
 
-// Tuning switches (split-K through the LayerNorm, LayerNorm as a GEMM prologue, vocoder stream count, ...) live in
-// the handle: mt2_model::opts (mt2_kernels.h EngineOpts), set through mt2_set_option.  LayerNorm as a GEMM prologue
-// is OFF by default: measured slower than LN + GEMM as two launches at every size (profiles/r01_lnfuse_ab.txt: C2
-// 90.8 vs 89.8 ms even when restricted to the latency-floor launches, 99.9 vs 89.4 ms when applied everywhere).
+// Tuning switches (split-K through the LayerNorm, vocoder stream count, tile thresholds, ...) live in the handle:
+// mt2_model::opts (mt2_kernels.h EngineOpts), set through mt2_set_option.
 
 // ---------------------------------------------------------------------------------------------------
 // planning helpers
@@ -129,10 +127,13 @@ static void linear(const Ctx& c, const float* x, int ldx, int M, const float* W,
 
 // y[M, N] = act(LN(x_rows)[M, K] @ W^T + b), x_rows[m] = x + (m * a_mul + shift0) * ldx.  Three forms, same result
 // up to fp32 round-off:
-//   algebraic (default, opts.lnalg; needs the folded operands Wl / s / c of EncLayerW): ONE launch, statistics in the
-//     GEMM's prologue while its first operand chunks are in flight, rstd * (acc - mean * s) + c in its epilogue;
-//   prologue  (opts.lnfuse): one launch, fragments normalised on the fly (slower K loop, two smallest tiles only);
+//   at most 64 rows: ONE launch of the weight-streaming kernel, which normalises its A rows itself (from the (mean, M2) pairs
+//     of the producer's epilogue where they exist);
+//   pair-fed (ln_pairs; needs the folded operands Wl / s / c of EncLayerW and the producer's pairs): ONE launch,
+//     rstd * (acc - mean * s) + c in the epilogue of an x6 / x3h tile, no pass over K;
 //   plain: launch_layernorm into `h_scratch` + a GEMM.
+// (LayerNorm as a prologue of the f32 tiles - options lnfuse / lnalg of rounds 1-2 - measured slower at every size and was
+// retired in round 6: profiles/r06_retired_kernel_forms_and_options.patch.)
 // What a layer hands to the next LayerNorm about the residual stream x (AR step forms below):
 //   S > 0    - a residual update not yet applied: x += bias + sum_g parts[g] (split-K through the LayerNorm);
 //   stat     - x is final and the GEMM that wrote it left its row statistics as (mean, M2) pairs per wave tile
@@ -173,26 +174,16 @@ static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, 
             if (e != hipErrorNotSupported) MT2_HIP(e);
         }
     }
-    if (st && st->stat && st->stat_nt > 0 && c.m.opts.ln_pairs && w.Wl && c.m.opts.force_cfg < 0 && M <= c.m.opts.ln_pairs_maxm) {
+    // (pairs of the tile-major kernel - 16 columns each, up to 64 per row - are not what the x6 / x3h tiles merge: launch_gemm would
+    // answer InvalidValue, not NotSupported)
+    if (st && st->stat && st->stat_nt > 0 && st->stat_w != 16 && st->stat_nt <= 32 && (st->stat_nt & 1) == 0 && c.m.opts.ln_pairs && w.Wl &&
+        c.m.opts.force_cfg < 0 && M <= c.m.opts.ln_pairs_maxm) {
         // the rows' statistics came with them (pairs from the producer GEMM's epilogue): algebraic LayerNorm with NO pass
         // over K - rstd * (x W'^T - mean * s) + c on the x6 tiles; a tile without that form answers NotSupported
         GemmP q = p;
         q.pro_act = 5; q.W = w.Wl; q.bias = w.c; q.ln_g = w.s; q.ln_stat = st->stat; q.ln_nt = st->stat_nt; q.ln_w = st->stat_w;
         attach_planes(c.m, q);
         const hipError_t e = launch_gemm(q, c.s, &c.m.opts);
-        if (e == hipSuccess) return;
-        if (e != hipErrorNotSupported) MT2_HIP(e);
-    }
-    if (c.m.opts.lnalg && w.Wl && K <= 1024) {
-        p.pro_act = 4; p.W = w.Wl; p.bias = w.c; p.ln_g = w.s;
-        const hipError_t e = launch_gemm(p, c.s, &c.m.opts);
-        if (e == hipSuccess) return;
-        if (e != hipErrorNotSupported) MT2_HIP(e);
-        p.W = w.W; p.bias = w.bias;
-    }
-    p.pro_act = 3; p.ln_g = w.g; p.ln_b = w.b;
-    if (c.m.opts.lnfuse && K <= 1024) {
-        const hipError_t e = launch_gemm(p, c.s, &c.m.opts);
         if (e == hipSuccess) return;
         if (e != hipErrorNotSupported) MT2_HIP(e);
     }
@@ -340,18 +331,15 @@ static void encoder_layer(const Ctx& c, const EncW& e, const EncLayerW& w, float
 // (launch_ln_reduce).  Deterministic, no extra launch, no inter-workgroup hand-off.
 static int choose_split(const Ctx& c, int M, int N, int K) {
     if (!c.m.opts.splitk) return 1;
-    // a split GEMM hands its reduction to a stand-alone LayerNorm launch, which the LayerNorm-prologue GEMM
-    // (ln_linear) otherwise removes: worth it only for the long K chains (PLM ff.3, K = 4096)
-    if (c.m.opts.lnfuse && K < 2048) return 1;
     // a handful of rows on the tile-major weight-streaming kernel (round 4): that kernel adds bias + residual itself and the
     // NEXT GEMM normalises its own input rows (LayerNorm prologue), so a split - whose reduction needs a LayerNorm launch of
     // its own - only pays where one column block's K range is too long for one workgroup: the PLM's ff.3 (K = 4096: 64
     // blocks x 256 KiB); there the K slices are 1024 wide (256 workgroups x 64 KiB) and the reduction rides on LN1 as before
     if (c.m.opts.skinny_tm && c.m.opts.skinny_rows > 0 && M <= c.m.opts.skinny_rows && M <= 64 && c.m.opts.force_cfg < 0 &&
         (N & 15) == 0 && (K & 63) == 0) {
-        if (K <= 1536 || c.m.opts.skinny_unsplit) return 1;
+        if (K <= 1536) return 1;
         int S = 1;
-        const int kmin = c.m.opts.skinny_kslice >= 256 ? c.m.opts.skinny_kslice : 1024;      // narrowest K slice
+        const int kmin = 1024;      // narrowest K slice (two slices of 2048: C1 +2.6 %, eight of 512: +0.4 %; un-split: +7.3 %)
         while (S < 16 && K % (S * 2) == 0 && K / (S * 2) >= kmin && (K / (S * 2)) % 64 == 0) S *= 2;
         return S;
     }
@@ -991,7 +979,7 @@ static void plm_run(const Ctx& c, const float* cond, int ld_c, const std::vector
                     const ArPrefix& pre = ArPrefix()) {
     mt2_model& m = c.m;
     const mt2_config& cfg = m.cfg;
-    const OptGuard pairs_guard(m.opts.ln_pairs, m.opts.ln_pairs_plm);
+    const OptGuard pairs_guard(m.opts.ln_pairs, 0);      // the hand-off pays in the ADM only (profiles/r05_opts_ab.txt)
     const EncW& e = m.plm_enc;
     const int d = e.d, Dc = cfg.plm_tc_dim, De = cfg.plm_vq_dim, NB = cfg.plm_bins;
     ArOrder ord = ar_order(lens, B);

@@ -46,7 +46,6 @@ struct GemmP {
     const int* rowbase; int a_mul; int shift0; int taps; int dil; int Cin;
     const float* W; long long strideW; int ldw;
     unsigned long long* dbg = nullptr;   // MT2_PHASE_TIMING builds only: per-phase cycle sums of one wave (tools/x6_phase_timing.py)
-    int w_nt = 0;               // weight loads with the non-temporal cache policy (set by launch_gemm: weights streamed ~once per launch)
     int epi_t4 = 1;             // 16-byte-store epilogue where the layout allows it (set by launch_gemm from EngineOpts::epi_t4)
     int sk_nw = 8;              // gemm_skinny_tm_kernel: waves per workgroup that split K (8; 16 = option skinny_nw, set by launch_gemm)
     int ldr_prio = 0;           // s_setprio of the loader waves of the loader-wave kernels (set by launch_gemm from EngineOpts::ldr_prio)
@@ -95,32 +94,24 @@ struct EngineOpts {
     int force_cfg = -1;                                    // >= 0: tile configuration index for every GEMM launch
     int t_ks4 = 256, t_ks2 = 640, t32 = 256, t32x32 = 256; // tile-choice thresholds in tiles (tools/gemm_sweep.py)
     bool splitk = true;          // split-K through the LayerNorm in the AR layers
-    bool lnfuse = false;         // LayerNorm as a GEMM prologue in the AR layers (measured slower, profiles/r01_lnfuse_ab.txt)
-    int lnalg_rows = 4;          // ... for tile configurations whose waves own at most this many rows each (see launch_gemm)
-    bool lnalg = false;          // ALGEBRAIC LayerNorm in the AR layers: LN1 -> QKV and LN2 -> ff.0 are ONE launch each,
-                                 // statistics in the GEMM's prologue, rstd * (acc - mean * s) + c in its epilogue
     int voc_streams = 3;         // resblock chains of a vocoder stage in flight (1 = serial)
     bool win_conv = true;        // window-convolution kernel for narrow square convs (Cin = Cout in {32, 64, 128})
     bool x6_conv = true;         // ... on the bf16 matrix pipe, f32-equivalent 3-way split (6 products), where W3 planes exist
-    bool x6_gemm = true;         // the big-tile implicit GEMMs likewise (gemm_x6_dma_kernel)
+    bool x6_gemm = true;         // the implicit GEMMs likewise (loader-wave and K-split tiles)
     bool x6_splitk = true;       // K slices (through the next LayerNorm) to give the N = d AR GEMMs enough x6 tiles
-    int x3h = 1;                 // f32-equivalent THREE-product form on the fp16 pipe (gemm_x3h.hip) wherever an x6 tile has one and the
-                                 // weights come with fp16 planes (GemmP::Wh): 0 off (everything stays x6)
+    int x3h = 7;                 // f32-equivalent THREE-product form on the fp16 pipe (gemm_x3h.hip) wherever an x6 tile has one and the
+                                 // weights come with fp16 planes (GemmP::Wh); bits: 1 the 128x128 loader tiles, 2 the K-split tiles of the
+                                 // AR steps, 4 the window convolutions; 0: everything stays x6
     int* x3h_flag = nullptr;     // device word of the range guard (GemmP::x3h_flag); the model handle owns one
+    int t_x3h_128 = 72;          // x3h: from this many 128x128 tiles on the loader tile instead of the K-split tiles (t_x6_128's role)
     int t_x3h_w4 = 400, x3h_w4_mink = 1536;   // x3h: from this many 128x128 tiles and this K on the 64x64-per-wave form (tile 94) instead of 91
-    bool x6_loaders = true;      // x6 GEMM tiles with loader waves (gemm_x6_ldr_kernel) instead of self-refilling compute waves
-    bool nt_weights = false;     // non-temporal weight loads when a launch has at most nt_row_tiles row tiles (AR steps)
-    int nt_row_tiles = 2;
     int t_x6_256 = 160, t_x6_128 = 72;   // ... from this many 256x128 / 128x128 tiles on (profiles/r02_gemm_sweep_x6.txt)
     int x6_ks = 4;               // x6 arithmetic + eight loader waves for the AR steps' K-split tiles (gemm_x6_ks_kernel): 0 off;
                                  // 1, 3: the 32x64 k4 and 64x64 k2/k4 tiles (84, 85); 2, 4: + the 32x32 k8 tile (86); 5: the
-                                 // 64x64 tile only (four-loader forms 79 / 80 / 82: force only).  Default 4: isolated launches +10..50 %
+                                 // 64x64 tile only.  Default 4: isolated launches +10..50 %
                                  // (profiles/r03_gemm_sweep_x6k.txt), C3 step -1.6 % (profiles/r03_ab_interleaved_v1.txt)
-    int t_x6_ks_over128 = 0;     // with x6_ks: up to this many 64x64 tiles the K-split x6 tile replaces the 128x128 loader tile
     bool epi_t4 = true;          // DPP-transposed 16-byte-store epilogue for wave tiles without epilogue prefetch
     int ldr_prio = 3;            // issue priority (s_setprio 0..3) of the loader waves (gemm_x6_ldr / gemm_x6_ks / conv_win_x6 kernels)
-    bool x6_mp256 = false;       // MP form (config 68) wherever the 256x128 loader tile (51) would run
-    int x6_mp = 0;               // 1: MP form (gemm_x6_ldr_kernel<..., MP>) of the 128x128 and small loader tiles, 2: of 256x128 too
     int skinny_rows = 64;        // linear layers with at most this many rows (<= 64) run on the weight-streaming kernel of
     int attn_lds_min = 640;      // attention: from this many queries per sequence on the LDS-tiled kernel (AttnP::lds_min_qlen; 0 never)
     int attn_x6_min = 192;       // attention on the bf16 pipe (f32-equivalent, AttnP::x6_min_qlen) from this many queries on; 0: never
@@ -129,33 +120,23 @@ struct EngineOpts {
     int attn_ds = 1;             // short sequences on the AR heads: head dim split over the waves as well (AttnP::ds_short)
     bool skinny_tm = true;       // ... on the tile-major weight copy where one exists (gemm_skinny_tm_kernel; LayerNorm prologue included)
     int skinny_groups = 1;       // ... only for launches with at least this many GemmP groups (split-K slabs)
-    int skinny_kslice = 1024;    // ... the narrowest K slice of such a split (PLM ff.3, K = 4096: four slices of 1024)
-    int skinny_unsplit = 0;      // launches of at most skinny_rows rows: no K split even for the long chains (PLM ff.3, K = 4096): the
-                                 // kernel adds bias + residual itself and the next LayerNorm rides in the consuming GEMM's prologue.
-                                 // MEASURED NEGATIVE: C1 +7.3 % (64 workgroups stream 256 KiB each; the four-slice form keeps 256 busy)
     int skinny_pairs = 1;        // launches of at most skinny_rows rows: the residual GEMM's epilogue leaves (mean, M2) pairs per 16-column block
                                  // and the LayerNorm prologue of the consuming launch merges them instead of re-reading all M x K rows
     int skinny_nw = 16;          // waves of the tile-major weight-streaming kernel that split K (8; 16: four per SIMD - twelve for K = 768 -
                                  // at M <= 32: C1 -1.8 %, profiles/r05_opts_ab.txt)
-    int skinny_nt = 0;           // gemm_skinny.hip (0: off); skinny_nt: non-temporal weight loads (measured: C1 65.2 ms with, 56.8 without)
-    int x6_small_cfg = 0;        // 63..64: small loader-wave x6 tile for launches with at most t_x6_small_max 128x128 tiles and
-    int t_x6_small_max = 200, t_x6_small_min = 48;   // at least t_x6_small_min small tiles (0: off)
     bool markers = false;        // a named no-op kernel at every stage boundary: lets tools/pmc_stage_summary.py attribute
                                  // the rocprofv3 --pmc rows of one step to stages (measurement only)
     bool trace_on = false;       // HIP events around every GEMM launch (measurement only)
     std::vector<TraceRec> trace;
     const char* last_cfg = "";   // name of the tile configuration the last launch used
     int last_stat_nt = 0, last_stat_w = 0;   // GemmP::stat_out of the last launch: pairs per row / columns per pair (0: none written)
-    int ln_pairs = 0;            // AR layers with more than skinny_rows rows: the residual GEMMs (out-projection, ff.3) write row
-                                 // statistics as (mean, M2) pairs per wave tile in their epilogue and LN1 -> QKV / LN2 -> ff.0 run
-                                 // as ONE pair-fed algebraic-LayerNorm GEMM - no stand-alone LayerNorm launch (1: where the
-                                 // producer is not K-split anyway; 2: also un-split the producers with K <= ln_pairs_maxk).
-                                 // Parity-green and MEASURED NEGATIVE, hence 0 (profiles/r05_opts_ab.txt, interleaved: C3 +0.65 %
-                                 // with 1, +0.9 % with 2; C5 +2.0 %; C2 -1.0 %): the LayerNorm launches it removes ran in the
-                                 // shadow of the other AR chain, the epilogue work it adds does not
-    int ln_pairs_adm = 2, ln_pairs_plm = -1;       // per-stage override of ln_pairs (-1: none).  The ADM alone (d = 768: both residual GEMMs
-                                 // have K <= 1024, nothing rides on a K-split reduce any more) is where the hand-off pays at B = 32:
-                                 // interleaved C3 -0.43 %, C2 -1.3 %, C5 +0.1 % with the row cap below (profiles/r05_opts_ab.txt)
+    int ln_pairs = 0;            // (the value in force for the stage that is running: ln_pairs_adm inside the ADM, 0 elsewhere)
+    int ln_pairs_adm = 2;        // ADM layers with more than skinny_rows rows: the residual GEMMs (out-projection, ff.3) write row statistics
+                                 // as (mean, M2) pairs per wave tile in their epilogue and LN1 -> QKV / LN2 -> ff.0 run as ONE pair-fed
+                                 // algebraic-LayerNorm GEMM - no stand-alone LayerNorm launch (1: where the producer is not K-split anyway;
+                                 // 2: also un-split the producers with K <= ln_pairs_maxk).  The ADM alone (d = 768: both residual GEMMs
+                                 // have K <= 1024) is where the hand-off pays at B = 32: interleaved C3 -0.43 %, C2 -1.3 %; in the PLM and
+                                 // globally it measured +0.65 .. +2.0 % and was retired (profiles/r05_opts_ab.txt)
     int ln_pairs_maxk = 1024;    // ... ln_pairs = 2: the longest K chain that is taken out of the K split
     int ln_pairs_maxm = 1280;    // ... only for launches of at most this many rows: beyond, the consumers run on the 256x128 tile
                                  // (no pair-fed form) and a LayerNorm launch is no longer a latency item (C5: 5342 vs 5210 ms without a cap,
@@ -164,8 +145,8 @@ struct EngineOpts {
 hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
 // gemm_x3h.hip: the kernels of the fp16-pipe form by tile id and variant (prologue none / relu / leaky relu / - / - / pair statistics);
 // nullptr: no such variant
-enum X3hTile : int { X3H_LDR_128x128 = 0, X3H_LDR_128x128_S4, X3H_LDR_128x128_W4, X3H_LDR_128x128_W4_S4, X3H_KS_32x64_K4, X3H_KS_64x64_K2,
-                     X3H_KS_32x32_K8, X3H_WIN_256x32, X3H_WIN_256x64, X3H_WIN_128x128, kX3hTiles };
+enum X3hTile : int { X3H_LDR_128x128 = 0, X3H_LDR_128x128_W4_S4, X3H_KS_32x64_K4, X3H_KS_64x64_K2, X3H_KS_32x32_K8, X3H_WIN_256x64,
+                     X3H_WIN_128x128, kX3hTiles };
 typedef void (*X3hKernel)(GemmP);
 X3hKernel x3h_kernel(int tile, int variant);
 // gemm_skinny.hip: weight-streaming linear layer for M <= 64 rows (taps = 1, no rowbase, K a multiple of 32)

@@ -188,7 +188,8 @@ def synthesize_sharded(tts, utterances, vocoder: bool = False):
     if not utterances:
         return []
     costs = [utterance_cost(u.phone.size, u.prompt_mel.shape[0],
-                            int(u.durations.sum()) if getattr(u, "durations", None) is not None else 6 * u.phone.size)
+                            int(u.durations.sum()) if getattr(u, "durations", None) is not None else 6 * u.phone.size,
+                            vocoder=vocoder, prompt_vqpe=False)        # what this call will actually run on each utterance
              for u in utterances]
     shards = shard_utterances(costs, world)
     mine = shards[rank]

@@ -261,7 +261,7 @@ class NativeModel:
         check_range = False leaves the call asynchronous and the check (`range_guard()`) to the caller."""
         _check(call())
         if check_range and self.range_guard():
-            prev = self.get_option("x3h")
+            prev = self.get_option("x3h")        # (a bit mask of the fp16-pipe forms in use)
             self.set_option("x3h", 0)
             try:
                 _check(call())
@@ -780,26 +780,6 @@ def op_gemm_x6_ln(X, W, bias=None, R=None, M=None, a_mul=1, shift0=0, epi_act=AC
                                      C.byref(nt), C.byref(pw), _ptr(ln_stat), ln_nt, int(ln_w), _ptr(ln_s), C.c_float(eps)))
     if want_stats:
         return out, stat.view(-1)[:M * nt.value * 2].reshape(M, nt.value, 2).clone(), pw.value      # dense [M][nt][2]
-    return out
-
-
-def op_ln_gemm(X, gamma, beta, W, bias=None, M=None, a_mul=1, shift0=0, eps=1e-5, epi_act=ACT_NONE, force_cfg=-1,
-               algebraic=False):
-    """LN(X) @ W^T + b in one launch.  algebraic=True folds gamma / beta into the operands on the host (float64 sums,
-    as the model loader does) and runs the statistics-in-prologue / correction-in-epilogue form of the kernel."""
-    import torch
-    lib = load_library()
-    K, N = X.shape[1], W.shape[0]
-    M = M or X.shape[0]
-    out = torch.empty(M, N, device=X.device, dtype=torch.float32)
-    if algebraic:
-        Wd, gd, bd = W.double().cpu(), gamma.double().cpu(), beta.double().cpu()
-        Wl = (W.cpu() * gamma.cpu()[None, :]).to(torch.float32)
-        s = Wl.double().sum(1).to(torch.float32)
-        c = (Wd @ bd + (bias.double().cpu() if bias is not None else 0.0)).to(torch.float32)
-        W, gamma, bias = Wl.to(X.device), s.to(X.device), c.to(X.device)
-    _check(lib.mt2_op_ln_gemm(_stream(), _ptr(X), K, X.shape[0], a_mul, shift0, _ptr(gamma), _ptr(beta), C.c_float(eps),
-                              _ptr(W), _ptr(bias), _ptr(out), N, M, N, K, epi_act, force_cfg, 1 if algebraic else 0))
     return out
 
 

@@ -265,13 +265,17 @@ def load_lightning_state_dict(ckpt_path: str, prefix: str) -> Dict[str, np.ndarr
         except pickle.UnpicklingError as first:      # what the weights_only unpickler raises for a class it does not know
             # Real Lightning checkpoints pickle a few harmless value types beside the tensors (hyper_parameters, callback
             # and scheduler states): retry with exactly those allow-listed - still no arbitrary code - before refusing
+            blocked = first
             try:
+                if not hasattr(torch.serialization, "safe_globals"):      # torch < 2.5: no scoped allow-list - refuse as before
+                    raise pickle.UnpicklingError(str(first))
                 with torch.serialization.safe_globals(_benign_checkpoint_types()):
                     raw = torch.load(ckpt_path, map_location="cpu", weights_only=True)
-            except pickle.UnpicklingError:
+            except pickle.UnpicklingError as second:
+                blocked = second                                         # the class that still blocks AFTER the allow-list
                 raise RuntimeError(
                     f"{ckpt_path}: the checkpoint pickles objects beyond tensors, plain containers and the allow-listed value "
-                    f"types ({str(first)[:160]}...); re-save its weights alone - torch.save({{'state_dict': "
+                    f"types ({str(blocked)[:160]}...); re-save its weights alone - torch.save({{'state_dict': "
                     "torch.load(path, weights_only=False)['state_dict']}, new_path) in an environment you trust - or set "
                     "MEGATTS2_UNSAFE_PICKLE=1 if you trust the file") from None
     raw = raw["state_dict"]

@@ -32,14 +32,16 @@ def test_tile_configuration_table_matches_the_indices_the_chooser_uses():
     n = lib.mt2_gemm_config_count()
     names = [lib.mt2_gemm_config_name(i).decode() for i in range(n)]
     assert len(set(names)) == n, "duplicate tile configuration names"
-    want = {12: "dma64x64_2x2_s3", 15: "dma128x32_4x1_s4", 16: "dma256x128_4x2_s3", 17: "dma128x128_4x2_s4",
+    want = {3: "64x64_2x2", 12: "dma64x64_2x2_s3", 15: "dma128x32_4x1_s4", 16: "dma256x128_4x2_s3", 17: "dma128x128_4x2_s4",
             18: "dma64x64_2x2_k2_s2", 20: "dma64x64_2x2_k4_s2", 22: "dma32x64_1x2_k4_s2", 23: "dma256x64_4x2_s3",
             28: "dma32x32_1x1_k8_s2", 30: "win256x32_8x1_s3", 31: "win256x64_8x1_s3", 32: "win128x128_4x2_s3",
-            34: "x6win256x32_8x1_s3", 35: "x6win256x64_8x1_s3", 36: "x6win128x128_4x2_s2", 37: "x6dma256x128_4x2_s2",
-            39: "x6dma128x128_4x2_s2", 49: "retired:x6areg64x128_2x2_s3", 51: "x6ldr256x128_4x2+4_s2",
-            55: "x6ldr128x128_4x2+4_s3", 58: "x6winl256x64_8x1+4_s3", 59: "x6winl128x128_4x2+4_s2", 68: "x6ldm256x128_4x2+4_s2",
-            72: "x6ldm128x128_2x2+4_s3", 75: "x6ldf128x128_4x2+4_s3", 84: "x6ks32x64_1x2_k4+8_s2", 85: "x6ks64x64_2x2_k2+8_s3",
-            86: "x6ks32x32_1x1_k8+8_s2", 87: "skinny32_f32", 88: "skinny64_f32", 89: "skinnytm32_f32", 90: "skinnytm64_f32"}
+            34: "x6win256x32_8x1_s3", 35: "retired:x6win256x64_8x1_s3", 37: "retired:x6dma256x128_4x2_s2",
+            49: "retired:x6areg64x128_2x2_s3", 51: "x6ldr256x128_4x2+4_s2", 55: "x6ldr128x128_4x2+4_s3", 58: "x6winl256x64_8x1+4_s3",
+            59: "x6winl128x128_4x2+4_s2", 68: "retired:x6ldm256x128_4x2+4_s2", 75: "retired:x6ldf128x128_4x2+4_s3",
+            84: "x6ks32x64_1x2_k4+8_s2", 85: "x6ks64x64_2x2_k2+8_s3", 86: "x6ks32x32_1x1_k8+8_s2", 87: "skinny32_f32",
+            88: "skinny64_f32", 89: "skinnytm32_f32", 90: "skinnytm64_f32", 91: "x3hldr128x128_4x2+4_s3",
+            92: "retired:x3hldr128x128_4x2+4_s4", 94: "x3hldr128x128_2x2+4_s4", 95: "x3hks32x64_1x2_k4+8_s2",
+            96: "x3hks64x64_2x2_k2+8_s3", 97: "x3hks32x32_1x1_k8+8_s2", 99: "x3hwin256x64_8x1+4_s3", 100: "x3hwin128x128_4x2+4_s2"}
     for i, name in want.items():
         assert names[i] == name, (i, names[i], name)
 

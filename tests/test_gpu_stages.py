@@ -245,7 +245,9 @@ def test_vq_quantize_near_ties_against_the_live_reference(kind):
     the numpy port, port vs reference.  Exact hits and random rows: 0 flips against the reference.  Engineered near-ties: the
     argmax lies inside the f32 round-off of the expanded distance (the reference itself disagrees with float64 arithmetic and
     with the numpy port there), so a flip is legitimate only if the two picks' float64 scores differ by less than 16 f32 roundings
-    of the distance's terms - and the HIP kernel may not flip much more often than the port does."""
+    of the distance's terms (asserted for EVERY flip against the reference, not only for those beyond the port's count) - and the
+    HIP kernel may not sit further from exact arithmetic than the reference itself does (flips against the float64 argmax: the
+    reference 8 / 163, the HIP kernel 14 / 168 on the tiny / production rows when the fixture was made)."""
     import hashlib
     tts = model(kind)
     z = load_golden(f"{kind}_vq_near_ties.npz")
@@ -265,7 +267,8 @@ def test_vq_quantize_near_ties_against_the_live_reference(kind):
     assert np.array_equal(got[:512], ref[:512]), "exact hits: the row itself (or an earlier identical row) is returned"
     assert np.array_equal(got[1024:], ref[1024:]), "flip on a row that is not an engineered near-tie"
     assert O.vq_flips_within_roundoff(E, x[hip_ref], got[hip_ref], ref[hip_ref]).all()
-    assert hip_ref.size <= 2 * port_ref.size + 8
+    b64 = z["best64"].astype(np.int64)
+    assert int((got != b64).sum()) <= 1.25 * int((ref != b64).sum()) + 8
 
 
 def test_tiny_end_to_end(tiny_batch):

@@ -311,6 +311,14 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         tcyc0 = __builtin_readcyclecounter();
         if (lane == 0) p.dbg[9] = treal0 - t_entry;
     }
+#ifdef MT2_PHASE_TIMING
+    // measurement build (tools/x3h_phase_timing.py): per-phase s_memtime sums of one wave.  0 LDS wait of k-block 1 (behind the first
+    // fragment's products), 1 barrier, 2 -, 3 first fragment fetch, 4 second fetch + first split, 5 products of the chunk
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = probe ? __builtin_readcyclecounter() : 0ull;
+#define MT2_T(i_) do { if (probe) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i_] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define MT2_T(i_) do { } while (0)
+#endif
     for (int c = 0; c < nk; ++c) {
         const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
 #if defined(MT2_X3H_ABLATE) && MT2_X3H_ABLATE == 1                                   // ablation: ingest only - the compute waves just keep the
@@ -320,23 +328,29 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
             continue;
         }
 #endif
+        MT2_T(5);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        MT2_T(1);
         fetch(0, sa, sb);
         __builtin_amdgcn_sched_barrier(0);
         wait_block(0);
         __builtin_amdgcn_sched_barrier(0);
+        MT2_T(3);
         fetch(1, sa, sb);
         split2_f16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], amax);
         __builtin_amdgcn_sched_barrier(0);
+        MT2_T(4);
 #pragma unroll
         for (int s = 0; s < F; ++s) {
             const int b = s / TM, i = s % TM;
             if (s + 1 < F) {
                 const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
                 if (b2 != b) {
+                    MT2_T(5);
                     wait_block(b2);
                     __builtin_amdgcn_sched_barrier(0);
+                    MT2_T(0);
                 } else {
                     tie(b2, i2);
                 }
@@ -352,6 +366,12 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         st = st + 1 == NST ? 0 : st + 1;
     }
     unsigned long long t_loop_end = 0;
+    MT2_T(5);
+#ifdef MT2_PHASE_TIMING
+    if (probe && lane == 0)
+        for (int i = 0; i < 6; ++i) p.dbg[i] = tacc[i];
+#endif
+#undef MT2_T
     if (probe) {
         t_loop_end = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {

@@ -80,11 +80,16 @@ static void attach_planes(const mt2_model& m, GemmP& p) {
         // the fp16 planes carry one scale per weight row: usable when this launch walks the buffer with the rows it was split by
         // (K slices of a row - split-K - share the row's scale)
         const int ldw = p.ldw ? p.ldw : (p.taps > 0 ? p.taps : 1) * p.Cin;
-        if (it->ph && ldw == (int)it->row_len && p.strideW % (long long)it->row_len == 0) {
+        const long long rl = (long long)it->row_len, groups = p.groups > 0 ? p.groups : 1;
+        const long long col0 = (long long)((size_t)(p.W - it->base) % it->row_len);
+        // groups either step through whole matrices (the parallel branches of a conv stack: strideW a multiple of the row length)
+        // or through K slices of the SAME rows (split-K: every slice inside one row, shared scales)
+        const bool whole = p.strideW % rl == 0, slices = !whole && col0 + p.strideW * groups <= rl;
+        if (it->ph && ldw == (int)it->row_len && (whole || slices)) {
             p.Wh = it->ph + (p.W - it->base);
             p.wh_plane = (long long)it->n;
             p.wh_inv = it->inv + (size_t)(p.W - it->base) / it->row_len;
-            p.wh_inv_stride = p.strideW / (long long)it->row_len;
+            p.wh_inv_stride = whole ? p.strideW / rl : 0;
         }
     }
 }

@@ -217,6 +217,11 @@ ablate)
     [ -d variants/$v ] && cp tools/*.py variants/$v/tools/ && (cd variants/$v && timeout 300 python tools/x6_ablate.py $v 2>&1 | grep -v amdgpu.ids) >> gpurun_out/x6_ablate.txt
   done
   echo "ablate rc=$?"; cat gpurun_out/x6_ablate.txt ;;
+phase3h)
+  # per-phase cycle sums of one compute wave of the x3h loader tile (variant h_phase: tools/build_variant.sh h_phase "-DMT2_PHASE_TIMING")
+  cp tools/*.py variants/h_phase/tools/
+  (cd variants/h_phase && timeout 300 python tools/x3h_phase_timing.py) > gpurun_out/x3h_phase_timing.txt 2>&1
+  echo "phase3h rc=$?"; grep -v amdgpu.ids gpurun_out/x3h_phase_timing.txt ;;
 ablate3h)
   # the same for the x3h tile (tools/x3h_ablate.py; variants h_abl1..h_abl4)
   : > gpurun_out/x3h_ablate.txt

@@ -1515,6 +1515,11 @@ static void x3h_variant_exists(GemmP) {}
       { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr,                               \
         (HAS_LNX_) ? x3h_variant_exists : nullptr }, 0, true, 0, (HAS_LNX_) ? (BN_) / (WN_) : 0, ID_ }
 
+#define MT2_X3HL2(ID_, BM_, BN_, WM_, WN_, NL_, NST_, HAS_LNX_)                                                    \
+    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(2 * BN_ / 16) * 1024),       \
+      "x3hldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_ "c2",                                            \
+      { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr,                               \
+        (HAS_LNX_) ? x3h_variant_exists : nullptr }, 0, true, 0, (HAS_LNX_) ? (BN_) / (WN_) : 0, ID_ }
 #define MT2_X3HK(ID_, BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                           \
     { BM_, BN_, (WM_* WN_ * KS_ + NL_) * 64, (size_t)KS_ * NST_ * ((size_t)BM_ * BK * 4 + (size_t)(2 * BN_ / 16) * 1024), \
       "x3hks" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "+" #NL_ "_s" #NST_,                                        \
@@ -1652,6 +1657,9 @@ static const TileCfg kCfgs[] = {
     MT2_RETIRED("x3hwin256x32_8x1+0_s3"),                   // 98: the 34 tile
     MT2_X3HW(X3H_WIN_256x64, 2, 256, 64, 8, 1, 3, 4),             // 99: the 58 tile
     MT2_X3HW(X3H_WIN_128x128, 4, 128, 128, 4, 2, 2, 4),           // 100: the 59 tile
+    // ... the loader tiles with ONE barrier per 64-deep super-chunk (4 stages = 2 super-stages, 128 KiB)
+    MT2_X3HL2(X3H_LDR_128x128_C2, 128, 128, 4, 2, 4, 4, true),    // 101: the 91 tile (+ PRO_LNX)
+    MT2_X3HL2(X3H_LDR_128x128_W4_C2, 128, 128, 2, 2, 4, 4, false), // 102: the 94 tile
 };
 constexpr int kSkinny32 = 87, kSkinny64 = 88, kSkinnyTm32 = 89, kSkinnyTm64 = 90;
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);

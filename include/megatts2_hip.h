@@ -254,7 +254,8 @@ int mt2_op_gemm(void* stream, const float* X, int ldx, int Rx, const int32_t* ro
 int mt2_op_gemm_x6(void* stream, const float* X, int ldx, int Rx, int shift0, int taps, int dil, int Cin, const float* W,
                    const void* W3, const float* bias, const float* R, int ldr, const int32_t* valid, float* C, int ldc,
                    int M, int N, int pro_act, float pro_slope, int epi_act, int force_cfg);
-/* The same launch with the weights ALSO as two fp16 planes Wh [2][N][K] (hi, lo * 2^11) of the row-scaled matrix and the inverse
+/* The same launch with the weights ALSO as two fp16 planes (hi, lo * 2^11) of the row-scaled matrix - Wh: chunk-interleaved,
+ * [N][ceil32(K) / 32] blocks of 128 bytes = 32 hi then 32 lo values of one row and 32-k chunk, 128-byte aligned - and the inverse
  * power-of-two row scales wh_inv [N] (mt2_x3h_split): the Linear / Conv1d of modules/transformer.py:35-57,88-102 and
  * modules/convnet.py:23-31 on the fp16 matrix pipe in the f32-equivalent THREE-product form (csrc/gemm_x3h.hip; force_cfg 91..94
  * or -1).  range_flag (device int32, may be NULL): |= 1 when an activation with |a| >= 65504 was converted (fp16 range). */
@@ -262,8 +263,9 @@ int mt2_op_gemm_x3h(void* stream, const float* X, int ldx, int Rx, int shift0, i
                     const void* W3, const void* Wh, const float* wh_inv, const float* bias, const float* R, int ldr,
                     const int32_t* valid, float* C, int ldc, int M, int N, int pro_act, float pro_slope, int epi_act, int force_cfg,
                     int32_t* range_flag);
-/* host helper: the fp16-pipe operand format of a row-major f32 matrix W [rows][row_len] (host memory): planes [2][rows * row_len]
- * uint16 (fp16 bit patterns), inv [rows] */
+/* host helper: the fp16-pipe operand format of a row-major f32 matrix W [rows][row_len] (host memory): planes
+ * [rows][2 * ceil32(row_len)] uint16 (fp16 bit patterns; per row and 32-k chunk 32 hi values, then 32 lo values; K zero-padded to a
+ * multiple of 32), inv [rows] */
 int mt2_x3h_split(const float* W, long long rows, long long row_len, uint16_t* planes, float* inv);
 /* Range guard of the fp16-pipe GEMMs inside a model handle (option "x3h", default 1): waits for the handle's last call, then
  * *tripped = 1 (and the guard is re-armed) when that call converted an activation outside the fp16 range - its outputs are then

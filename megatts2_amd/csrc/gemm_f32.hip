@@ -1904,7 +1904,9 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     if (fi == PRO_LNX && !c->x6_ks) lds = c->lds + (size_t)c->bm * 2 * sizeof(float);
     if (c->x3h >= 0) {
         if (!p.Wh || !p.wh_inv || (p.K & 7) || (p.ldw & 7) || (p.pro_act >= PRO_LN && p.pro_act != PRO_LNX)) return hipErrorInvalidValue;
-        if (p.wh_plane == 0) p.wh_plane = (long long)p.N * p.ldw;
+        if (p.wh_ldb == 0) p.wh_ldb = 4ll * ((p.ldw + 31) / 32 * 32);      // chunk-interleaved rows, K padded to whole chunks
+        if (p.groups > 1 && p.wh_gstride == 0) p.wh_gstride = p.strideW * 4;   // (exact for whole-chunk rows; attach_planes sets it otherwise)
+        if ((((unsigned long long)p.Wh) & 127) || (p.wh_ldb & 127) || (p.wh_gstride & 127)) return hipErrorInvalidValue;
         p.x3h_flag = o.x3h_flag;
     } else
     if (c->x6 && (!p.W3 || (p.K & 7) || (p.ldw & 7) || (p.pro_act >= PRO_LN && p.pro_act != PRO_LNX))) return hipErrorInvalidValue;

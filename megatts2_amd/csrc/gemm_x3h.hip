@@ -75,7 +75,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int PA = BM / 8;                            // f32 A pieces per chunk: 8 rows x 128 B
-    constexpr int PB = 2 * BN / 16;                       // fp16 plane pieces per chunk: 16 rows x 64 B
+    constexpr int PB = BN / 8;                            // weight pieces per chunk: 8 rows x 128 B ([hi | lo] blocks, x3h_planes.h)
     constexpr int A_IT = (PA + NL - 1) / NL, B_IT = (PB + NL - 1) / NL;   // per loader wave
     constexpr int L = A_IT + B_IT;
     constexpr int STAGE_A = BM * BK * 4, STAGE_B = PB * 1024, STAGE = STAGE_A + STAGE_B;   // bytes
@@ -105,12 +105,11 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         loader_priority(p.ldr_prio);
         const int lw = wave_all - NW;
         const float* __restrict__ X = p.X + (long long)g * p.strideX;
-        const unsigned short* __restrict__ Wh = reinterpret_cast<const unsigned short*>(p.Wh) + (long long)g * p.strideW;
+        const char* __restrict__ Wh = reinterpret_cast<const char*>(p.Wh) + (long long)g * p.wh_gstride;
         const long long zoff_x = (const float*)g_zero16 - X;
-        const long long zoff_w = (const unsigned short*)g_zero16 - Wh;
-        const long long plane = p.wh_plane;
+        const long long zoff_w = (const char*)g_zero16 - Wh;
         const int lrow = lane >> 3;
-        const int ldx = p.ldx, Rx = p.Rx, Cin = p.Cin, dil = p.dil, ldw = p.ldw;
+        const int ldx = p.ldx, Rx = p.Rx, Cin = p.Cin, dil = p.dil;
         const bool multi_tap = p.taps > 1;
         int abase[A_IT], akl[A_IT];
 #pragma unroll
@@ -122,16 +121,15 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
             abase[j] = b;
             akl[j] = ((lane & 7) ^ ((pc * 4 + (lane >> 4)) & 7)) * 4;       // k offset of this lane's 16-byte slot
         }
-        long long wofs[B_IT];
-        int wk[B_IT];
+        // B piece pc: weight rows pc*8 .. +7 of the tile, one 128-byte [hi | lo] block per row and chunk; the lane's 16-byte slot is
+        // swizzled like an A row's (logical slot = physical ^ ((row >> 1) & 7); logical slots 0-3: hi of k = 8 s .., 4-7: lo)
+        long long wofs[B_IT];        // BYTE offset of the lane's slot in chunk 0, or < 0 when the row is beyond N
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
-            const int pc = j * NL + lw;                      // B piece = plane * (BN / 16) + row block
-            const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
-            const int nl = rb * 16 + (lane >> 2);
-            const int n = n0 + nl;
-            wk[j] = ((lane & 3) ^ ((nl >> 2) & 3)) * 8;
-            wofs[j] = n < p.N ? pl * plane + (long long)n * ldw : -1;
+            const int pc = j * NL + lw;
+            const int nl = pc * 8 + lrow, n = n0 + nl;
+            const int sl = (lane & 7) ^ ((nl >> 1) & 7);
+            wofs[j] = n < p.N ? (long long)n * p.wh_ldb + sl * 16 : -1;
         }
         wait_vmcnt<0>();                                     // the rowbase loads
         const bool fast = (Kt % BK == 0) && (!multi_tap || Cin % BK == 0);
@@ -154,7 +152,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
                 }
 #pragma unroll
                 for (int j = 0; j < B_IT; ++j) {
-                    const long long off = (live && wofs[j] >= 0) ? wofs[j] + (kchunk + wk[j]) : zoff_w;
+                    const long long off = (live && wofs[j] >= 0) ? wofs[j] + (long long)kchunk * 4 : zoff_w;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wh + off),
                                                      (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16, 0, 0);
                 }
@@ -174,10 +172,9 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
                                                  (__attribute__((address_space(3))) void*)(As + j * NL * 256), 16, 0, 0);
             }
 #pragma unroll
-            for (int j = 0; j < B_IT; ++j) {
-                const int k = kchunk + wk[j];
-                const bool ok = (k < Kt) & (wofs[j] >= 0);
-                const long long off = ok ? wofs[j] + k : zoff_w;
+            for (int j = 0; j < B_IT; ++j) {             // (the planes are zero-padded to whole chunks: no K tail on this side)
+                const bool ok = (kchunk < Kt) & (wofs[j] >= 0);
+                const long long off = ok ? wofs[j] + (long long)kchunk * 4 : zoff_w;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wh + off),
                                                  (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16, 0, 0);
             }
@@ -250,14 +247,15 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     const int swza = (lane >> 1) & 7;
     const unsigned a_lane = lds0 + ((wm * WTM + (lane & 31)) * BK) * 4;
     const int nrow = wn * WTN + (lane & 31);
-    const int swzb = (nrow >> 2) & 3;
-    const unsigned b_lane = lds0 + STAGE_A + nrow * 64;
-    unsigned koffa[2][2], koffb[2];
+    const int swzb = (nrow >> 1) & 7;                     // (row + 32 j has the same swizzle: the column tiles ride in the offset field)
+    const unsigned b_lane = lds0 + STAGE_A + nrow * 128;
+    unsigned koffa[2][2], koffb[2][2];                    // koffb[b][plane]: logical slot plane * 4 + b * 2 + half of the row's 128-byte block
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         koffa[b][0] = (unsigned)(((b * 4 + half * 2) ^ swza) * 16);
         koffa[b][1] = (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
-        koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+        koffb[b][0] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+        koffb[b][1] = (unsigned)(((4 + b * 2 + half) ^ swzb) * 16);
     }
 
     int st = 0;
@@ -269,15 +267,16 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     constexpr int NMF = 3 * TN, SPLIT_VALU = 28 + (PRO == ACT_RELU || PRO == ACT_LRELU ? 8 : 0);
     constexpr int VPM = (SPLIT_VALU + NMF - 1) / NMF;
     auto fetch = [&](int b, unsigned sa, unsigned sb) {
-        const unsigned va0 = sa + koffa[b][0], va1 = sa + koffa[b][1], vb = sb + koffb[b];
+        const unsigned va0 = sa + koffa[b][0], va1 = sa + koffa[b][1], vb0 = sb + koffb[b][0], vb1 = sb + koffb[b][1];
         static_for(std::make_integer_sequence<int, TM>{}, [&](auto ic) {
             constexpr int i = decltype(ic)::value;
             ra[b][i][0] = lds_read_b128_imm<i * 32 * BK * 4>(va0);
             ra[b][i][1] = lds_read_b128_imm<i * 32 * BK * 4>(va1);
         });
-        static_for(std::make_integer_sequence<int, 2 * TN>{}, [&](auto ic) {
-            constexpr int pl = decltype(ic)::value / TN, j = decltype(ic)::value % TN;
-            rb[b][pl][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<(pl * BN + j * 32) * 64>(vb));
+        static_for(std::make_integer_sequence<int, TN>{}, [&](auto ic) {
+            constexpr int j = decltype(ic)::value;
+            rb[b][0][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb0));
+            rb[b][1][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb1));
         });
     };
     // the three products of fragment (b, i) with the column tiles of k-block b: cross terms first (into the low accumulator),
@@ -448,7 +447,7 @@ template <int BM, int BN, int WGM, int WGN, int KS, int NL, int NST, int PRO>
 __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel(GemmP p) {
     constexpr int NW = WGM * WGN;                         // waves of one K group
     constexpr int NWC = NW * KS;                          // compute waves
-    constexpr int PA = BM / 8, PB = 2 * BN / 16;          // 1-KiB pieces of one group's chunk: f32 A rows, fp16 plane rows
+    constexpr int PA = BM / 8, PB = BN / 8;               // 1-KiB pieces of one group's chunk: f32 A rows, [hi | lo] weight blocks (8 rows x 128 B)
     constexpr int PG = PA + PB, PT = PG * KS;             // pieces per round (all groups)
     constexpr int LW = PT / NL;                           // pieces per loader wave and round
     constexpr int STAGE_A = BM * BK * 4, STAGE_B = PB * 1024, STAGE = STAGE_A + STAGE_B;   // bytes, one group's stage
@@ -475,11 +474,11 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
         loader_priority(p.ldr_prio);
         const int lw = wave_all - NWC;
         const char* __restrict__ Xb = reinterpret_cast<const char*>(p.X + (long long)g * p.strideX);
-        const char* __restrict__ Wb = reinterpret_cast<const char*>(reinterpret_cast<const unsigned short*>(p.Wh) + (long long)g * p.strideW);
+        const char* __restrict__ Wb = reinterpret_cast<const char*>(p.Wh) + (long long)g * p.wh_gstride;
         const char* zero = reinterpret_cast<const char*>(g_zero16);
         const char* base[LW];            // operand base of the piece (X or Wh)
-        long long rowb[LW];              // byte offset of the lane's row + its k slot inside a chunk, < 0: zero row
-        int kmul[LW], ldsoff[LW];        // bytes per k element (4: A, 2: B); LDS byte offset of the piece inside its group's stage
+        long long rowb[LW];              // byte offset of the lane's row + its 16-byte slot inside a chunk, < 0: zero row
+        int ldsoff[LW];                  // LDS byte offset of the piece inside its group's stage (both operands: 128 bytes per row and chunk)
         int grp[LW];
 #pragma unroll
         for (int j = 0; j < LW; ++j) {
@@ -490,21 +489,21 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
                 int src = kInvalidRow;
                 if (m < p.M) src = p.rowbase ? p.rowbase[m] : m * p.a_mul + p.shift0;
                 const int kl = ((lane & 7) ^ ((w * 4 + (lane >> 4)) & 7)) * 4;
-                base[j] = Xb; kmul[j] = 4; ldsoff[j] = w * 1024;
+                base[j] = Xb; ldsoff[j] = w * 1024;
                 rowb[j] = (unsigned)src < (unsigned)p.Rx ? ((long long)src * p.ldx + kl) * 4 : -1;
-            } else {                                       // B piece: plane pl, rows rb*16 .. +15, 4 lanes per 64-byte row
-                const int bp = w - PA, pl = bp / (BN / 16), rb = bp - pl * (BN / 16);
-                const int nl = rb * 16 + (lane >> 2), n = n0 + nl;
-                const int kl = ((lane & 3) ^ ((nl >> 2) & 3)) * 8;
-                base[j] = Wb; kmul[j] = 2; ldsoff[j] = STAGE_A + bp * 1024;
-                rowb[j] = n < p.N ? (pl * p.wh_plane + (long long)n * p.ldw + kl) * 2 : -1;
+            } else {                                       // B piece: weight rows bp*8 .. +7, one 128-byte [hi | lo] block per row
+                const int bp = w - PA;
+                const int nl = bp * 8 + (lane >> 3), n = n0 + nl;
+                const int sl = (lane & 7) ^ ((nl >> 1) & 7);
+                base[j] = Wb; ldsoff[j] = STAGE_A + bp * 1024;
+                rowb[j] = n < p.N ? (long long)n * p.wh_ldb + sl * 16 : -1;
             }
         }
         wait_vmcnt<0>();                                   // the rowbase loads
         auto issue = [&](int rd, int st) {
 #pragma unroll
             for (int j = 0; j < LW; ++j) {
-                const long long kb = (long long)(rd * KS + grp[j]) * BK * kmul[j];
+                const long long kb = (long long)(rd * KS + grp[j]) * BK * 4;
                 const char* src = rowb[j] >= 0 ? base[j] + rowb[j] + kb : zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(ring + (grp[j] * NST + st) * STAGE + ldsoff[j]),
@@ -547,14 +546,15 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
     const int swza = (lane >> 1) & 7;
     const unsigned a_lane = lds0 + ((wm * 32 + (lane & 31)) * BK) * 4;
     const int nrow = wn * 32 + (lane & 31);
-    const int swzb = (nrow >> 2) & 3;
-    const unsigned b_lane = lds0 + STAGE_A + nrow * 64;
-    unsigned koffa[2][2], koffb[2];
+    const int swzb = (nrow >> 1) & 7;
+    const unsigned b_lane = lds0 + STAGE_A + nrow * 128;
+    unsigned koffa[2][2], koffb[2][2];                    // koffb[b][plane]: logical slot plane * 4 + b * 2 + half
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         koffa[b][0] = (unsigned)(((b * 4 + half * 2) ^ swza) * 16);
         koffa[b][1] = (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
-        koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+        koffb[b][0] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+        koffb[b][1] = (unsigned)(((4 + b * 2 + half) ^ swzb) * 16);
     }
     float amax = 0.0f;
     f32x4 ra[2][2];
@@ -562,9 +562,8 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
     auto fetch = [&](int b, unsigned sa, unsigned sb) {
         ra[b][0] = lds_read_b128(sa + koffa[b][0]);
         ra[b][1] = lds_read_b128(sa + koffa[b][1]);
-        const unsigned vb = sb + koffb[b];                 // the plane offset is a constant of the tile: offset field
-        rb[b][0] = __builtin_bit_cast(u32x4, lds_read_b128_imm<0>(vb));
-        rb[b][1] = __builtin_bit_cast(u32x4, lds_read_b128_imm<BN * 64>(vb));
+        rb[b][0] = __builtin_bit_cast(u32x4, lds_read_b128(sb + koffb[b][0]));
+        rb[b][1] = __builtin_bit_cast(u32x4, lds_read_b128(sb + koffb[b][1]));
     };
     auto wait_block = [&](int b) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -656,7 +655,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
     constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int BPIECES = 2 * BN / 16;                  // 1-KiB pieces of one weight chunk: 2 planes x BN rows x 64 B
+    constexpr int BPIECES = BN / 8;                       // 1-KiB pieces of one weight chunk: 8 rows x 128 B ([hi | lo] blocks)
     constexpr int NI = NL > 0 ? NL : NW;                  // waves that issue the ring refill
     constexpr int B_IT = (BPIECES + NI - 1) / NI;
     constexpr int STAGE_B = B_IT * NI * 1024;             // BYTES per ring stage (dummy slots included)
@@ -680,11 +679,10 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
     const int m0 = tile * BM;
 
     const float* __restrict__ X = p.X;
-    const unsigned short* __restrict__ Wh = reinterpret_cast<const unsigned short*>(p.Wh);
+    const char* __restrict__ Wh = reinterpret_cast<const char*>(p.Wh);
     const long long zoff_x = (const float*)g_zero16 - X;
-    const long long zoff_w = (const unsigned short*)g_zero16 - Wh;
+    const long long zoff_w = (const char*)g_zero16 - Wh;
     const int ldx = p.ldx, Rx = p.Rx, Kt = p.K;
-    const long long plane = p.wh_plane;                             // elements between the weight planes
 
     {   // ---- the f32 input window, once
         const int lrow = lane >> 3;
@@ -701,23 +699,22 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
                                              (__attribute__((address_space(3))) void*)(win + (q * WRp + r8 * 8) * 32), 16, 0, 0);
         }
     }
-    // ---- weight chunks (2 fp16 planes x BN rows x 32 k = 64-byte rows) through the ring; piece = 16 rows of one plane;
-    // lane -> row lane >> 2, physical 16-B slot lane & 3, logical slot = phys ^ ((row >> 2) & 3)
+    // ---- weight chunks (BN rows x one 128-byte [hi | lo] block) through the ring; piece = 8 rows; lane -> row lane >> 3, physical
+    // 16-B slot lane & 7, logical slot = phys ^ ((row >> 1) & 7) (0-3: hi of k = 8 s .., 4-7: lo)
     const int nk = Kt / 32;
-    long long wofs[B_IT];
+    long long wofs[B_IT];        // BYTE offset of the lane's slot in chunk 0
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
-        const int pc = j * NI + wave;                    // piece = plane * (BN / 16) + row block
-        const int pl = pc / (BN / 16), rb = pc - pl * (BN / 16);
-        const int n = rb * 16 + (lane >> 2);
-        const int sl = (lane & 3) ^ ((n >> 2) & 3);
-        wofs[j] = (pc < BPIECES && n < p.N) ? pl * plane + (long long)n * p.ldw + sl * 8 : -1;
+        const int pc = j * NI + wave;                    // piece = row block
+        const int n = pc * 8 + (lane >> 3);
+        const int sl = (lane & 7) ^ ((n >> 1) & 7);
+        wofs[j] = (pc < BPIECES && n < p.N) ? (long long)n * p.wh_ldb + sl * 16 : -1;
     }
     auto issue = [&](int c, int st) {
         char* Bs = ring + st * STAGE_B + wave * 1024;
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
-            const long long off = wofs[j] >= 0 ? wofs[j] + c * 32 : zoff_w;
+            const long long off = wofs[j] >= 0 ? wofs[j] + (long long)c * 128 : zoff_w;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wh + off),
                                              (__attribute__((address_space(3))) void*)(Bs + j * NI * 1024), 16, 0, 0);
         }
@@ -767,13 +764,16 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
     const int half = lane >> 5;
     const unsigned lds_ring = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
     const unsigned lds_win = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)win;
-    // B fragment of k block b (16 k): logical slot b*2 + half of row n = wn*WTN + j*32 + (lane & 31), plane pl
+    // B fragment of k block b (16 k): logical slot plane * 4 + b * 2 + half of row n = wn*WTN + j*32 + (lane & 31)
     const int nrow = wn * WTN + (lane & 31);
-    const unsigned b_lane = lds_ring + nrow * 64;
-    const int swzb = (nrow >> 2) & 3;
-    unsigned koffb[2];
+    const unsigned b_lane = lds_ring + nrow * 128;
+    const int swzb = (nrow >> 1) & 7;
+    unsigned koffb[2][2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) koffb[b] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+    for (int b = 0; b < 2; ++b) {
+        koffb[b][0] = (unsigned)(((b * 2 + half) ^ swzb) * 16);
+        koffb[b][1] = (unsigned)(((4 + b * 2 + half) ^ swzb) * 16);
+    }
     const int arow0 = wm * WTM + (lane & 31);
     float amax = 0.0f;
 
@@ -795,15 +795,16 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
         u32x4 rb[2][2][TN];
         auto fetch = [&](int b) {
             const unsigned va0 = sa + (unsigned)(((b * 4 + half * 2) ^ swza) * 16), va1 = sa + (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
-            const unsigned vb = sb + koffb[b];
+            const unsigned vb0 = sb + koffb[b][0], vb1 = sb + koffb[b][1];
             static_for(std::make_integer_sequence<int, TM>{}, [&](auto ic) {
                 constexpr int i = decltype(ic)::value;
                 ra[b][i][0] = lds_read_b128_imm<i * 32 * BK * 4>(va0);
                 ra[b][i][1] = lds_read_b128_imm<i * 32 * BK * 4>(va1);
             });
-            static_for(std::make_integer_sequence<int, 2 * TN>{}, [&](auto ic) {
-                constexpr int pl = decltype(ic)::value / TN, j = decltype(ic)::value % TN;
-                rb[b][pl][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<(pl * BN + j * 32) * 64>(vb));
+            static_for(std::make_integer_sequence<int, TN>{}, [&](auto ic) {
+                constexpr int j = decltype(ic)::value;
+                rb[b][0][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb0));
+                rb[b][1][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb1));
             });
         };
         constexpr int F = 2 * TM, NMF = 3 * TN, SPLIT_VALU = 28 + (PRO == ACT_RELU || PRO == ACT_LRELU ? 8 : 0);

@@ -145,7 +145,7 @@ struct Loader {
             MT2_REQUIRE(v.size() % row_len == 0, "weight buffer is not a whole number of rows");
             PlaneRange pr{d, v.size(), upload_planes(v)};
             const size_t rows = v.size() / row_len;
-            std::vector<uint16_t> ph(2 * v.size());
+            std::vector<uint16_t> ph(rows * 2 * x3h_padded_k(row_len));      // chunk-interleaved [hi | lo] blocks, K padded to whole chunks
             std::vector<float> inv(rows);
             x3h_split_rows(v.data(), rows, row_len, ph.data(), inv.data());
             void* dp = nullptr;

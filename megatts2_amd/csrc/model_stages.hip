@@ -81,14 +81,16 @@ static void attach_planes(const mt2_model& m, GemmP& p) {
         // (K slices of a row - split-K - share the row's scale)
         const int ldw = p.ldw ? p.ldw : (p.taps > 0 ? p.taps : 1) * p.Cin;
         const long long rl = (long long)it->row_len, groups = p.groups > 0 ? p.groups : 1;
-        const long long col0 = (long long)((size_t)(p.W - it->base) % it->row_len);
+        const long long row0 = (long long)((size_t)(p.W - it->base) / it->row_len), col0 = (long long)((size_t)(p.W - it->base) % it->row_len);
+        const long long ldb = 4ll * (long long)x3h_padded_k(it->row_len);      // bytes per chunk-interleaved row (x3h_planes.h)
         // groups either step through whole matrices (the parallel branches of a conv stack: strideW a multiple of the row length)
-        // or through K slices of the SAME rows (split-K: every slice inside one row, shared scales)
-        const bool whole = p.strideW % rl == 0, slices = !whole && col0 + p.strideW * groups <= rl;
-        if (it->ph && ldw == (int)it->row_len && (whole || slices)) {
-            p.Wh = it->ph + (p.W - it->base);
-            p.wh_plane = (long long)it->n;
-            p.wh_inv = it->inv + (size_t)(p.W - it->base) / it->row_len;
+        // or through K slices of the SAME rows (split-K: every slice inside one row, shared scales); a launch starts on a chunk
+        const bool whole = p.strideW % rl == 0, slices = !whole && col0 + p.strideW * groups <= rl && p.strideW % 32 == 0;
+        if (it->ph && ldw == (int)it->row_len && col0 % 32 == 0 && (whole || slices || groups == 1)) {
+            p.Wh = reinterpret_cast<const char*>(it->ph) + row0 * ldb + (col0 / 32) * 128;
+            p.wh_ldb = ldb;
+            p.wh_gstride = whole ? (p.strideW / rl) * ldb : (p.strideW / 32) * 128;
+            p.wh_inv = it->inv + row0;
             p.wh_inv_stride = whole ? p.strideW / rl : 0;
         }
     }

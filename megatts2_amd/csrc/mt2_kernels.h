@@ -52,10 +52,12 @@ struct GemmP {
     const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like
     long long w3_plane = 0;     // W (same ldw / strideW, in bf16 elements), planes w3_plane elements apart (0: N * ldw) -
                                 // lets launch_gemm run on the bf16 matrix pipe in the f32-equivalent 6-product form
-    const void* Wh = nullptr;   // optional: the same weights as two fp16 planes (hi, lo * 2^11) of the ROW-SCALED matrix (x3h_planes.h), addressed
-    long long wh_plane = 0;     // like W (same ldw / strideW, in fp16 elements), planes wh_plane elements apart; wh_inv[n] = the inverse (an
-    const float* wh_inv = nullptr;   // exact power of two) of the scale of weight row n, n = 0 being W's first row; group g: + g * wh_inv_stride.
-    long long wh_inv_stride = 0;     // Lets launch_gemm run on the fp16 matrix pipe in the f32-equivalent 3-product form (gemm_x3h.hip)
+    const void* Wh = nullptr;   // optional: the same weights as two fp16 planes (hi, lo * 2^11) of the ROW-SCALED matrix, chunk-interleaved
+    long long wh_ldb = 0;       // (x3h_planes.h: row n = blocks of 128 B, block c = [hi | lo] of k = 32 c ..): Wh points at the block of
+    long long wh_gstride = 0;   // W's first element, wh_ldb = BYTES between rows (0: 4 * ceil32(ldw)), wh_gstride = bytes between groups;
+    const float* wh_inv = nullptr;   // wh_inv[n] = the inverse (an exact power of two) of the scale of weight row n, n = 0 being W's first
+    long long wh_inv_stride = 0;     // row; group g: + g * wh_inv_stride.  Lets launch_gemm run on the fp16 matrix pipe in the f32-equivalent
+                                     // 3-product form (gemm_x3h.hip)
     int* x3h_flag = nullptr;    // device word: |= 1 when an x3h launch converted an activation with |a| >= 65504 (fp16 range; set by launch_gemm
                                 // from EngineOpts::x3h_flag - the caller repeats the call without x3h)
     const float* Wtm = nullptr; // optional: the WHOLE matrix W points into, as tile-major blocks of 16 columns x 64 k (gemm_skinny.hip;

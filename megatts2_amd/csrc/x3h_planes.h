@@ -8,6 +8,11 @@
 //   w * s_n = hi + 2^-11 lo + d,  |d| <= 2^-23 |w s_n| for elements within 2^-29 of the row maximum (normal hi); smaller elements
 //   keep an ABSOLUTE accuracy of 2^-36 * 2^15 / s_n = 2^-50 of the row maximum - far below the f32 rounding of the row's dot products.
 //   inv_n = 2^-e_n is multiplied back in the GEMM epilogue (exact).
+// Layout: CHUNK-INTERLEAVED.  Row n of the matrix is stored as ceil(K / 32) blocks of 128 bytes, block c = [hi of k = 32 c .. 32 c + 31
+// (64 B) | lo of the same k (64 B)]; K is zero-padded to a multiple of 32.  One block is exactly what a workgroup's ring stage needs of
+// row n, and it is ONE 128-byte line: LDS-DMA moves 64-byte row segments (the plane-major layout of x6) at half the rate of 128-byte
+// ones (tools/ubench/ldsdma_issue.hip, profiles/r06_ubench_ldsdma_issue.txt: 27 vs 59 B/clk/CU).  Row stride = 4 * Kp bytes - for
+// K % 32 == 0 the byte offset of (n, k0) with k0 % 32 == 0 is 4 (n K + k0), the offset of the f32 element itself.
 // The conversion is written out (round to nearest even, gradual underflow) so that the planes do not depend on the host compiler's
 // _Float16 support.
 #pragma once
@@ -47,9 +52,11 @@ inline float f16_to_f32(uint16_t h) {
     return sign ? -v : v;
 }
 
-// w: rows x row_len (row-major).  planes: [2][rows * row_len] uint16 (hi plane, then lo plane); inv: [rows]
+inline size_t x3h_padded_k(size_t row_len) { return (row_len + 31) / 32 * 32; }
+// w: rows x row_len (row-major).  planes: rows x (2 * x3h_padded_k(row_len)) uint16, chunk-interleaved (above); inv: [rows]
 inline void x3h_split_rows(const float* w, size_t rows, size_t row_len, uint16_t* planes, float* inv) {
-    const size_t n = rows * row_len;
+    const size_t kp = x3h_padded_k(row_len);
+    std::memset(planes, 0, rows * 2 * kp * sizeof(uint16_t));
     for (size_t r = 0; r < rows; ++r) {
         float mx = 0.0f;
         const float* row = w + r * row_len;
@@ -71,8 +78,9 @@ inline void x3h_split_rows(const float* w, size_t rows, size_t row_len, uint16_t
             const float v = row[k] * s;
             const uint16_t h = f32_to_f16_rn(v);
             const float res = (v - f16_to_f32(h)) * 2048.0f;
-            planes[r * row_len + k] = h;
-            planes[n + r * row_len + k] = f32_to_f16_rn(res);
+            uint16_t* blk = planes + r * 2 * kp + (k / 32) * 64;
+            blk[k % 32] = h;
+            blk[32 + k % 32] = f32_to_f16_rn(res);
         }
     }
 }

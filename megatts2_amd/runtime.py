@@ -695,28 +695,36 @@ def op_conv_x6(X, W, bias=None, R=None, valid=None, shift0=0, taps=1, dil=1, Cin
 
 def split_f16x2_rows(W):
     """f32 matrix [N, K] -> the x3h operand format, written independently of csrc/x3h_planes.h (numpy float16 rounds to nearest
-    even with gradual underflow): (planes int16 [2, N, K] = fp16 bit patterns of hi and lo * 2^11 of the row-scaled matrix,
-    inv f32 [N] = the inverse power-of-two row scales)."""
+    even with gradual underflow): (planes int16 [N, Kp / 32, 2, 32] = fp16 bit patterns, per row and 32-k chunk the hi values then the
+    lo * 2^11 values of the row-scaled matrix, K zero-padded to Kp = ceil32(K); inv f32 [N] = the inverse power-of-two row scales)."""
     import torch
     w = W.detach().to(torch.float32).cpu().numpy()
+    N, K = w.shape
     mx = np.abs(np.where(np.isfinite(w), w, 0)).max(axis=1)
-    e = np.zeros(w.shape[0], np.int32)
+    e = np.zeros(N, np.int32)
     nz = mx > 0
     e[nz] = np.clip(15 - np.frexp(mx[nz])[1], -100, 100)
     s = np.ldexp(np.float32(1), e).astype(np.float32)
     v = (w * s[:, None]).astype(np.float32)
     hi = v.astype(np.float16)
     lo = ((v - hi.astype(np.float32)) * np.float32(2048)).astype(np.float16)
-    planes = np.stack([hi.view(np.int16), lo.view(np.int16)])
-    return torch.from_numpy(planes.copy()), torch.from_numpy(np.ldexp(np.float32(1), -e).astype(np.float32))
+    Kp = -(-K // 32) * 32
+    planes = np.zeros((N, Kp // 32, 2, 32), np.int16)
+    pad = np.zeros((N, Kp), np.int16)
+    pad[:, :K] = hi.view(np.int16)
+    planes[:, :, 0, :] = pad.reshape(N, Kp // 32, 32)
+    pad[:, :K] = lo.view(np.int16)
+    planes[:, :, 1, :] = pad.reshape(N, Kp // 32, 32)
+    return torch.from_numpy(planes), torch.from_numpy(np.ldexp(np.float32(1), -e).astype(np.float32))
 
 
 def x3h_split_native(W):
-    """The library's own host splitter (mt2_x3h_split) on a CPU f32 matrix: (planes int16 [2, N, K], inv f32 [N])."""
+    """The library's own host splitter (mt2_x3h_split) on a CPU f32 matrix: (planes int16 [N, Kp / 32, 2, 32], inv f32 [N])."""
     import torch
     lib = load_library()
     w = W.detach().to(torch.float32).cpu().contiguous()
-    planes = torch.empty((2,) + tuple(w.shape), dtype=torch.int16)
+    kp = -(-w.shape[1] // 32) * 32
+    planes = torch.empty(w.shape[0], kp // 32, 2, 32, dtype=torch.int16)
     inv = torch.empty(w.shape[0], dtype=torch.float32)
     _check(lib.mt2_x3h_split(C.c_void_p(w.data_ptr()), C.c_longlong(w.shape[0]), C.c_longlong(w.shape[1]),
                              C.c_void_p(planes.data_ptr()), C.c_void_p(inv.data_ptr())))

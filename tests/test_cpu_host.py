@@ -415,16 +415,17 @@ def test_x3h_host_split_matches_numpy_float16():
     import torch
     from megatts2_amd import runtime as rt
     rng = np.random.default_rng(5)
-    W = (rng.standard_normal((300, 160)) * np.exp(rng.uniform(-20, 20, (300, 160)))).astype(np.float32)
+    W = (rng.standard_normal((300, 168)) * np.exp(rng.uniform(-20, 20, (300, 168)))).astype(np.float32)      # K = 168: a K tail (padded to 192)
     W[3] = 0.0
-    W[4] = (rng.standard_normal(160) * 1e-30).astype(np.float32)
-    W[5] = (rng.standard_normal(160) * 1e30).astype(np.float32)
-    W[6, :] = np.float32(1.0) + np.arange(160, dtype=np.float32) * np.float32(2.0 ** -11)          # exact ties of the hi plane
+    W[4] = (rng.standard_normal(168) * 1e-30).astype(np.float32)
+    W[5] = (rng.standard_normal(168) * 1e30).astype(np.float32)
+    W[6, :] = np.float32(1.0) + np.arange(168, dtype=np.float32) * np.float32(2.0 ** -11)          # exact ties of the hi plane
     a, ai = rt.split_f16x2_rows(torch.from_numpy(W))
     b, bi = rt.x3h_split_native(torch.from_numpy(W))
     assert torch.equal(a, b) and torch.equal(ai, bi)
-    hi = a[0].numpy().view(np.float16).astype(np.float64)
-    lo = a[1].numpy().view(np.float16).astype(np.float64)
+    K = W.shape[1]                                       # chunk-interleaved layout: [N, K / 32, {hi, lo}, 32]
+    hi = a[:, :, 0, :].reshape(W.shape[0], -1)[:, :K].numpy().view(np.float16).astype(np.float64)
+    lo = a[:, :, 1, :].reshape(W.shape[0], -1)[:, :K].numpy().view(np.float16).astype(np.float64)
     rec = (hi + lo / 2048.0) * ai.numpy().astype(np.float64)[:, None]
     w = W.astype(np.float64)
     rowmax = np.maximum(np.abs(w).max(1, keepdims=True), 1e-300)

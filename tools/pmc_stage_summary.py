@@ -68,7 +68,7 @@ def main(argv):
     gemm_launches = 0
 
     def is_engine(name):      # the GEMM / implicit-conv engine in all its arithmetic variants (f32 MFMA, x6, window)
-        return any(k in name for k in ("gemm_f32", "gemm_x6", "gemm_skinny", "conv_win"))
+        return any(k in name for k in ("gemm_f32", "gemm_x6", "gemm_x3h", "gemm_skinny", "conv_win"))
     seen_counter_stage = set()
     for spec in ins:
         path, _, keep = spec.partition(":")

@@ -1815,7 +1815,10 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     // (profiles/r06_gemm_sweep_x3h_v1_gate.txt: the 128x128 x3h tile beats BOTH x6 loader tiles on every shape of the model - 199 vs
     // 146 TF/s at 864x4096x1024, 245 vs 188 at 4096^3 - and with long K chains and enough tiles to keep every CU busy for more than
     // one round the one-compute-wave-per-SIMD form, 64x64 per wave, is a few per cent ahead: 238 vs 221 on the decoder stack)
-    if ((o.x3h & 1) && x3h_ok && (bi == 55 || bi == 51)) bi = (p.K >= o.x3h_w4_mink && t128 >= o.t_x3h_w4) ? 94 : 91;
+    if ((o.x3h & 1) && x3h_ok && (bi == 55 || bi == 51)) {
+        bi = (p.K >= o.x3h_w4_mink && t128 >= o.t_x3h_w4) ? 94 : 91;
+        if (t128 >= o.t_x3h_c2) bi = bi == 91 ? 101 : 102;      // one barrier per 64-deep super-chunk
+    }
     // K-split tiles 84 / 85 / 86 -> 95 / 96 / 97 (profiles/r06_gemm_sweep_x3hk_v1.txt: +13..20 %, +25..50 %, +20..30 % per launch)
     if ((o.x3h & 2) && x3h_ok && bi >= 84 && bi <= 86) bi += 11;
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;

@@ -204,7 +204,12 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     // ---------------------------------------------------------------------- compute wave
     const int wave = wave_all;
     const int wm = wave / WGN, wn = wave % WGN;
-    constexpr bool PRET = TM * TN <= 2;                   // epilogue operands in flight during the K loop
+    // Epilogue operands in flight during the K loop (49 registers) only where the epilogue needs its row-per-lane form: the
+    // row-statistics / pair-fed LayerNorm instantiation.  Everything else takes the 16-byte-store epilogue (DPP-transposed 4 x 4
+    // blocks, float4 bias / residual loads): 4 stores per 32x32 tile and lane instead of 16 - the store tail of this tile measured
+    // 4.6 us of a 36-us AR launch; +5..7 % per launch (profiles/r06_gemm_sweep_x3h_v4_t4_epilogue.txt) - and frees the registers
+    // the prefetch spilled to scratch in the 12-wave form.
+    constexpr bool PRET = TM * TN <= 2 && PRO == PRO_LNX;
     EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
     if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     // the inverse row scales of this lane's output columns (exact powers of two)
@@ -428,7 +433,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         if (p.stat_out) epilogue_pre_t<TM, TN, true>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
         else epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     } else if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-    else if (NW + NL <= 8 && p.epi_t4 && epilogue_t4_ok(p)) epilogue_t4<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    else if (p.epi_t4 && epilogue_t4_ok(p)) epilogue_t4<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     if (probe) {                                  // ticks spent in the epilogue (stores issued, not necessarily retired)
         __builtin_amdgcn_s_waitcnt(0);
@@ -734,7 +739,11 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
         }
         return;
     }
+#ifdef MT2_X3H_WIN_T4
+    constexpr bool PRET = false;                          // measurement build: 16-byte-store epilogue (residual loaded as float4 there)
+#else
     constexpr bool PRET = TM * TN <= 2;
+#endif
     EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
     if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, 0, m0 + wm * WTM, wn * WTN, lane);
     float inv_s[TN];
@@ -885,6 +894,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = __builtin_fmaf(acl[i][j][e], kX3hLoInv, acc[i][j][e]) * inv_s[j];
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, 0, m0 + wm * WTM, wn * WTN, lane);
+    else if (p.epi_t4 && epilogue_t4_ok(p)) epilogue_t4<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
 }
 

@@ -106,6 +106,7 @@ struct EngineOpts {
                                  // AR steps, 4 the window convolutions; 0: everything stays x6
     int* x3h_flag = nullptr;     // device word of the range guard (GemmP::x3h_flag); the model handle owns one
     int t_x3h_128 = 72;          // x3h: from this many 128x128 tiles on the loader tile instead of the K-split tiles (t_x6_128's role)
+    int t_x3h_c2 = 1 << 30;      // x3h: from this many 128x128 tiles on the CH = 2 forms of the loader tiles (101 / 102)
     int t_x3h_w4 = 400, x3h_w4_mink = 1536;   // x3h: from this many 128x128 tiles and this K on the 64x64-per-wave form (tile 94) instead of 91
     int t_x6_256 = 160, t_x6_128 = 72;   // ... from this many 256x128 / 128x128 tiles on (profiles/r02_gemm_sweep_x6.txt)
     int x6_ks = 4;               // x6 arithmetic + eight loader waves for the AR steps' K-split tiles (gemm_x6_ks_kernel): 0 off;

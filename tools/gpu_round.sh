@@ -217,6 +217,13 @@ ablate)
     [ -d variants/$v ] && cp tools/*.py variants/$v/tools/ && (cd variants/$v && timeout 300 python tools/x6_ablate.py $v 2>&1 | grep -v amdgpu.ids) >> gpurun_out/x6_ablate.txt
   done
   echo "ablate rc=$?"; cat gpurun_out/x6_ablate.txt ;;
+vsweep)
+  # a GEMM sweep mode inside measurement builds (VSWEEP_LIST variants, VSWEEP_MODE sweep mode) next to the production library
+  for v in ${VSWEEP_LIST}; do
+    cp tools/*.py variants/$v/tools/
+    (cd variants/$v && timeout 600 python tools/gemm_sweep.py ${VSWEEP_MODE:-x3h}) > gpurun_out/vsweep_$v.txt 2>&1
+    echo "vsweep $v rc=$?"; grep -v amdgpu.ids gpurun_out/vsweep_$v.txt
+  done ;;
 phase3h)
   # per-phase cycle sums of one compute wave of the x3h loader tile (variant h_phase: tools/build_variant.sh h_phase "-DMT2_PHASE_TIMING")
   cp tools/*.py variants/h_phase/tools/

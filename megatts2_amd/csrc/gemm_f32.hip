@@ -1515,11 +1515,6 @@ static void x3h_variant_exists(GemmP) {}
       { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr,                               \
         (HAS_LNX_) ? x3h_variant_exists : nullptr }, 0, true, 0, (HAS_LNX_) ? (BN_) / (WN_) : 0, ID_ }
 
-#define MT2_X3HL2(ID_, BM_, BN_, WM_, WN_, NL_, NST_, HAS_LNX_)                                                    \
-    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(2 * BN_ / 16) * 1024),       \
-      "x3hldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_ "c2",                                            \
-      { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr,                               \
-        (HAS_LNX_) ? x3h_variant_exists : nullptr }, 0, true, 0, (HAS_LNX_) ? (BN_) / (WN_) : 0, ID_ }
 #define MT2_X3HK(ID_, BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                           \
     { BM_, BN_, (WM_* WN_ * KS_ + NL_) * 64, (size_t)KS_ * NST_ * ((size_t)BM_ * BK * 4 + (size_t)(2 * BN_ / 16) * 1024), \
       "x3hks" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "+" #NL_ "_s" #NST_,                                        \
@@ -1657,9 +1652,10 @@ static const TileCfg kCfgs[] = {
     MT2_RETIRED("x3hwin256x32_8x1+0_s3"),                   // 98: the 34 tile
     MT2_X3HW(X3H_WIN_256x64, 2, 256, 64, 8, 1, 3, 4),             // 99: the 58 tile
     MT2_X3HW(X3H_WIN_128x128, 4, 128, 128, 4, 2, 2, 4),           // 100: the 59 tile
-    // ... the loader tiles with ONE barrier per 64-deep super-chunk (4 stages = 2 super-stages, 128 KiB)
-    MT2_X3HL2(X3H_LDR_128x128_C2, 128, 128, 4, 2, 4, 4, true),    // 101: the 91 tile (+ PRO_LNX)
-    MT2_X3HL2(X3H_LDR_128x128_W4_C2, 128, 128, 2, 2, 4, 4, false), // 102: the 94 tile
+    // ... the loader tiles with ONE barrier per 64-deep super-chunk (4 stages = 2 super-stages, 128 KiB): +1 % isolated, +2.4 % SLOWER
+    // in the model (profiles/r06_experiment_x3h_superchunk.patch)
+    MT2_RETIRED("x3hldr128x128_4x2+4_s4c2"),                // 101: the 91 tile
+    MT2_RETIRED("x3hldr128x128_2x2+4_s4c2"),                // 102: the 94 tile
 };
 constexpr int kSkinny32 = 87, kSkinny64 = 88, kSkinnyTm32 = 89, kSkinnyTm64 = 90;
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -1815,10 +1811,7 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     // (profiles/r06_gemm_sweep_x3h_v1_gate.txt: the 128x128 x3h tile beats BOTH x6 loader tiles on every shape of the model - 199 vs
     // 146 TF/s at 864x4096x1024, 245 vs 188 at 4096^3 - and with long K chains and enough tiles to keep every CU busy for more than
     // one round the one-compute-wave-per-SIMD form, 64x64 per wave, is a few per cent ahead: 238 vs 221 on the decoder stack)
-    if ((o.x3h & 1) && x3h_ok && (bi == 55 || bi == 51)) {
-        bi = (p.K >= o.x3h_w4_mink && t128 >= o.t_x3h_w4) ? 94 : 91;
-        if (t128 >= o.t_x3h_c2) bi = bi == 91 ? 101 : 102;      // one barrier per 64-deep super-chunk
-    }
+    if ((o.x3h & 1) && x3h_ok && (bi == 55 || bi == 51)) bi = (p.K >= o.x3h_w4_mink && t128 >= o.t_x3h_w4) ? 94 : 91;
     // K-split tiles 84 / 85 / 86 -> 95 / 96 / 97 (profiles/r06_gemm_sweep_x3hk_v1.txt: +13..20 %, +25..50 %, +20..30 % per launch)
     if ((o.x3h & 2) && x3h_ok && bi >= 84 && bi <= 86) bi += 11;
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;

@@ -64,12 +64,10 @@ __device__ __forceinline__ void split2_f16(const f32x4& lo, const f32x4& hi, flo
 // NL loader waves refill the ring (f32 A rows + two fp16 weight planes), the WGM x WGN compute waves never issue a vector-memory
 // instruction inside the K loop.  PRO: prologue activation of the A values (ACT_*), or PRO_LNX: the pair-fed algebraic LayerNorm /
 // row-statistics epilogue form (K loop of ACT_NONE).
-// CH: ring stages (32-deep chunks) per s_barrier.  The phase timer (profiles/r06_x3h_phase_timing_v1.txt) shows a compute wave of the
-// CH = 1 form spending 745 of its ~1 765 cycles per chunk in the HEAD of the chunk - barrier 266, first fragment fetch at LDS latency
-// 334, first split 145 - with no MFMA of its own in flight, and the two compute waves of a SIMD are in that head TOGETHER (the barrier
-// aligns them): the matrix pipe idles ~40 % of every chunk.  With CH = 2 the waves meet once per 64-deep super-chunk and the fragment
-// pipeline (fetch of k block b + 2 behind the products of block b) runs through its four k blocks without a head in between.
-template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO, int CH = 1>
+// One s_barrier per 32-deep chunk.  (A form with one barrier per 64-deep super-chunk - the fragment pipeline running through four k
+// blocks without the 745-cycle head of a chunk in between - was built in round 6, parity-green, +1 % isolated and +2.4 % SLOWER in the
+// model: profiles/r06_experiment_x3h_superchunk.patch)
+template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(GemmP p) {
     constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -79,9 +77,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     constexpr int A_IT = (PA + NL - 1) / NL, B_IT = (PB + NL - 1) / NL;   // per loader wave
     constexpr int L = A_IT + B_IT;
     constexpr int STAGE_A = BM * BK * 4, STAGE_B = PB * 1024, STAGE = STAGE_A + STAGE_B;   // bytes
-    constexpr int NSS = NST / CH;                         // super-stages of CH chunks: what a barrier hands over
-    static_assert(PA % NL == 0 && PB % NL == 0 && WTM % 32 == 0 && WTN % 32 == 0, "config");
-    static_assert(CH >= 1 && NST % CH == 0 && NSS >= 2 && (NSS - 2) * L * CH < 64, "ring");
+    static_assert(PA % NL == 0 && PB % NL == 0 && WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * L < 64, "config");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* ring = reinterpret_cast<char*>(smem);
@@ -98,7 +94,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     const int m0 = (nmajor ? tile % ntm : tile / ntn) * BM, n0 = (nmajor ? tile / ntm : tile % ntn) * BN;
     const int Kt = p.K;
     const int nk = (Kt + BK - 1) / BK;
-    const int nks = (nk + CH - 1) / CH;                   // super-chunks (a chunk past K reads zeros)
 
     if (wave_all >= NW) {
         // ------------------------------------------------------------------ loader wave lw: pieces lw, lw + NL, ...
@@ -134,25 +129,24 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         wait_vmcnt<0>();                                     // the rowbase loads
         const bool fast = (Kt % BK == 0) && (!multi_tap || Cin % BK == 0);
         int s_tap = 0, s_cc = 0;
-        // (always_inline: with CH = 2 the body has four call sites and hipcc otherwise emits it as a FUNCTION - the closure, address
-        // state included, then travels through scratch memory: measured 8x slower)
+        // (always_inline: with more than two call sites hipcc emits the body as a FUNCTION - the closure, address state included, then
+        // travels through scratch memory: measured 8x slower)
         auto issue = [&](int c, int st) __attribute__((always_inline)) {
             const int kchunk = c * BK;
             float* As = reinterpret_cast<float*>(ring + st * STAGE) + lw * 256;
             char* Bs = ring + st * STAGE + STAGE_A + lw * 1024;
             if (fast) {
                 const int dsrc = s_tap * dil;
-                const bool live = CH == 1 || c < nk;      // the zero chunk that pads the last super-chunk
 #pragma unroll
                 for (int j = 0; j < A_IT; ++j) {
                     const int src = abase[j] + dsrc;
-                    const long long off = (live && (unsigned)src < (unsigned)Rx) ? (long long)src * ldx + (s_cc + akl[j]) : zoff_x;
+                    const long long off = (unsigned)src < (unsigned)Rx ? (long long)src * ldx + (s_cc + akl[j]) : zoff_x;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
                                                      (__attribute__((address_space(3))) void*)(As + j * NL * 256), 16, 0, 0);
                 }
 #pragma unroll
                 for (int j = 0; j < B_IT; ++j) {
-                    const long long off = (live && wofs[j] >= 0) ? wofs[j] + (long long)kchunk * 4 : zoff_w;
+                    const long long off = wofs[j] >= 0 ? wofs[j] + (long long)kchunk * 4 : zoff_w;
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wh + off),
                                                      (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16, 0, 0);
                 }
@@ -179,24 +173,20 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
                                                  (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16, 0, 0);
             }
         };
-        auto issue_super = [&](int sc, int ss) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < CH; ++u) issue(sc * CH + u, ss * CH + u);
-        };
-#pragma unroll
-        for (int ss = 0; ss < NSS - 1; ++ss)
-            if (ss < nks) issue_super(ss, ss);
-        int ss = 0;
-        for (int sc = 0; sc < nks; ++sc) {
-            if (sc + NSS - 2 < nks) wait_vmcnt<(NSS - 2) * L * CH>();   // this wave's pieces of super-chunk sc have landed
+        for (int st = 0; st < NST - 1; ++st)
+            if (st < nk) issue(st, st);
+        int st = 0;
+        for (int c = 0; c < nk; ++c) {
+            if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();       // this wave's pieces of chunk c have landed
             else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();                            // super-chunk sc complete; sc - 1's stages are free
+            __builtin_amdgcn_s_barrier();                            // chunk c complete; chunk c-1's stage is free
 #if defined(MT2_X3H_ABLATE) && MT2_X3H_ABLATE == 2                   // ablation: no operand ingest inside the K loop
-            if (sc + NSS - 1 < nks && sc < 1) issue_super(sc + NSS - 1, ss == 0 ? NSS - 1 : ss - 1);
+            if (c + NST - 1 < nk && c < 1) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
 #else
-            if (sc + NSS - 1 < nks) issue_super(sc + NSS - 1, ss == 0 ? NSS - 1 : ss - 1);
+            if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
 #endif
-            ss = ss + 1 == NSS ? 0 : ss + 1;
+            st = st + 1 == NST ? 0 : st + 1;
         }
         return;
     }
@@ -338,13 +328,13 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
 #else
 #define MT2_T(i_) do { } while (0)
 #endif
-    constexpr int KB = 2 * CH, FS = KB * TM;              // 16-deep k blocks and fragments per barrier
-    for (int sc = 0; sc < nks; ++sc) {
-        const unsigned sa0 = a_lane + (unsigned)(st * CH) * STAGE, sb0 = b_lane + (unsigned)(st * CH) * STAGE;
+    constexpr int FS = 2 * TM;                            // fragments per chunk (two 16-deep k blocks)
+    for (int c = 0; c < nk; ++c) {
+        const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
 #if defined(MT2_X3H_ABLATE) && MT2_X3H_ABLATE == 1                           // ablation: ingest only - the compute waves just keep the
-        if (sc + 1 < nks) {                                                  // barrier cadence (the last chunk runs the real body so
+        if (c + 1 < nk) {                                                    // barrier cadence (the last chunk runs the real body so
             __builtin_amdgcn_s_barrier();                                    // that the accumulators stay live)
-            st = st + 1 == NSS ? 0 : st + 1;
+            st = st + 1 == NST ? 0 : st + 1;
             continue;
         }
 #endif
@@ -352,22 +342,21 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         MT2_T(1);
-        // k block kb of the super-chunk = block kb & 1 of its stage kb >> 1; register buffer kb & 1
-        fetch(0, sa0, sb0);
+        fetch(0, sa, sb);
         __builtin_amdgcn_sched_barrier(0);
         wait_block(0);
         __builtin_amdgcn_sched_barrier(0);
         MT2_T(3);
-        fetch(1, sa0, sb0);
+        fetch(1, sa, sb);
         split2_f16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], amax);
         __builtin_amdgcn_sched_barrier(0);
         MT2_T(4);
 #pragma unroll
         for (int s = 0; s < FS; ++s) {
-            const int kb = s / TM, b = kb & 1, i = s % TM;
+            const int b = s / TM, i = s % TM;
             if (s + 1 < FS) {
-                const int kb2 = (s + 1) / TM, b2 = kb2 & 1, i2 = (s + 1) % TM;
-                if (kb2 != kb) {
+                const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
+                if (b2 != b) {
                     MT2_T(5);
                     wait_block(b2);
                     __builtin_amdgcn_sched_barrier(0);
@@ -383,14 +372,8 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
                 products(b, i, pln[s & 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (i == TM - 1 && kb + 2 < KB) {
-                // every MFMA that reads buffer b has been issued (in order, operands read at issue): request k block kb + 2 into
-                // it - the data land a whole LDS latency later, behind the products of block kb + 1
-                fetch(b, sa0 + (unsigned)((kb + 2) >> 1) * STAGE, sb0 + (unsigned)((kb + 2) >> 1) * STAGE);
-                __builtin_amdgcn_sched_barrier(0);
-            }
         }
-        st = st + 1 == NSS ? 0 : st + 1;
+        st = st + 1 == NST ? 0 : st + 1;
     }
     unsigned long long t_loop_end = 0;
     MT2_T(5);
@@ -402,7 +385,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     if (probe) {
         t_loop_end = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
-            p.dbg[6] = (unsigned long long)nk;               // (32-deep chunks, whatever CH)
+            p.dbg[6] = (unsigned long long)nk;
             p.dbg[7] = t_loop_end - treal0;
             p.dbg[8] = __builtin_readcyclecounter() - tcyc0;
         }
@@ -739,11 +722,9 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
         }
         return;
     }
-#ifdef MT2_X3H_WIN_T4
-    constexpr bool PRET = false;                          // measurement build: 16-byte-store epilogue (residual loaded as float4 there)
-#else
+    // (the 16-byte-store epilogue that pays in the loader-wave GEMM measured SLOWER here - 128 channels with residual 1 109 vs 1 029 us,
+    // 64 channels 763 vs 661: these launches need the residual in flight during the K loop; profiles/r06_vocx_win_t4_epilogue.txt)
     constexpr bool PRET = TM * TN <= 2;
-#endif
     EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
     if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, 0, m0 + wm * WTM, wn * WTN, lane);
     float inv_s[TN];
@@ -894,7 +875,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = __builtin_fmaf(acl[i][j][e], kX3hLoInv, acc[i][j][e]) * inv_s[j];
     if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, 0, m0 + wm * WTM, wn * WTN, lane);
-    else if (p.epi_t4 && epilogue_t4_ok(p)) epilogue_t4<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
 }
 
@@ -904,13 +884,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
     { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
       gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr,                                         \
       gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, PRO_LNX> }
-#define MT2_X3H_LDR2(BM_, BN_, WM_, WN_, NL_, NST_)                                                                         \
-    { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, 2>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, 2>, \
-      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, 2>, nullptr, nullptr,                                      \
-      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, PRO_LNX, 2> }
-#define MT2_X3H_LDR_PLAIN2(BM_, BN_, WM_, WN_, NL_, NST_)                                                                   \
-    { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, 2>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, 2>, \
-      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, 2>, nullptr, nullptr, nullptr }
 #define MT2_X3H_LDR_PLAIN(BM_, BN_, WM_, WN_, NL_, NST_)                                                                    \
     { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
       gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr, nullptr }
@@ -935,8 +908,6 @@ X3hKernel x3h_kernel(int tile, int variant) {
         MT2_X3H_KS(32, 32, 1, 1, 8, 8, 2),          // X3H_KS_32x32_K8: the 86 tile
         MT2_X3H_WIN(2, 256, 64, 8, 1, 3, 4),        // X3H_WIN_256x64: the 58 tile (8 compute + 4 loader waves)
         MT2_X3H_WIN(4, 128, 128, 4, 2, 2, 4),       // X3H_WIN_128x128: the 59 tile
-        MT2_X3H_LDR2(128, 128, 4, 2, 4, 4),         // X3H_LDR_128x128_C2: 8 + 4 waves, one barrier per 64-deep super-chunk (2 x 64 KiB)
-        MT2_X3H_LDR_PLAIN2(128, 128, 2, 2, 4, 4),   // X3H_LDR_128x128_W4_C2: 4 + 4 waves likewise
         // (measured and not kept, round 6: the 8 + 4 tile with a 4-deep ring - no gain; the 4 + 4 tile with a 3-deep ring - the
         // 4-deep one is never slower; the 32-channel window convolution - 3..19 % slower than its x6 form)
     };

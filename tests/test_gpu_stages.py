@@ -271,6 +271,35 @@ def test_vq_quantize_near_ties_against_the_live_reference(kind):
     assert int((got != b64).sum()) <= 1.25 * int((ref != b64).sum()) + 8
 
 
+def test_fp16_range_guard_repeats_the_call_on_the_bf16_path():
+    """Round 6 (gemm_x3h.hip): activations are split into fp16 planes at run time, so a value at or beyond 65 504 cannot be
+    represented - every x3h launch tracks max |a| and raises the handle's guard word, and the host layer (`NativeModel._guarded`,
+    `mt2_x3h_guard`) REPEATS the call with x3h off (the bf16 six-product form has f32's exponent range).  A prompt mel scaled by
+    3e4 drives the mel encoder's first activations to ~1e5: the guarded call must (1) notice, (2) return exactly what a handle
+    with x3h = 0 returns, (3) stay quiet on ordinary input, (4) leave the option as it found it."""
+    tts = model("prod")
+    nat = tts.native
+    z = load_golden("prod_utt0.npz")
+    B = 8
+    phone = dev(np.stack([z["phone"]] * B))
+    mel = np.stack([z["prompt_mel"]] * B).astype(np.float32)
+    big = dev(mel * np.float32(3e4))
+    x3h = nat.get_option("x3h")
+    assert x3h != 0, "the fp16-pipe forms are the default"
+    n0 = nat.range_fallbacks
+    got = nat.tc_latent(phone, big)
+    assert nat.range_fallbacks == n0 + 1 and nat.get_option("x3h") == x3h
+    nat.set_option("x3h", 0)
+    try:
+        want = nat.tc_latent(phone, big)
+    finally:
+        nat.set_option("x3h", x3h)
+    assert torch.isfinite(got).all() and torch.equal(got, want)
+    ok = nat.tc_latent(phone, dev(mel))
+    assert nat.range_fallbacks == n0 + 1 and not nat.range_guard()
+    assert O.rel_l2(ok[0].cpu().numpy(), z["tc_latent"]) < NORTH_STAR
+
+
 def test_tiny_end_to_end(tiny_batch):
     """Whole pipeline on the ragged batch: forced durations (the fixtures' frame counts), free-running PLM."""
     tts = model("tiny")

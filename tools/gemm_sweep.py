@@ -33,7 +33,7 @@ if mode == "x6":       # the bf16-pipe (f32-equivalent) configurations against t
               ("adm_qkv", 1120, 2304, 768, 1), ("adm_ff0", 2240, 1024, 768, 1), ("adm_out", 2240, 768, 768, 1),
               ("big", 4096, 4096, 4096, 1)]
 elif mode == "x3h":    # round 6: the fp16-pipe three-product tiles (91-94) against the x6 loader tiles they replace (55, 51) - VERDICT r5 gate shapes first
-    cfgs = [55, 91, 101, 94, 102, 51]
+    cfgs = [55, 91, 94, 51]
     shapes = [("plm_ff0", 864, 4096, 1024, 1), ("big", 4096, 4096, 4096, 1), ("plm_ff0", 1728, 4096, 1024, 1), ("plm_ff0", 432, 4096, 1024, 1),
               ("plm_qkv", 1728, 3072, 1024, 1), ("plm_qkv", 864, 3072, 1024, 1), ("plm_ff1", 1728, 1024, 4096, 1),
               ("plm_ff1", 864, 1024, 4096, 1), ("plm_out", 1728, 1024, 1024, 1), ("adm_qkv", 2240, 2304, 768, 1),

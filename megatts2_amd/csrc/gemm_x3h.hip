@@ -449,6 +449,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.z;
+    const unsigned long long t_entry = p.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;      // overhead probe only (tools/x3h_overheads.py)
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN, nt = ntm * ntn;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
@@ -563,6 +564,13 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][0]), acc, 0, 0, 0);
         acl = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8, rb[b][0]), acl, 0, 0, 0);
     };
+    const bool probe = p.dbg != nullptr && blockIdx.x == gridDim.x / 2 && wave_all == 0;
+    unsigned long long treal0 = 0, tcyc0 = 0;
+    if (probe) {
+        treal0 = __builtin_amdgcn_s_memrealtime();
+        tcyc0 = __builtin_readcyclecounter();
+        if (lane == 0) p.dbg[9] = treal0 - t_entry;
+    }
     int st = 0;
     for (int rd = 0; rd < nr; ++rd) {
         __builtin_amdgcn_s_barrier();
@@ -583,6 +591,15 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
         products(1);
         __builtin_amdgcn_sched_barrier(0);
         st = st + 1 == NST ? 0 : st + 1;
+    }
+    unsigned long long t_loop_end = 0;
+    if (probe) {
+        t_loop_end = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            p.dbg[6] = (unsigned long long)(nr * KS);
+            p.dbg[7] = t_loop_end - treal0;
+            p.dbg[8] = __builtin_readcyclecounter() - tcyc0;
+        }
     }
     if (p.x3h_flag != nullptr && __builtin_amdgcn_ballot_w64(amax >= kX3hMaxIn) != 0ull && lane == 0) atomicOr(p.x3h_flag, 1);
 #pragma unroll
@@ -630,6 +647,11 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
         }
         if (PRO == PRO_LNX && p.stat_out) epilogue_pre<16, PRO == PRO_LNX>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, 0);
         else epilogue_pre<16>(p, out, pre, g, m0 + wm * 32, n0 + wn * 32, lane, 0);
+    }
+    if (probe) {                                  // ticks from the end of the K loop to the last store issued (reduction + epilogue)
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) p.dbg[10] = t_end - t_loop_end;
     }
 }
 

@@ -217,6 +217,9 @@ ablate)
     [ -d variants/$v ] && cp tools/*.py variants/$v/tools/ && (cd variants/$v && timeout 300 python tools/x6_ablate.py $v 2>&1 | grep -v amdgpu.ids) >> gpurun_out/x6_ablate.txt
   done
   echo "ablate rc=$?"; cat gpurun_out/x6_ablate.txt ;;
+overheads3h)
+  timeout 300 python tools/x3h_overheads.py > gpurun_out/x3h_overheads.txt 2>&1
+  echo "overheads3h rc=$?"; grep -v amdgpu.ids gpurun_out/x3h_overheads.txt ;;
 vsweep)
   # a GEMM sweep mode inside measurement builds (VSWEEP_LIST variants, VSWEEP_MODE sweep mode) next to the production library
   for v in ${VSWEEP_LIST}; do

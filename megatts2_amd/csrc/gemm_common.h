@@ -294,19 +294,45 @@ __device__ __forceinline__ bool epilogue_t4_ok(const GemmP& p) {
 }
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_t4(const GemmP& p, f32x16 (&acc)[TM][TN], int g, int mw, int nw, int lane) {
-    const float* __restrict__ bias = p.bias ? p.bias + (long long)g * p.strideB : nullptr;
-    const float* __restrict__ R = p.R ? p.R + (long long)g * p.strideR : nullptr;
     float* __restrict__ C = p.C + (long long)g * p.strideC;
     const int epi_act = p.epi_act;
     const float epi_par = p.pro_slope, out_scale = p.out_scale;
     const bool b0 = lane & 1, b1 = lane & 2;
     const int rr = (lane & 3) + 4 * (lane >> 5), c4 = ((lane & 31) >> 2) * 4;
+    // Every operand load of the epilogue goes out FIRST, unconditionally and from a safe address (absent operands and rows / columns
+    // beyond the matrix point at constants), so that the bias vectors, the row masks and the TM x TN x 4 residual vectors are ONE
+    // memory round trip - a load behind a branch per row block (round 3's form) serialised them: 8.8 us instead of 4.4 for a
+    // 128x128 tile with residual and row mask (profiles/r06_x3h_overheads.txt).  The K loop's operand registers are dead by now.
+    const bool hasR = p.R != nullptr, hasB = p.bias != nullptr;
+    const float* __restrict__ bias0 = hasB ? p.bias + (long long)g * p.strideB : g_zero16;
+    const float* __restrict__ R0 = hasR ? p.R + (long long)g * p.strideR : g_zero16;
+    const long long ldr = hasR ? p.ldr : 0;
+    const int* __restrict__ vp = p.valid ? p.valid : g_one_i;
+    const int vs = p.valid ? 1 : 0;
+    f32x4 bv[TN], rv[TM][TN][4];
+    int vm[TM][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 32 + c4;
+        bv[j] = *reinterpret_cast<const f32x4*>(bias0 + ((hasB && n < p.N) ? n : 0));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int m = mw + i * 32 + 8 * q + rr;
+            m = m < p.M ? m : 0;
+            vm[i][q] = vp[m * vs];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nw + j * 32 + c4;
+                rv[i][j][q] = *reinterpret_cast<const f32x4*>(R0 + m * ldr + ((hasR && n < p.N) ? n : 0));
+            }
+        }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = nw + j * 32 + c4;
         const bool nok = n < p.N;                       // N is a multiple of 4: the four columns are in or out together
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (bias && nok) bv = *reinterpret_cast<const f32x4*>(bias + n);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -319,13 +345,12 @@ __device__ __forceinline__ void epilogue_t4(const GemmP& p, f32x16 (&acc)[TM][TN
                 const int m = mw + i * 32 + 8 * q + rr;
                 if (nok && m < p.M) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_rt(epi_act, v[e] + bv[e], epi_par) * out_scale;
-                    if (R) {
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(R + (long long)m * p.ldr + n);
+                    for (int e = 0; e < 4; ++e) v[e] = act_rt(epi_act, v[e] + bv[j][e], epi_par) * out_scale;
+                    if (hasR) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rv[e];
+                        for (int e = 0; e < 4; ++e) v[e] += rv[i][j][q][e];
                     }
-                    if (p.valid && p.valid[m] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (vm[i][q] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(C + (long long)m * p.ldc + n) = v;
                 }
             }

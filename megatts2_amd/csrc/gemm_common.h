@@ -292,8 +292,12 @@ __device__ __forceinline__ bool epilogue_t4_ok(const GemmP& p) {
     return ((p.N | p.ldc | (p.R ? p.ldr : 0)) & 3) == 0 && (((unsigned long long)p.C | (unsigned long long)p.R | (unsigned long long)p.bias) & 15) == 0 &&
            ((p.strideC | p.strideR | p.strideB) & 3) == 0;
 }
-template <int TM, int TN>
+// STAT (GemmP::stat_out, one 32-row block per wave): the (mean, M2) pair of every output row over the wave tile's 32 TN columns - after
+// the transposition a lane holds 4 consecutive columns of row 8 q + rr, the row's other columns sit in the 7 lanes that differ in lane
+// bits 2-4: three butterfly steps per quantity, fixed order.
+template <int TM, int TN, bool STAT = false>
 __device__ __forceinline__ void epilogue_t4(const GemmP& p, f32x16 (&acc)[TM][TN], int g, int mw, int nw, int lane) {
+    static_assert(!STAT || TM == 1, "row statistics: one 32-row block per wave");
     float* __restrict__ C = p.C + (long long)g * p.strideC;
     const int epi_act = p.epi_act;
     const float epi_par = p.pro_slope, out_scale = p.out_scale;
@@ -329,6 +333,11 @@ __device__ __forceinline__ void epilogue_t4(const GemmP& p, f32x16 (&acc)[TM][TN
                 rv[i][j][q] = *reinterpret_cast<const f32x4*>(R0 + m * ldr + ((hasR && n < p.N) ? n : 0));
             }
         }
+    float sv[STAT ? 4 : 1], qv[STAT ? 4 : 1];
+    if constexpr (STAT) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sv[q] = 0.0f; qv[q] = 0.0f; }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = nw + j * 32 + c4;
@@ -343,7 +352,8 @@ __device__ __forceinline__ void epilogue_t4(const GemmP& p, f32x16 (&acc)[TM][TN
                 const float q0 = dpp_quad(y0, 0x4E), q1 = dpp_quad(y1, 0x4E), q2 = dpp_quad(y2, 0x4E), q3 = dpp_quad(y3, 0x4E);
                 f32x4 v = {b1 ? q2 : y0, b1 ? q3 : y1, b1 ? y2 : q0, b1 ? y3 : q1};
                 const int m = mw + i * 32 + 8 * q + rr;
-                if (nok && m < p.M) {
+                const bool in = nok && m < p.M;
+                if (in) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = act_rt(epi_act, v[e] + bv[j][e], epi_par) * out_scale;
                     if (hasR) {
@@ -353,6 +363,29 @@ __device__ __forceinline__ void epilogue_t4(const GemmP& p, f32x16 (&acc)[TM][TN
                     if (vm[i][q] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
                     *reinterpret_cast<f32x4*>(C + (long long)m * p.ldc + n) = v;
                 }
+                if constexpr (STAT) {                   // of the FINAL values (0 outside M x N)
+                    if (!in) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    sv[q] += (v[0] + v[1]) + (v[2] + v[3]);
+                    qv[q] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+            }
+        }
+    }
+    if constexpr (STAT) {
+        const float w_cols = 32.0f * TN;
+        const int t = nw / (32 * TN);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float S = sv[q], Q = qv[q];
+#pragma unroll
+            for (int o = 4; o < 32; o <<= 1) { S += __shfl_xor(S, o); Q += __shfl_xor(Q, o); }
+            const int m = mw + 8 * q + rr;
+            if ((lane & 28) == 0 && m < p.M) {
+                const float mean = S / w_cols;
+                float2 pr;
+                pr.x = mean;
+                pr.y = fmaxf(Q - S * mean, 0.0f);
+                *reinterpret_cast<float2*>(p.stat_out + ((long long)m * p.stat_nt + t) * 2) = pr;
             }
         }
     }

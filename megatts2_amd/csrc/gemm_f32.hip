@@ -1880,6 +1880,15 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     int idx = 0;
     const TileCfg* c = choose_cfg(p, o, &idx);
     if (p.pro_act == PRO_LNX && !(c->stat_w && c->fn[PRO_LNX])) return hipErrorNotSupported;      // callers fall back to LayerNorm + GEMM
+    // the x3h loader tile writes through the 16-byte-store epilogue only in its pair-statistics variant: columns in fours, 16-byte bases
+    if (c->x3h >= 0 && !c->x6_ks && !c->win_qs && (p.pro_act == PRO_LNX || p.stat_out)) {
+        const bool t4 = ((p.N | p.ldc | (p.R ? p.ldr : 0)) & 3) == 0 && ((p.strideC | p.strideR | p.strideB) & 3) == 0 &&
+                        (((unsigned long long)p.C | (unsigned long long)p.R | (unsigned long long)p.bias) & 15) == 0;
+        if (!t4) {
+            if (p.pro_act == PRO_LNX) return hipErrorNotSupported;
+            p.stat_out = nullptr;
+        }
+    }
     if (p.stat_out) {       // row-statistics epilogue where the chosen tile has one; otherwise the launch simply writes none
         const int nt = c->stat_w ? p.N / c->stat_w : 0;
         if (c->stat_w && c->fn[PRO_LNX] && (p.pro_act == ACT_NONE || p.pro_act == PRO_LNX) && p.groups == 1 &&

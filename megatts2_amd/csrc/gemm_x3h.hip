@@ -194,14 +194,10 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     // ---------------------------------------------------------------------- compute wave
     const int wave = wave_all;
     const int wm = wave / WGN, wn = wave % WGN;
-    // Epilogue operands in flight during the K loop (49 registers) only where the epilogue needs its row-per-lane form: the
-    // row-statistics / pair-fed LayerNorm instantiation.  Everything else takes the 16-byte-store epilogue (DPP-transposed 4 x 4
-    // blocks, float4 bias / residual loads): 4 stores per 32x32 tile and lane instead of 16 - the store tail of this tile measured
-    // 4.6 us of a 36-us AR launch; +5..7 % per launch (profiles/r06_gemm_sweep_x3h_v4_t4_epilogue.txt) - and frees the registers
-    // the prefetch spilled to scratch in the 12-wave form.
-    constexpr bool PRET = TM * TN <= 2 && PRO == PRO_LNX;
-    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
-    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    // No epilogue operand is prefetched during the K loop: every variant takes the 16-byte-store epilogue (DPP-transposed 4 x 4 blocks,
+    // float4 bias / residual loads issued together at its start, row statistics by butterflies over the transposed values): 4 stores
+    // per 32x32 tile and lane instead of 16 - the dword-store tail of this tile measured 4.6 us of a 36-us AR launch; +5..7 % per
+    // launch (profiles/r06_gemm_sweep_x3h_v4_t4_epilogue.txt) - and the 49 registers the prefetch spilled to scratch are free.
     // the inverse row scales of this lane's output columns (exact powers of two)
     float inv_s[TN];
     {
@@ -213,7 +209,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         }
     }
     // pair-fed algebraic LayerNorm and row-statistics epilogue (GemmP::ln_stat / stat_out), as in gemm_x6_ldr_kernel
-    constexpr bool LNXOK = PRET && TM == 1 && PRO == PRO_LNX;
+    constexpr bool LNXOK = TM == 1 && TM * TN <= 2 && PRO == PRO_LNX;
     const bool lnx = LNXOK && p.pro_act == PRO_LNX;
     [[maybe_unused]] float* lnstat = reinterpret_cast<float*>(ring + NST * STAGE);
     if constexpr (LNXOK) {
@@ -413,10 +409,10 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
                 }
             }
         }
-        if (p.stat_out) epilogue_pre_t<TM, TN, true>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-        else epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-    } else if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-    else if (p.epi_t4 && epilogue_t4_ok(p)) epilogue_t4<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+        // (launch_gemm admits the PRO_LNX variant only with N, ldc, ldr multiples of 4 and 16-byte aligned bases: epilogue_t4_ok)
+        if (p.stat_out) epilogue_t4<TM, TN, true>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+        else epilogue_t4<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    } else if (p.epi_t4 && epilogue_t4_ok(p)) epilogue_t4<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     if (probe) {                                  // ticks spent in the epilogue (stores issued, not necessarily retired)
         __builtin_amdgcn_s_waitcnt(0);

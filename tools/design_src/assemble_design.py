@@ -1,0 +1,51 @@
+import json, subprocess, sys, csv, re
+bench = sys.argv[1]
+d = json.loads(open(bench).read().strip().splitlines()[-1])
+rf = d["roofline"]
+head = open('/tmp/x3h/design_head.md').read()
+sec1 = open('/tmp/x3h/sec1.md').read()
+sec2 = open('/tmp/x3h/sec2.md').read()
+sec2add = open('/tmp/x3h/design_sec2add.md').read()
+sec3 = open('/tmp/x3h/design_sec3.md').read()
+sec4 = open('/tmp/x3h/design_sec4.md').read()
+sec5 = open('/tmp/x3h/design_sec5.md').read()
+sec6 = open('/tmp/x3h/sec6.md').read()
+sec7 = open('/tmp/x3h/sec7.md').read()
+tables = subprocess.run([sys.executable, 'tools/design_tables.py', bench], capture_output=True, text=True).stdout
+tables = tables.split('\nclock probe:')[0].rstrip() + '\n'
+st = d["stage_ms"]
+w = d.get("workloads", {})
+def ms(x): return f"{x:.1f}"
+rep = {
+ "@C3MS@": ms(d["ms_per_step"]), "@C3KFPS@": f"{d['value']/1e3:.1f}", "@VOCMS@": ms(st["vocoder"]), "@ADMMS@": ms(st["adm"]),
+ "@PLMMS@": ms(st["plm"]), "@C5MS@": f"{w.get('C5', {}).get('ms_per_step', 0):,.0f}".replace(",", " "), "@STEPMS@": ms(d["ms_per_step"]),
+}
+# dominant kernel from the kernel stats (2 steps traced)
+rows = list(csv.DictReader(open('profiles/r06_c3_kernel_stats.csv')))
+tot = sum(float(r["TotalDurationNs"]) for r in rows) / 2e6
+dom = [r for r in rows if "gemm_x3h_ldr_kernel<128, 128, 4, 2, 4, 3" in r["Name"]]
+dcalls = sum(int(r["Calls"]) for r in dom) / 2
+dms = sum(float(r["TotalDurationNs"]) for r in dom) / 2e6
+pc = {r["config"]: r for r in rf["per_config"]}
+r91 = pc.get("x3hldr128x128_4x2+4_s3", {})
+rep["@DOMK@"] = (f"{dcalls:.0f} launches per step, {dms:.1f} ms of kernel time per step ({dms * 1e3 / max(dcalls, 1):.1f} µs average); the traced step of this run "
+                 f"prices its launches at {r91.get('tflops', 0):.0f} TF/s while two chains share the chip (isolated: 208 TF/s at 864×4096×1024 = 0.25 of 833.3, "
+                 f"0.43 of the ceiling at the 1.9–2.0 GHz such launches sustain)")
+rep["@SUMK@"] = f"{tot:.0f}"
+pm = json.load(open('profiles/r06_pmc_c3_latest.json'))
+ws = pm["whole_step"]
+hb = ws["read_gb_corrected"] + ws["write_gb"]
+rep["@HBM@"] = (f"{hb:.0f} GB per step ({ws['read_gb_corrected']:.0f} read + {ws['write_gb']:.0f} written; PLM "
+                f"{pm['stages']['plm']['read_gb_corrected'] + pm['stages']['plm']['write_gb']:.0f}, ADM {pm['stages']['adm']['read_gb_corrected'] + pm['stages']['adm']['write_gb']:.0f}, "
+                f"vocoder {pm['stages']['vocoder']['read_gb_corrected'] + pm['stages']['vocoder']['write_gb']:.0f}) = {hb / d['ms_per_step']:.2f} TB/s")
+cb = d.get("cpu_baseline", {})
+rep["@CPU@"] = f"{cb.get('value', 0):.0f} mel-frames/s on the {cb.get('cores', 0)} cores the cgroup grants ({cb.get('cpu_s', 0):.0f} s sample of {cb.get('utterances', 0)} utterances); GPU / CPU = {d['value'] / max(cb.get('value', 1), 1):.0f}×"
+rep["@TABLES@"] = tables
+rep["@INTERLEAVED@"] = ("Measured after the change: K-split tiles +2…3 %, 128-channel window convolution +6 %, loader tile unchanged "
+                        "(`r06_gemm_sweep_x3h*_interleaved_planes.txt`): in the loader tile the compute-side chain, not the ingest, is the longer of the two.")
+doc = head + sec1 + sec2.rstrip('\n') + '\n' + sec2add + '\n' + sec3 + sec4 + sec5 + sec6 + sec7
+for k, v in rep.items():
+    doc = doc.replace(k, v)
+left = re.findall(r'@[A-Z0-9]+@', doc)
+open('DESIGN.md', 'w').write(doc)
+print(len(doc.encode()), "bytes; unresolved:", left)

@@ -8,13 +8,20 @@ print(f"| workload | mel-frames/s | ms/step | stages (ms) | frac of {pk:.1f} (of
 print("|---|---|---|---|---|")
 st = ", ".join(f"{k} {v:.1f}" for k, v in d["stage_ms"].items() if v >= 0.05)
 print(f"| **C3** (default, driver line) | **{d['value'] / 1e3:.1f} k** | **{d['ms_per_step']:.1f}** | {st} | {rf['frac']:.3f} ({rf.get('frac_of_x6_peak', 0):.2f}; {rf['frac_of_f32_mfma_peak']:.2f}) |")
+def fr(w):
+    if 'frac' not in w:
+        return '–'
+    f32 = w.get('frac_of_f32_mfma_peak')
+    return f"{w['frac']:.3f} ({w.get('frac_of_x6_peak', 0):.2f}; {f32:.2f})" if f32 is not None else f"{w['frac']:.3f} ({w.get('frac_of_x6_peak', 0):.2f})"
+
+
 for k, w in d.get("workloads", {}).items():
     if "error" in w:
         print(f"| {k} | error: {w['error']} |")
         continue
     st = ", ".join(f"{a} {b:.1f}" for a, b in w.get("stage_ms", {}).items() if b >= 0.05)
     extra = f"; HBM {w['hbm_gb_s']:.0f} GB/s = {w['hbm_frac_of_8tbs']:.3f} of 8 TB/s, weight-streaming floor {w['weight_streaming_floor_ms']} ms" if w.get("bound") == "hbm" else ""
-    print(f"| {k} | {w['value'] / 1e3:.1f} k | {w['ms_per_step']:.1f} | {st} | {w.get('frac', 0):.3f} ({w.get('frac_of_x6_peak', 0):.2f}; {w.get('frac_of_f32_mfma_peak', 0):.2f}){extra} |")
+    print(f"| {k} | {w['value'] / 1e3:.1f} k | {w['ms_per_step']:.1f} | {st} | {fr(w)}{extra} |")
 print()
 print(f"| stage | algorithmic GFLOP | ms | TF/s | frac of {pk:.1f} (of 416.7; of 157.3) | fabric GB | GB/s (of 8 TB/s) | matrix pipe busy |")
 print("|---|---|---|---|---|---|---|---|")

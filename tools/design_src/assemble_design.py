@@ -1,16 +1,17 @@
+"""Assembles DESIGN.md from tools/design_src/*.md and a bench.py JSON line:  python tools/design_src/assemble_design.py profiles/r06_bench_c3_20steps_v1.json"""
 import json, subprocess, sys, csv, re
 bench = sys.argv[1]
 d = json.loads(open(bench).read().strip().splitlines()[-1])
 rf = d["roofline"]
-head = open('/tmp/x3h/design_head.md').read()
-sec1 = open('/tmp/x3h/sec1.md').read()
-sec2 = open('/tmp/x3h/sec2.md').read()
-sec2add = open('/tmp/x3h/design_sec2add.md').read()
-sec3 = open('/tmp/x3h/design_sec3.md').read()
-sec4 = open('/tmp/x3h/design_sec4.md').read()
-sec5 = open('/tmp/x3h/design_sec5.md').read()
-sec6 = open('/tmp/x3h/sec6.md').read()
-sec7 = open('/tmp/x3h/sec7.md').read()
+head = open('tools/design_src/design_head.md').read()
+sec1 = open('tools/design_src/sec1.md').read()
+sec2 = open('tools/design_src/sec2.md').read()
+sec2add = open('tools/design_src/design_sec2add.md').read()
+sec3 = open('tools/design_src/design_sec3.md').read()
+sec4 = open('tools/design_src/design_sec4.md').read()
+sec5 = open('tools/design_src/design_sec5.md').read()
+sec6 = open('tools/design_src/sec6.md').read()
+sec7 = open('tools/design_src/sec7.md').read()
 tables = subprocess.run([sys.executable, 'tools/design_tables.py', bench], capture_output=True, text=True).stdout
 tables = tables.split('\nclock probe:')[0].rstrip() + '\n'
 st = d["stage_ms"]
@@ -41,6 +42,8 @@ rep["@HBM@"] = (f"{hb:.0f} GB per step ({ws['read_gb_corrected']:.0f} read + {ws
 cb = d.get("cpu_baseline", {})
 rep["@CPU@"] = f"{cb.get('value', 0):.0f} mel-frames/s on the {cb.get('cores', 0)} cores the cgroup grants ({cb.get('cpu_s', 0):.0f} s sample of {cb.get('utterances', 0)} utterances); GPU / CPU = {d['value'] / max(cb.get('value', 1), 1):.0f}×"
 rep["@TABLES@"] = tables
+rep["@C4KFPS@"] = f"{w.get('C4_strong_n1', {}).get('value', 0) / 1e3:.1f}"
+rep["@C4MS@"] = f"{w.get('C4_strong_n1', {}).get('ms_per_step', 0):.0f}"
 rep["@INTERLEAVED@"] = ("Measured after the change: K-split tiles +2…3 %, 128-channel window convolution +6 %, loader tile unchanged "
                         "(`r06_gemm_sweep_x3h*_interleaved_planes.txt`): in the loader tile the compute-side chain, not the ingest, is the longer of the two.")
 doc = head + sec1 + sec2.rstrip('\n') + '\n' + sec2add + '\n' + sec3 + sec4 + sec5 + sec6 + sec7

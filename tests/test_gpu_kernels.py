@@ -449,7 +449,8 @@ def test_gemm_skinny_streams_weights_for_a_handful_of_rows(rt, M, N, K, a_mul, s
 @pytest.mark.parametrize("M,N,K,a_mul,shift0", [(1, 1024, 1024, 1, 0), (16, 3072, 1024, 1, 0), (33, 1024, 4096, 1, 0),
                                                  (64, 768, 768, 1, 0), (42, 2304, 768, 1, 0), (7, 96, 192, 1, 0),
                                                  (16, 1024, 1024, 5, 4), (40, 96, 64, 2, 1), (32, 64, 64, 1, 0),
-                                                 (5, 128, 2880, 1, 0), (17, 48, 320, 1, 0), (48, 512, 1024, 1, 0)])
+                                                 (5, 128, 2880, 1, 0), (17, 48, 320, 1, 0), (48, 512, 1024, 1, 0),
+                                                 (40, 256, 1024, 1, 0), (64, 256, 1024, 1, 0)])   # > 48 KiB of dynamic LDS with the LN prologue
 @pytest.mark.parametrize("pro", ["none", "relu", "lrelu", "ln"])
 @pytest.mark.parametrize("waves8", [False, True])
 def test_gemm_skinny_tile_major_weights_and_layernorm_prologue(rt, M, N, K, a_mul, shift0, pro, waves8):

@@ -716,8 +716,8 @@ def main() -> None:
         # (shader cycles) and s_memrealtime (constant rate) around its K loop; the bf16 pipe's ceiling scales with it
         from megatts2_amd import runtime as rt
         probes = []
-        for nm, M_, N_, K_, taps_, cfg_ in (("big 4096^3", 4096, 4096, 4096, 1, 94), ("conv stack 14064x512x1536", 14064, 512, 1536, 3, 94),
-                                          ("plm_ff0 864x4096x1024", 864, 4096, 1024, 1, 91), ("adm_qkv 1120x2304x768", 1120, 2304, 768, 1, 91),
+        for nm, M_, N_, K_, taps_, cfg_ in (("big 4096^3", 4096, 4096, 4096, 1, 103), ("conv stack 14064x512x1536", 14064, 512, 1536, 3, 103),
+                                          ("plm_ff0 864x4096x1024", 864, 4096, 1024, 1, 103), ("adm_qkv 1120x2304x768", 1120, 2304, 768, 1, 103),
                                           ("big 4096^3 (x6, rounds 2-5)", 4096, 4096, 4096, 1, 51)):
             try:
                 ms_, cn_, ghz_ = rt.bench_gemm(M_, N_, K_, taps=taps_, force_cfg=cfg_, iters=6, w_copies=2, flags=4 | 8)

@@ -1515,6 +1515,12 @@ static void x3h_variant_exists(GemmP) {}
       { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr,                               \
         (HAS_LNX_) ? x3h_variant_exists : nullptr }, 0, true, 0, (HAS_LNX_) ? (BN_) / (WN_) : 0, ID_ }
 
+#define MT2_X3HLX(ID_, BM_, BN_, WM_, WN_, NL_, NST_, HAS_LNX_)                                                    \
+    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(2 * BN_ / 16) * 1024),       \
+      "x3hldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_ "xc",                                            \
+      { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr,                               \
+        (HAS_LNX_) ? x3h_variant_exists : nullptr }, 0, true, 0, (HAS_LNX_) ? (BN_) / (WN_) : 0, ID_ }
+
 #define MT2_X3HK(ID_, BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                           \
     { BM_, BN_, (WM_* WN_ * KS_ + NL_) * 64, (size_t)KS_ * NST_ * ((size_t)BM_ * BK * 4 + (size_t)(2 * BN_ / 16) * 1024), \
       "x3hks" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "+" #NL_ "_s" #NST_,                                        \
@@ -1656,6 +1662,10 @@ static const TileCfg kCfgs[] = {
     // in the model (profiles/r06_experiment_x3h_superchunk.patch)
     MT2_RETIRED("x3hldr128x128_4x2+4_s4c2"),                // 101: the 91 tile
     MT2_RETIRED("x3hldr128x128_2x2+4_s4c2"),                // 102: the 94 tile
+    // ... the loader tiles with the fragment pipeline running across the chunk boundary (gemm_x3h_ldr_kernel<..., XC = 1>)
+    MT2_X3HLX(X3H_LDR_128x128_XC4, 128, 128, 4, 2, 4, 4, true),     // 103: the 91 tile, 4 x 32 KiB
+    MT2_X3HLX(X3H_LDR_128x128_XC3, 128, 128, 4, 2, 4, 3, true),     // 104: ... 3 x 32 KiB (one chunk-time of DMA latency)
+    MT2_X3HLX(X3H_LDR_128x128_W4_XC4, 128, 128, 2, 2, 4, 4, false), // 105: the 94 tile
 };
 constexpr int kSkinny32 = 87, kSkinny64 = 88, kSkinnyTm32 = 89, kSkinnyTm64 = 90;
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -1811,7 +1821,10 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     // (profiles/r06_gemm_sweep_x3h_v1_gate.txt: the 128x128 x3h tile beats BOTH x6 loader tiles on every shape of the model - 199 vs
     // 146 TF/s at 864x4096x1024, 245 vs 188 at 4096^3 - and with long K chains and enough tiles to keep every CU busy for more than
     // one round the one-compute-wave-per-SIMD form, 64x64 per wave, is a few per cent ahead: 238 vs 221 on the decoder stack)
-    if ((o.x3h & 1) && x3h_ok && (bi == 55 || bi == 51)) bi = (p.K >= o.x3h_w4_mink && t128 >= o.t_x3h_w4) ? 94 : 91;
+    // x3h bit 8: the cross-chunk form of the 8-wave tile (103) - ahead of 91 AND of the 64x64-per-wave form 94 on every shape of the
+    // model (profiles/r06_gemm_sweep_x3hxc_v2_buffer_loads.txt)
+    if ((o.x3h & 1) && x3h_ok && (bi == 55 || bi == 51))
+        bi = (o.x3h & 8) ? 103 : ((p.K >= o.x3h_w4_mink && t128 >= o.t_x3h_w4) ? 94 : 91);
     // K-split tiles 84 / 85 / 86 -> 95 / 96 / 97 (profiles/r06_gemm_sweep_x3hk_v1.txt: +13..20 %, +25..50 %, +20..30 % per launch)
     if ((o.x3h & 2) && x3h_ok && bi >= 84 && bi <= 86) bi += 11;
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;

@@ -29,6 +29,21 @@
 
 #include <atomic>
 
+// measurement builds (tools/x3h_ablate.py): MT2_X3H_ABLATE = 1 ingest only, 2 no ingest inside the K loop, 3 no split arithmetic, 4 no
+// matrix instructions, 5 = 2 + 3, 6 = 2 + 3 + no barrier inside the K loop (cross-chunk form), 7 = 2 + no barrier
+#ifndef MT2_X3H_ABLATE
+#define MT2_X3H_ABLATE 0
+#endif
+#define MT2_ABL_NOINGEST (MT2_X3H_ABLATE == 2 || MT2_X3H_ABLATE == 5 || MT2_X3H_ABLATE == 6 || MT2_X3H_ABLATE == 7)
+#define MT2_ABL_NOSPLIT (MT2_X3H_ABLATE == 3 || MT2_X3H_ABLATE == 5 || MT2_X3H_ABLATE == 6)
+#define MT2_ABL_NOBARRIER (MT2_X3H_ABLATE == 6 || MT2_X3H_ABLATE == 7)
+// measurement build -DMT2_X3H_NO_BUFFER_LOADS: the loaders' 64-bit global_load_lds form everywhere (the A/B of the buffer-load form)
+#ifdef MT2_X3H_NO_BUFFER_LOADS
+#define MT2_BUFFER_LOADS false
+#else
+#define MT2_BUFFER_LOADS true
+#endif
+
 namespace mt2 {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -43,7 +58,7 @@ constexpr float kX3hLoScale = 2048.0f, kX3hLoInv = 1.0f / 2048.0f, kX3hMaxIn = 6
 // the range guard; the bf16 split of x6 takes 11 per pair.
 template <int PRO>
 __device__ __forceinline__ void split2_f16(const f32x4& lo, const f32x4& hi, float slope, u32x4& ph, u32x4& pl, float& amax) {
-#if defined(MT2_X3H_ABLATE) && MT2_X3H_ABLATE == 3     // ablation: no split arithmetic (wrong numbers, same MFMA / LDS / DMA work)
+#if MT2_ABL_NOSPLIT     // ablation: no split arithmetic (wrong numbers, same MFMA / LDS / DMA work)
     ph = __builtin_bit_cast(u32x4, lo); pl = __builtin_bit_cast(u32x4, hi);
     return;
 #endif
@@ -67,7 +82,8 @@ __device__ __forceinline__ void split2_f16(const f32x4& lo, const f32x4& hi, flo
 // One s_barrier per 32-deep chunk.  (A form with one barrier per 64-deep super-chunk - the fragment pipeline running through four k
 // blocks without the 745-cycle head of a chunk in between - was built in round 6, parity-green, +1 % isolated and +2.4 % SLOWER in the
 // model: profiles/r06_experiment_x3h_superchunk.patch)
-template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO>
+// XC = 1: the fragment pipeline runs ACROSS the chunk boundary (below, "cross-chunk form").
+template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO, int XC = 0>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(GemmP p) {
     constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -129,12 +145,50 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         wait_vmcnt<0>();                                     // the rowbase loads
         const bool fast = (Kt % BK == 0) && (!multi_tap || Cin % BK == 0);
         int s_tap = 0, s_cc = 0;
+        // Whole chunks and operands below 2 GiB: BUFFER loads - the lane's byte offset of a piece is a 32-bit register computed once
+        // (per tap), the walk along K is the instruction's SCALAR offset, a row outside the operand is the offset 2^31 = out of range
+        // = zeros.  A piece then costs the loader an s_add (M0) and the load: the 64-bit per-lane address arithmetic of the
+        // global_load form below (v_mad_i64, compares, selects: ~10 VALU instructions per piece, ~950 cycles per chunk and loader
+        // wave on the SIMDs the compute waves split their fragments on) was the longest phase of a loader's chunk
+        // (profiles/r06_x3h_phase_timing_v3_loader.txt).
+        const bool fast32 = MT2_BUFFER_LOADS && fast && (long long)Rx * ldx * 4 + (long long)Kt * 4 < 0x7fffffffll && (long long)p.N * p.wh_ldb < 0x7fffffffll;
+        constexpr unsigned kOut = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)kOut, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wh), 0, (int)kOut, 0x00020000);
+        unsigned voa[A_IT], vob[B_IT];
+        auto row_offsets = [&](int dsrc) __attribute__((always_inline)) {     // the tap's rows: abase + tap * dil
+#pragma unroll
+            for (int j = 0; j < A_IT; ++j) {
+                const unsigned src = (unsigned)(abase[j] + dsrc);
+                voa[j] = src < (unsigned)Rx ? (src * (unsigned)ldx + (unsigned)akl[j]) * 4u : kOut;
+            }
+        };
+        row_offsets(0);
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) vob[j] = wofs[j] >= 0 ? (unsigned)wofs[j] : kOut;
         // (always_inline: with more than two call sites hipcc emits the body as a FUNCTION - the closure, address state included, then
         // travels through scratch memory: measured 8x slower)
         auto issue = [&](int c, int st) __attribute__((always_inline)) {
             const int kchunk = c * BK;
             float* As = reinterpret_cast<float*>(ring + st * STAGE) + lw * 256;
             char* Bs = ring + st * STAGE + STAGE_A + lw * 1024;
+            if (fast32) {
+                const int so_x = s_cc * 4, so_w = kchunk * 4;
+#pragma unroll
+                for (int j = 0; j < A_IT; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(As + j * NL * 256), 16,
+                                                             (int)voa[j], so_x, 0, 0);
+#pragma unroll
+                for (int j = 0; j < B_IT; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Bs + j * NL * 1024), 16,
+                                                             (int)vob[j], so_w, 0, 0);
+                s_cc += BK;
+                if (multi_tap && s_cc == Cin) {          // next tap: the rows move by dil, their validity with them
+                    s_cc = 0; ++s_tap;
+                    row_offsets(s_tap * dil);
+                }
+                return;
+            }
             if (fast) {
                 const int dsrc = s_tap * dil;
 #pragma unroll
@@ -176,18 +230,59 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < nk) issue(st, st);
+#ifdef MT2_PHASE_TIMING
+        // measurement build: where loader wave 0 of one workgroup spends its cycles (p.dbg[11..13]: vmcnt wait, barrier, issue)
+        const bool lprobe = p.dbg != nullptr && bid == (int)(gridDim.x / 2) && lw == 0;
+        unsigned long long lacc[3] = {0, 0, 0}, lprev = lprobe ? __builtin_readcyclecounter() : 0ull;
+#define MT2_LT(i_) do { if (lprobe) { const unsigned long long t_ = __builtin_readcyclecounter(); lacc[i_] += t_ - lprev; lprev = t_; } } while (0)
+#define MT2_LT_END() do { if (lprobe && lane == 0) { p.dbg[11] = lacc[0]; p.dbg[12] = lacc[1]; p.dbg[13] = lacc[2]; } } while (0)
+#else
+#define MT2_LT(i_) do { } while (0)
+#define MT2_LT_END() do { } while (0)
+#endif
+        if constexpr (XC) {
+            // cross-chunk form: at barrier c the compute waves still have reads of chunk c-1 in flight (they run one chunk ahead of
+            // their products) - the stage that is free is chunk c-2's, and chunk c + NST - 2 goes there
+            static_assert(NST >= 3, "cross-chunk form: chunk c-1 is still being read at barrier c");
+            for (int c = 0; c < nk; ++c) {
+                if (c == 0) { if (NST - 2 < nk) wait_vmcnt<(NST - 2) * L>(); else wait_vmcnt<0>(); }
+                else if (c + NST - 3 < nk) wait_vmcnt<(NST - 3) * L>();
+                else wait_vmcnt<0>();
+                MT2_LT(0);
+                if (!MT2_ABL_NOBARRIER || c == 0)
+                __builtin_amdgcn_s_barrier();                        // chunk c complete; chunk c-2's stage is free
+                MT2_LT(1);
+#if MT2_ABL_NOINGEST                   // ablation: no operand ingest inside the K loop
+                if (c >= 1 && c + NST - 2 < nk && c < 2) {
+#else
+                if (c >= 1 && c + NST - 2 < nk) {
+#endif
+                    const int cs = (c + NST - 2) % NST;
+                    issue(c + NST - 2, cs);
+                }
+                MT2_LT(2);
+            }
+            MT2_LT_END();
+            return;
+        }
         int st = 0;
         for (int c = 0; c < nk; ++c) {
             if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();       // this wave's pieces of chunk c have landed
             else wait_vmcnt<0>();
+            MT2_LT(0);
             __builtin_amdgcn_s_barrier();                            // chunk c complete; chunk c-1's stage is free
-#if defined(MT2_X3H_ABLATE) && MT2_X3H_ABLATE == 2                   // ablation: no operand ingest inside the K loop
+            MT2_LT(1);
+#if MT2_ABL_NOINGEST                   // ablation: no operand ingest inside the K loop
             if (c + NST - 1 < nk && c < 1) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
 #else
             if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
 #endif
+            MT2_LT(2);
             st = st + 1 == NST ? 0 : st + 1;
         }
+        MT2_LT_END();
+#undef MT2_LT
+#undef MT2_LT_END
         return;
     }
 
@@ -274,7 +369,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     // column tiles innermost so that consecutive MFMAs never wait on each other's accumulator
     auto products = [&](int b, int i, const u32x4* pp) {
         const f16x8 Ah = __builtin_bit_cast(f16x8, pp[0]), Al = __builtin_bit_cast(f16x8, pp[1]);
-#if defined(MT2_X3H_ABLATE) && MT2_X3H_ABLATE == 4     // ablation: fetch + split, no matrix instructions (operands kept live)
+#if MT2_X3H_ABLATE == 4     // ablation: fetch + split, no matrix instructions (operands kept live)
         asm volatile("" :: "v"(Ah), "v"(Al));
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(rb[b][0][j]), "v"(rb[b][1][j]));
@@ -325,9 +420,112 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
 #define MT2_T(i_) do { } while (0)
 #endif
     constexpr int FS = 2 * TM;                            // fragments per chunk (two 16-deep k blocks)
+    if constexpr (XC) {
+        // Cross-chunk form.  The one-barrier-per-chunk loop below starts every chunk with all eight compute waves waiting on the
+        // barrier, then on the first fragment's LDS latency (all waves fetch at once), then on its split - ~750 cycles in which no wave
+        // has a matrix instruction to issue, against ~780 cycles of matrix work per chunk and SIMD (profiles/r06_x3h_phase_timing_v1.txt).
+        // Here the stream of k blocks q = 2 c + b is pipelined without regard to chunks:
+        //   step (q, i):  split fragment (q, i) + 1  ||  products of fragment (q, i)
+        //   at the start of step (q, TM-1):  [q even: s_barrier - chunk c+1 has landed]  A(q+2) -> ra[q & 1]  (its last split was a step ago)
+        //   at the end   of step (q, TM-1):  B(q+2) -> rb[q & 1]  (the last product of k block q has been issued)
+        // so that A values are in flight for TM steps before their split and B fragments for TM steps before their first product;
+        // LDS returns in order, so "A(q+1) landed" is lgkmcnt <= |B(q+1)| + |A(q+2)| = 2 TN + 2 TM, and so is "B(q+1) landed" at step
+        // (q+1, 0) (behind it: A(q+2), B(q+2)).  No scalar memory instruction may sit in this loop (SMEM shares the counter and returns
+        // out of order) - tools/asm_audit.py checks.  In the last chunk nothing is fetched and every wait is lgkmcnt(0).
+        constexpr int N1 = 2 * TM + 2 * TN;
+        static_assert(N1 <= 15, "lgkmcnt is four bits wide");
+        auto fetch_a = [&](int b, unsigned sa) __attribute__((always_inline)) {
+            const unsigned va0 = sa + koffa[b][0], va1 = sa + koffa[b][1];
+            static_for(std::make_integer_sequence<int, TM>{}, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                ra[b][i][0] = lds_read_b128_imm<i * 32 * BK * 4>(va0);
+                ra[b][i][1] = lds_read_b128_imm<i * 32 * BK * 4>(va1);
+            });
+        };
+        auto fetch_b = [&](int b, unsigned sb) __attribute__((always_inline)) {
+            const unsigned vb0 = sb + koffb[b][0], vb1 = sb + koffb[b][1];
+            static_for(std::make_integer_sequence<int, TN>{}, [&](auto ic) {
+                constexpr int j = decltype(ic)::value;
+                rb[b][0][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb0));
+                rb[b][1][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb1));
+            });
+        };
+        auto tie_a = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) tie(b, i);
+        };
+        auto tie_b = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
+        };
+        __builtin_amdgcn_s_barrier();                     // chunk 0 has landed
+        asm volatile("" ::: "memory");
+        fetch_a(0, a_lane); fetch_b(0, b_lane); fetch_a(1, a_lane); fetch_b(1, b_lane);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N1) : "memory");
+        tie_a(0); tie_b(0);
+        split2_f16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], amax);
+        __builtin_amdgcn_sched_barrier(0);
+        int stn = 1 % NST;                                // stage of chunk c + 1
+        // one chunk of the stream; LAST: the launch's last chunk (nothing left to fetch) - peeled so that the steady-state body is
+        // straight-line code
+        auto chunk = [&](auto last_c) __attribute__((always_inline)) {
+            constexpr bool last = decltype(last_c)::value;
+            const unsigned sa = a_lane + (unsigned)stn * STAGE, sb = b_lane + (unsigned)stn * STAGE;    // chunk c + 1
+#pragma unroll
+            for (int s = 0; s < FS; ++s) {
+                const int b = s / TM, i = s % TM;         // fragment (q = 2 c + b, i); its split halves are pln[s & 1]
+                if (i == 0 && TM > 1) {                   // B(q) must have landed
+                    if constexpr (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N1) : "memory");
+                    tie_b(b);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (i == TM - 1) {
+                    if constexpr (!last) {
+                        if (b == 0 && !MT2_ABL_NOBARRIER) {
+                            __builtin_amdgcn_s_barrier();                 // chunk c + 1 has landed
+                            asm volatile("" ::: "memory");
+                        }
+                        fetch_a(b, sa);                                   // A(q + 2)
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N1) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
+                    tie_a(b ^ 1);                                         // A(q + 1)
+                    if (TM == 1) tie_b(b);                                // B(q): issued before A(q + 1)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const bool more = s + 1 < FS || !last;                    // a fragment follows
+                if (more) {
+                    const int s2 = (s + 1) % FS, b2 = s2 / TM, i2 = s2 % TM;
+                    if (b2 == b) tie(b2, i2);
+                    split2_f16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], amax);
+                    products(b, i, pln[s & 1]);
+                    pattern();
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    products(b, i, pln[s & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (!last) {
+                    if (i == TM - 1) {
+                        fetch_b(b, sb);                                   // B(q + 2)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            stn = stn + 1 == NST ? 0 : stn + 1;
+        };
+        for (int c = 0; c + 1 < nk; ++c) chunk(std::false_type{});
+        chunk(std::true_type{});
+    } else
     for (int c = 0; c < nk; ++c) {
         const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
-#if defined(MT2_X3H_ABLATE) && MT2_X3H_ABLATE == 1                           // ablation: ingest only - the compute waves just keep the
+#if MT2_X3H_ABLATE == 1                           // ablation: ingest only - the compute waves just keep the
         if (c + 1 < nk) {                                                    // barrier cadence (the last chunk runs the real body so
             __builtin_amdgcn_s_barrier();                                    // that the accumulators stay live)
             st = st + 1 == NST ? 0 : st + 1;
@@ -485,7 +683,27 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
             }
         }
         wait_vmcnt<0>();                                   // the rowbase loads
-        auto issue = [&](int rd, int st) {
+        // operands below 2 GiB: buffer loads - per piece a 32-bit lane offset (row + slot + the K group's chunk), the round as the
+        // scalar offset, zero rows as the out-of-range offset 2^31 (gemm_x3h_ldr_kernel's loader, above)
+        constexpr unsigned kOut = 0x80000000u;
+        const bool fast32 = MT2_BUFFER_LOADS && (long long)p.Rx * p.ldx * 4 + (long long)p.K * 4 < 0x7fffffffll && (long long)p.N * p.wh_ldb < 0x7fffffffll;
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Xb), 0, (int)kOut, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wb), 0, (int)kOut, 0x00020000);
+        unsigned vo[LW];
+#pragma unroll
+        for (int j = 0; j < LW; ++j) vo[j] = rowb[j] >= 0 ? (unsigned)rowb[j] + (unsigned)grp[j] * (BK * 4) : kOut;
+        auto issue = [&](int rd, int st) __attribute__((always_inline)) {
+            if (fast32) {
+                const int so = rd * KS * BK * 4;
+#pragma unroll
+                for (int j = 0; j < LW; ++j) {
+                    const bool is_a = base[j] == Xb;               // (wave-uniform: the piece index depends on the wave only)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? rs_x : rs_w,
+                                                             (__attribute__((address_space(3))) void*)(ring + (grp[j] * NST + st) * STAGE + ldsoff[j]),
+                                                             16, (int)vo[j], so, 0, 0);
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < LW; ++j) {
                 const long long kb = (long long)(rd * KS + grp[j]) * BK * 4;
@@ -716,8 +934,21 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
         const int sl = (lane & 7) ^ ((n >> 1) & 7);
         wofs[j] = (pc < BPIECES && n < p.N) ? (long long)n * p.wh_ldb + sl * 16 : -1;
     }
-    auto issue = [&](int c, int st) {
+    // weights below 2 GiB: buffer loads (32-bit lane offset, the chunk as the scalar offset, rows beyond N out of range = zeros)
+    constexpr unsigned kOut = 0x80000000u;
+    const bool fast32 = MT2_BUFFER_LOADS && (long long)p.N * p.wh_ldb < 0x7fffffffll;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wh), 0, (int)kOut, 0x00020000);
+    unsigned vob[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) vob[j] = wofs[j] >= 0 ? (unsigned)wofs[j] : kOut;
+    auto issue = [&](int c, int st) __attribute__((always_inline)) {
         char* Bs = ring + st * STAGE_B + wave * 1024;
+        if (fast32) {
+#pragma unroll
+            for (int j = 0; j < B_IT; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(Bs + j * NI * 1024), 16, (int)vob[j], c * 128, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) {
             const long long off = wofs[j] >= 0 ? wofs[j] + (long long)c * 128 : zoff_w;
@@ -906,6 +1137,14 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
     { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
       gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr, nullptr }
 
+#define MT2_X3H_LDR_XC(BM_, BN_, WM_, WN_, NL_, NST_)                                                                             \
+    { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, 1>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, 1>, \
+      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, 1>, nullptr, nullptr,                                             \
+      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, PRO_LNX, 1> }
+#define MT2_X3H_LDR_XC_PLAIN(BM_, BN_, WM_, WN_, NL_, NST_)                                                                       \
+    { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, 1>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, 1>, \
+      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, 1>, nullptr, nullptr, nullptr }
+
 #define MT2_X3H_KS(BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                                          \
     { gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_NONE>, gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_RELU>, \
       gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr,                                           \
@@ -926,6 +1165,9 @@ X3hKernel x3h_kernel(int tile, int variant) {
         MT2_X3H_KS(32, 32, 1, 1, 8, 8, 2),          // X3H_KS_32x32_K8: the 86 tile
         MT2_X3H_WIN(2, 256, 64, 8, 1, 3, 4),        // X3H_WIN_256x64: the 58 tile (8 compute + 4 loader waves)
         MT2_X3H_WIN(4, 128, 128, 4, 2, 2, 4),       // X3H_WIN_128x128: the 59 tile
+        MT2_X3H_LDR_XC(128, 128, 4, 2, 4, 4),       // X3H_LDR_128x128_XC4: cross-chunk fragment pipeline, 4 x 32 KiB
+        MT2_X3H_LDR_XC(128, 128, 4, 2, 4, 3),       // X3H_LDR_128x128_XC3
+        MT2_X3H_LDR_XC_PLAIN(128, 128, 2, 2, 4, 4), // X3H_LDR_128x128_W4_XC4
         // (measured and not kept, round 6: the 8 + 4 tile with a 4-deep ring - no gain; the 4 + 4 tile with a 3-deep ring - the
         // 4-deep one is never slower; the 32-channel window convolution - 3..19 % slower than its x6 form)
     };

@@ -40,6 +40,13 @@ elif mode == "x3h":    # round 6: the fp16-pipe three-product tiles (91-94) agai
               ("adm_qkv", 1120, 2304, 768, 1), ("adm_ff0", 2240, 1024, 768, 1), ("adm_out", 2240, 768, 768, 1),
               ("mrte_stack", 14064, 512, 1536, 3), ("decoder", 13858, 512, 2560, 5), ("vqpe", 13858, 384, 1920, 5),
               ("hifi_s1", 111000, 256, 1792, 7), ("hifi_s1k11", 111000, 256, 2816, 11)]
+elif mode == "x3hxc":  # round 6: the loader tiles with the fragment pipeline across the chunk boundary (103-105) against 91 / 94
+    cfgs = [91, 103, 104, 94, 105]
+    shapes = [("plm_ff0", 864, 4096, 1024, 1), ("big", 4096, 4096, 4096, 1), ("plm_ff0", 1728, 4096, 1024, 1), ("plm_ff0", 432, 4096, 1024, 1),
+              ("plm_qkv", 864, 3072, 1024, 1), ("plm_ff1", 864, 1024, 4096, 1), ("plm_out", 1728, 1024, 1024, 1),
+              ("adm_qkv", 2240, 2304, 768, 1), ("adm_qkv", 1120, 2304, 768, 1), ("adm_ff0", 2240, 1024, 768, 1), ("adm_out", 2240, 768, 768, 1),
+              ("mrte_stack", 14064, 512, 1536, 3), ("decoder", 13858, 512, 2560, 5), ("vqpe", 13858, 384, 1920, 5),
+              ("hifi_s1", 111000, 256, 1792, 7)]
 elif mode == "x3hk":   # round 6: the K-split tiles on the fp16 pipe (95-97) against their x6 forms (84-86) and the 128x128 tiles
     cfgs = [84, 95, 85, 96, 86, 97, 55, 91]
     shapes = [("plm_qkv", 96, 3072, 1024, 1), ("plm_qkv", 224, 3072, 1024, 1), ("plm_qkv", 448, 3072, 1024, 1), ("plm_qkv", 672, 3072, 1024, 1),

@@ -164,6 +164,38 @@ sweep_x6)
 sweep_x3h)
   timeout 900 python tools/gemm_sweep.py x3h > gpurun_out/gemm_sweep_x3h.txt 2>&1
   echo "sweep_x3h rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x3h.txt ;;
+power)
+  # package power and shader clock while C3 steps run back to back (and while the isolated 4096^3 GEMM runs)
+  ls /sys/class/drm/card*/device/hwmon/hwmon*/ > gpurun_out/power_sysfs_ls.txt 2>&1
+  timeout 600 python tools/power_sampler.py gpurun_out/power_c3_samples.txt -- python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-roofline --no-sub-workloads ${POWER_OPT:-} > gpurun_out/power_c3.txt 2>&1
+  echo "power rc=$?"; grep -v "^{" gpurun_out/power_c3.txt | tail -14; grep "^{" gpurun_out/power_c3.txt | cut -c1-330
+  timeout 300 python tools/power_sampler.py gpurun_out/power_gemm_samples.txt -- python -c "
+import sys; sys.path.insert(0, '.')
+from megatts2_amd import runtime as rt
+rt.device_check()
+for i in range(6): print(rt.bench_gemm(4096, 4096, 4096, force_cfg=103, iters=400, w_copies=2, flags=8))
+" > gpurun_out/power_gemm.txt 2>&1
+  tail -14 gpurun_out/power_gemm.txt ;;
+pmcx3h)
+  # where the waves of the x3h loader tiles wait: SQ counters of a few launches (tools/x3h_pmc_probe.py), separate passes
+  (cd /tmp && rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z0-9_]*" | sort -u | tr "\n" " ") > gpurun_out/pmcx3h_available.txt
+  : > gpurun_out/pmcx3h.txt
+  n=0
+  for c in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
+           "SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_LDS" \
+           "SQ_WAVE_CYCLES SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_FLAT"; do
+    n=$((n + 1))
+    rm -rf gpurun_out/pmcx3h_$n
+    (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/pmcx3h_$n -o pmc -- python $GRAFT_REPO_ROOT/tools/x3h_pmc_probe.py) > gpurun_out/pmcx3h_$n.log 2>&1
+    echo "pmcx3h pass $n rc=$?"; tail -2 gpurun_out/pmcx3h_$n.log | cut -c1-200
+    f=$(find gpurun_out/pmcx3h_$n -name "*counter_collection.csv" | head -1)
+    [ -n "$f" ] && python tools/x3h_pmc_probe.py summary "$f" >> gpurun_out/pmcx3h.txt
+    find gpurun_out/pmcx3h_$n -name "*.csv" -size +8M -delete
+  done
+  cat gpurun_out/pmcx3h.txt ;;
+sweep_x3hxc)
+  timeout 900 python tools/gemm_sweep.py x3hxc > gpurun_out/gemm_sweep_x3hxc.txt 2>&1
+  echo "sweep_x3hxc rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x3hxc.txt ;;
 sweep_x3hk)
   timeout 900 python tools/gemm_sweep.py x3hk > gpurun_out/gemm_sweep_x3hk.txt 2>&1
   echo "sweep_x3hk rc=$?"; grep -v amdgpu.ids gpurun_out/gemm_sweep_x3hk.txt
@@ -220,6 +252,16 @@ ablate)
 overheads3h)
   timeout 300 python tools/x3h_overheads.py > gpurun_out/x3h_overheads.txt 2>&1
   echo "overheads3h rc=$?"; grep -v amdgpu.ids gpurun_out/x3h_overheads.txt ;;
+vbench)
+  # the C3 bench in measurement builds next to the production library, interleaved on this box: VBENCH_LIST variants, VBENCH_ROUNDS
+  : > gpurun_out/vbench.txt
+  for r in $(seq 1 ${VBENCH_ROUNDS:-2}); do
+    timeout 600 python bench.py --steps ${VBENCH_STEPS:-8} --warmup 3 --no-cpu-baseline --no-roofline --no-sub-workloads ${VBENCH_OPT:-} 2>/dev/null | grep "^{" | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('prod', d['ms_per_step'], d.get('stage_ms'))" | tee -a gpurun_out/vbench.txt
+    for v in ${VBENCH_LIST}; do
+      cp bench.py variants/$v/; ln -sfn ../../tests variants/$v/tests; ln -sfn ../../profiles variants/$v/profiles
+      (cd variants/$v && timeout 600 python bench.py --steps ${VBENCH_STEPS:-8} --warmup 3 --no-cpu-baseline --no-roofline --no-sub-workloads ${VBENCH_OPT:-} 2>/dev/null | grep "^{" | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('$v', d['ms_per_step'], d.get('stage_ms'))") | tee -a gpurun_out/vbench.txt
+    done
+  done ;;
 vsweep)
   # a GEMM sweep mode inside measurement builds (VSWEEP_LIST variants, VSWEEP_MODE sweep mode) next to the production library
   for v in ${VSWEEP_LIST}; do

@@ -716,14 +716,29 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < nr) issue(st, st);
+#ifdef MT2_PHASE_TIMING
+        // measurement build: where loader wave 0 of one workgroup spends its cycles (p.dbg[11..13]: vmcnt wait, barrier, issue)
+        const bool lprobe = p.dbg != nullptr && bid == (int)(gridDim.x / 2) && lw == 0;
+        unsigned long long lacc[3] = {0, 0, 0}, lprev = lprobe ? __builtin_readcyclecounter() : 0ull;
+#define MT2_LT(i_) do { if (lprobe) { const unsigned long long t_ = __builtin_readcyclecounter(); lacc[i_] += t_ - lprev; lprev = t_; } } while (0)
+#else
+#define MT2_LT(i_) do { } while (0)
+#endif
         int st = 0;
         for (int rd = 0; rd < nr; ++rd) {
             if (rd + NST - 2 < nr) wait_vmcnt<(NST - 2) * LW>();
             else wait_vmcnt<0>();
+            MT2_LT(0);
             __builtin_amdgcn_s_barrier();                  // round rd complete in LDS; round rd-1's stages are free
+            MT2_LT(1);
             if (rd + NST - 1 < nr) issue(rd + NST - 1, st == 0 ? NST - 1 : st - 1);
+            MT2_LT(2);
             st = st + 1 == NST ? 0 : st + 1;
         }
+#ifdef MT2_PHASE_TIMING
+        if (lprobe && lane == 0) { p.dbg[11] = lacc[0]; p.dbg[12] = lacc[1]; p.dbg[13] = lacc[2]; }
+#endif
+#undef MT2_LT
         return;
     }
 
@@ -793,6 +808,9 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
         fetch(0, sa, sb);
         fetch(1, sa, sb);
         __builtin_amdgcn_sched_barrier(0);
+        // (a form with the fragment pipeline running across the rounds - the cross-chunk form of gemm_x3h_ldr_kernel - measured EQUAL,
+        // +-2 %: these tiles are bound by the ingest, KS x 8..16 KiB per round at the 64 B/clk of a CU's LDS-DMA path = 512..1 024
+        // cycles against 384 of matrix work; profiles/r06_experiment_x3h_ks_cross_round.patch, r06_x3h_phase_timing_v4_*.txt)
         // one tile per wave: a split does not fit in the shadow of its three MFMAs - split and multiply in turn, the other
         // waves of the SIMD (another K group) fill the gaps
         wait_block(0);

@@ -6,10 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from megatts2_amd import runtime as rt
 
 rt.device_check()
-for name, M, N, K, taps, cfg in [("plm_ff0", 864, 4096, 1024, 1, 91), ("plm_qkv", 448, 3072, 1024, 1, 91), ("adm_qkv", 1120, 2304, 768, 1, 91),
-                                 ("big", 4096, 4096, 4096, 1, 91), ("decoder", 13858, 512, 2560, 5, 91), ("plm_ff0", 864, 4096, 1024, 1, 94),
-                                 ("big", 4096, 4096, 4096, 1, 94), ("decoder", 13858, 512, 2560, 5, 94),
+for name, M, N, K, taps, cfg in [("plm_ff0", 864, 4096, 1024, 1, 91),
                                  ("plm_ff0", 864, 4096, 1024, 1, 103), ("adm_qkv", 1120, 2304, 768, 1, 103), ("big", 4096, 4096, 4096, 1, 103),
-                                 ("decoder", 13858, 512, 2560, 5, 103), ("plm_ff0", 864, 4096, 1024, 1, 104), ("plm_ff0", 864, 4096, 1024, 1, 105)]:
+                                 ("decoder", 13858, 512, 2560, 5, 103), ("plm_ff0", 864, 4096, 1024, 1, 104), ("plm_ff0", 864, 4096, 1024, 1, 105),
+                                 ("plm_ff0", 224, 4096, 1024, 1, 96), ("plm_out", 864, 1024, 1024, 1, 96), ("adm_qkv", 280, 2304, 768, 1, 96),
+                                 ("plm_ff1", 448, 1024, 4096, 1, 95), ("plm_out", 448, 1024, 1024, 1, 95), ("plm_out", 224, 1024, 1024, 1, 97)]:
     ms, cn, ghz = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=4, w_copies=2, flags=4)
     print(f"{name} {M}x{N}x{K} {cn}: {ms * 1e3:.1f} us {2.0 * M * N * K / ms / 1e9:.1f} TF/s  ({ms * 1e-3 * ghz * 1e9 / ((K + 31) // 32):.0f} cycles per chunk of kernel time at the measured {ghz:.2f} GHz)", flush=True)

@@ -1511,12 +1511,6 @@ struct TileCfg {
 static void x3h_variant_exists(GemmP) {}
 #define MT2_X3HL(ID_, BM_, BN_, WM_, WN_, NL_, NST_, HAS_LNX_)                                                     \
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(2 * BN_ / 16) * 1024),       \
-      "x3hldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_,                                                 \
-      { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr,                               \
-        (HAS_LNX_) ? x3h_variant_exists : nullptr }, 0, true, 0, (HAS_LNX_) ? (BN_) / (WN_) : 0, ID_ }
-
-#define MT2_X3HLX(ID_, BM_, BN_, WM_, WN_, NL_, NST_, HAS_LNX_)                                                    \
-    { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(2 * BN_ / 16) * 1024),       \
       "x3hldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_ "xc",                                            \
       { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr,                               \
         (HAS_LNX_) ? x3h_variant_exists : nullptr }, 0, true, 0, (HAS_LNX_) ? (BN_) / (WN_) : 0, ID_ }
@@ -1646,10 +1640,10 @@ static const TileCfg kCfgs[] = {
     { 32, 32, 512, 0, "skinnytm32_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },  // 89: the same on tile-major weights
     { 64, 32, 512, 0, "skinnytm64_f32", { nullptr, nullptr, nullptr, nullptr, nullptr } },  // 90   (+ LayerNorm prologue)
     // v4: the loader-wave tiles on the fp16 pipe, f32-equivalent THREE-product form (gemm_x3h.hip)
-    MT2_X3HL(X3H_LDR_128x128, 128, 128, 4, 2, 4, 3, true),        // 91: the 55 tile (+ PRO_LNX), 3 x 32 KiB
+    MT2_RETIRED("x3hldr128x128_4x2+4_s3"),                  // 91: the 55 tile, one-barrier-per-chunk loop, 3 x 32 KiB (-> 103)
     MT2_RETIRED("x3hldr128x128_4x2+4_s4"),                  // 92: ... with a 4-deep ring (128 KiB)
     MT2_RETIRED("x3hldr128x128_2x2+4_s3"),                  // 93: one compute wave per SIMD (64x64 per wave) + 4 loaders
-    MT2_X3HL(X3H_LDR_128x128_W4_S4, 128, 128, 2, 2, 4, 4, false), // 94: ... with a 4-deep ring
+    MT2_RETIRED("x3hldr128x128_2x2+4_s4"),                  // 94: ... with a 4-deep ring
     // ... and the K-split tiles of the AR steps (gemm_x3h_ks_kernel; + PRO_LNX)
     MT2_X3HK(X3H_KS_32x64_K4, 32, 64, 1, 2, 4, 8, 2),             // 95: the 84 tile, 96 KiB
     MT2_X3HK(X3H_KS_64x64_K2, 64, 64, 2, 2, 2, 8, 3),             // 96: the 85 tile, 96 KiB
@@ -1662,10 +1656,10 @@ static const TileCfg kCfgs[] = {
     // in the model (profiles/r06_experiment_x3h_superchunk.patch)
     MT2_RETIRED("x3hldr128x128_4x2+4_s4c2"),                // 101: the 91 tile
     MT2_RETIRED("x3hldr128x128_2x2+4_s4c2"),                // 102: the 94 tile
-    // ... the loader tiles with the fragment pipeline running across the chunk boundary (gemm_x3h_ldr_kernel<..., XC = 1>)
-    MT2_X3HLX(X3H_LDR_128x128_XC4, 128, 128, 4, 2, 4, 4, true),     // 103: the 91 tile, 4 x 32 KiB
-    MT2_X3HLX(X3H_LDR_128x128_XC3, 128, 128, 4, 2, 4, 3, true),     // 104: ... 3 x 32 KiB (one chunk-time of DMA latency)
-    MT2_X3HLX(X3H_LDR_128x128_W4_XC4, 128, 128, 2, 2, 4, 4, false), // 105: the 94 tile
+    // ... the loader tile with the fragment pipeline running across the chunk boundary (gemm_x3h_ldr_kernel; "xc" in the name)
+    MT2_X3HL(X3H_LDR_128x128, 128, 128, 4, 2, 4, 4, true),  // 103: the 55 tile (+ PRO_LNX), 4 x 32 KiB: THE x3h loader tile
+    MT2_RETIRED("x3hldr128x128_4x2+4_s3xc"),                // 104: ... 3 x 32 KiB (one chunk-time of DMA latency: slower)
+    MT2_RETIRED("x3hldr128x128_2x2+4_s4xc"),                // 105: the 94 tile in this form (slower than 103 on every shape)
 };
 constexpr int kSkinny32 = 87, kSkinny64 = 88, kSkinnyTm32 = 89, kSkinnyTm64 = 90;
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -1819,12 +1813,9 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     }
     // the fp16-pipe form of the tile (three products instead of six) where one exists and the weights come with fp16 planes
     // (profiles/r06_gemm_sweep_x3h_v1_gate.txt: the 128x128 x3h tile beats BOTH x6 loader tiles on every shape of the model - 199 vs
-    // 146 TF/s at 864x4096x1024, 245 vs 188 at 4096^3 - and with long K chains and enough tiles to keep every CU busy for more than
-    // one round the one-compute-wave-per-SIMD form, 64x64 per wave, is a few per cent ahead: 238 vs 221 on the decoder stack)
-    // x3h bit 8: the cross-chunk form of the 8-wave tile (103) - ahead of 91 AND of the 64x64-per-wave form 94 on every shape of the
-    // model (profiles/r06_gemm_sweep_x3hxc_v2_buffer_loads.txt)
-    if ((o.x3h & 1) && x3h_ok && (bi == 55 || bi == 51))
-        bi = (o.x3h & 8) ? 103 : ((p.K >= o.x3h_w4_mink && t128 >= o.t_x3h_w4) ? 94 : 91);
+    // 146 TF/s at 864x4096x1024, 245 vs 188 at 4096^3 on the first build; 243 and 297 with the cross-chunk pipeline and the loaders
+    // on buffer loads, profiles/r06_gemm_sweep_x3hxc_v2_buffer_loads.txt)
+    if ((o.x3h & 1) && x3h_ok && (bi == 55 || bi == 51)) bi = 103;
     // K-split tiles 84 / 85 / 86 -> 95 / 96 / 97 (profiles/r06_gemm_sweep_x3hk_v1.txt: +13..20 %, +25..50 %, +20..30 % per launch)
     if ((o.x3h & 2) && x3h_ok && bi >= 84 && bi <= 86) bi += 11;
     if (o.force_cfg >= 0 && o.force_cfg < kNumCfgs) bi = o.force_cfg;

@@ -29,7 +29,7 @@
 
 #include <atomic>
 
-// measurement builds (tools/x3h_ablate.py): MT2_X3H_ABLATE = 1 ingest only, 2 no ingest inside the K loop, 3 no split arithmetic, 4 no
+// measurement builds (tools/x3h_ablate.py): MT2_X3H_ABLATE = 2 no ingest inside the K loop, 3 no split arithmetic, 4 no
 // matrix instructions, 5 = 2 + 3, 6 = 2 + 3 + no barrier inside the K loop (cross-chunk form), 7 = 2 + no barrier
 #ifndef MT2_X3H_ABLATE
 #define MT2_X3H_ABLATE 0
@@ -79,11 +79,10 @@ __device__ __forceinline__ void split2_f16(const f32x4& lo, const f32x4& hi, flo
 // NL loader waves refill the ring (f32 A rows + two fp16 weight planes), the WGM x WGN compute waves never issue a vector-memory
 // instruction inside the K loop.  PRO: prologue activation of the A values (ACT_*), or PRO_LNX: the pair-fed algebraic LayerNorm /
 // row-statistics epilogue form (K loop of ACT_NONE).
-// One s_barrier per 32-deep chunk.  (A form with one barrier per 64-deep super-chunk - the fragment pipeline running through four k
-// blocks without the 745-cycle head of a chunk in between - was built in round 6, parity-green, +1 % isolated and +2.4 % SLOWER in the
-// model: profiles/r06_experiment_x3h_superchunk.patch)
-// XC = 1: the fragment pipeline runs ACROSS the chunk boundary (below, "cross-chunk form").
-template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO, int XC = 0>
+// One s_barrier per 32-deep chunk, and the compute waves' fragment pipeline runs ACROSS it (the K loop below).  (A form with one barrier
+// per 64-deep super-chunk was built in round 6, parity-green, +1 % isolated and +2.4 % SLOWER in the model:
+// profiles/r06_experiment_x3h_superchunk.patch.)
+template <int BM, int BN, int WGM, int WGN, int NL, int NST, int PRO>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(GemmP p) {
     constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -240,45 +239,26 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
 #define MT2_LT(i_) do { } while (0)
 #define MT2_LT_END() do { } while (0)
 #endif
-        if constexpr (XC) {
-            // cross-chunk form: at barrier c the compute waves still have reads of chunk c-1 in flight (they run one chunk ahead of
-            // their products) - the stage that is free is chunk c-2's, and chunk c + NST - 2 goes there
-            static_assert(NST >= 3, "cross-chunk form: chunk c-1 is still being read at barrier c");
-            for (int c = 0; c < nk; ++c) {
-                if (c == 0) { if (NST - 2 < nk) wait_vmcnt<(NST - 2) * L>(); else wait_vmcnt<0>(); }
-                else if (c + NST - 3 < nk) wait_vmcnt<(NST - 3) * L>();
-                else wait_vmcnt<0>();
-                MT2_LT(0);
-                if (!MT2_ABL_NOBARRIER || c == 0)
-                __builtin_amdgcn_s_barrier();                        // chunk c complete; chunk c-2's stage is free
-                MT2_LT(1);
-#if MT2_ABL_NOINGEST                   // ablation: no operand ingest inside the K loop
-                if (c >= 1 && c + NST - 2 < nk && c < 2) {
-#else
-                if (c >= 1 && c + NST - 2 < nk) {
-#endif
-                    const int cs = (c + NST - 2) % NST;
-                    issue(c + NST - 2, cs);
-                }
-                MT2_LT(2);
-            }
-            MT2_LT_END();
-            return;
-        }
-        int st = 0;
+        // cross-chunk form: at barrier c the compute waves still have reads of chunk c-1 in flight (they run one chunk ahead of
+        // their products) - the stage that is free is chunk c-2's, and chunk c + NST - 2 goes there
+        static_assert(NST >= 3, "cross-chunk form: chunk c-1 is still being read at barrier c");
         for (int c = 0; c < nk; ++c) {
-            if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * L>();       // this wave's pieces of chunk c have landed
+            if (c == 0) { if (NST - 2 < nk) wait_vmcnt<(NST - 2) * L>(); else wait_vmcnt<0>(); }
+            else if (c + NST - 3 < nk) wait_vmcnt<(NST - 3) * L>();
             else wait_vmcnt<0>();
             MT2_LT(0);
-            __builtin_amdgcn_s_barrier();                            // chunk c complete; chunk c-1's stage is free
+            if (!MT2_ABL_NOBARRIER || c == 0)
+            __builtin_amdgcn_s_barrier();                        // chunk c complete; chunk c-2's stage is free
             MT2_LT(1);
 #if MT2_ABL_NOINGEST                   // ablation: no operand ingest inside the K loop
-            if (c + NST - 1 < nk && c < 1) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+            if (c >= 1 && c + NST - 2 < nk && c < 2) {
 #else
-            if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
+            if (c >= 1 && c + NST - 2 < nk) {
 #endif
+                const int cs = (c + NST - 2) % NST;
+                issue(c + NST - 2, cs);
+            }
             MT2_LT(2);
-            st = st + 1 == NST ? 0 : st + 1;
         }
         MT2_LT_END();
 #undef MT2_LT
@@ -344,7 +324,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         koffb[b][1] = (unsigned)(((4 + b * 2 + half) ^ swzb) * 16);
     }
 
-    int st = 0;
     float amax = 0.0f;
     f32x4 ra[2][TM][2];
     u32x4 rb[2][2][TN];
@@ -352,19 +331,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     // VALU per split: 4 pairs x (6 + 1 guard) = 28 (+ the prologue activation); 3 TN MFMAs per fragment carry one split
     constexpr int NMF = 3 * TN, SPLIT_VALU = 28 + (PRO == ACT_RELU || PRO == ACT_LRELU ? 8 : 0);
     constexpr int VPM = (SPLIT_VALU + NMF - 1) / NMF;
-    auto fetch = [&](int b, unsigned sa, unsigned sb) {
-        const unsigned va0 = sa + koffa[b][0], va1 = sa + koffa[b][1], vb0 = sb + koffb[b][0], vb1 = sb + koffb[b][1];
-        static_for(std::make_integer_sequence<int, TM>{}, [&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            ra[b][i][0] = lds_read_b128_imm<i * 32 * BK * 4>(va0);
-            ra[b][i][1] = lds_read_b128_imm<i * 32 * BK * 4>(va1);
-        });
-        static_for(std::make_integer_sequence<int, TN>{}, [&](auto ic) {
-            constexpr int j = decltype(ic)::value;
-            rb[b][0][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb0));
-            rb[b][1][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb1));
-        });
-    };
     // the three products of fragment (b, i) with the column tiles of k-block b: cross terms first (into the low accumulator),
     // column tiles innermost so that consecutive MFMAs never wait on each other's accumulator
     auto products = [&](int b, int i, const u32x4* pp) {
@@ -386,15 +352,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
             acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8, rb[b][0][j]), acl[i][j], 0, 0, 0);
     };
     auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
-    auto wait_block = [&](int b) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < TM; ++i) tie(b, i);
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
-    };
     auto pattern = [&]() {
 #pragma unroll
         for (int k = 0; k < NMF; ++k) {
@@ -411,16 +368,8 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         tcyc0 = __builtin_readcyclecounter();
         if (lane == 0) p.dbg[9] = treal0 - t_entry;
     }
-#ifdef MT2_PHASE_TIMING
-    // measurement build (tools/x3h_phase_timing.py): per-phase s_memtime sums of one wave.  0 LDS wait of k-block 1 (behind the first
-    // fragment's products), 1 barrier, 2 -, 3 first fragment fetch, 4 second fetch + first split, 5 products of the chunk
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = probe ? __builtin_readcyclecounter() : 0ull;
-#define MT2_T(i_) do { if (probe) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[i_] += t_ - tprev; tprev = t_; } } while (0)
-#else
-#define MT2_T(i_) do { } while (0)
-#endif
     constexpr int FS = 2 * TM;                            // fragments per chunk (two 16-deep k blocks)
-    if constexpr (XC) {
+    {
         // Cross-chunk form.  The one-barrier-per-chunk loop below starts every chunk with all eight compute waves waiting on the
         // barrier, then on the first fragment's LDS latency (all waves fetch at once), then on its split - ~750 cycles in which no wave
         // has a matrix instruction to issue, against ~780 cycles of matrix work per chunk and SIMD (profiles/r06_x3h_phase_timing_v1.txt).
@@ -522,60 +471,8 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         };
         for (int c = 0; c + 1 < nk; ++c) chunk(std::false_type{});
         chunk(std::true_type{});
-    } else
-    for (int c = 0; c < nk; ++c) {
-        const unsigned sa = a_lane + (unsigned)st * STAGE, sb = b_lane + (unsigned)st * STAGE;
-#if MT2_X3H_ABLATE == 1                           // ablation: ingest only - the compute waves just keep the
-        if (c + 1 < nk) {                                                    // barrier cadence (the last chunk runs the real body so
-            __builtin_amdgcn_s_barrier();                                    // that the accumulators stay live)
-            st = st + 1 == NST ? 0 : st + 1;
-            continue;
-        }
-#endif
-        MT2_T(5);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        MT2_T(1);
-        fetch(0, sa, sb);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_block(0);
-        __builtin_amdgcn_sched_barrier(0);
-        MT2_T(3);
-        fetch(1, sa, sb);
-        split2_f16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], amax);
-        __builtin_amdgcn_sched_barrier(0);
-        MT2_T(4);
-#pragma unroll
-        for (int s = 0; s < FS; ++s) {
-            const int b = s / TM, i = s % TM;
-            if (s + 1 < FS) {
-                const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
-                if (b2 != b) {
-                    MT2_T(5);
-                    wait_block(b2);
-                    __builtin_amdgcn_sched_barrier(0);
-                    MT2_T(0);
-                } else {
-                    tie(b2, i2);
-                }
-                split2_f16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], amax);
-                products(b, i, pln[s & 1]);
-                pattern();
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                products(b, i, pln[s & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        st = st + 1 == NST ? 0 : st + 1;
     }
     unsigned long long t_loop_end = 0;
-    MT2_T(5);
-#ifdef MT2_PHASE_TIMING
-    if (probe && lane == 0)
-        for (int i = 0; i < 6; ++i) p.dbg[i] = tacc[i];
-#endif
-#undef MT2_T
     if (probe) {
         t_loop_end = __builtin_amdgcn_s_memrealtime();
         if (lane == 0) {
@@ -1151,18 +1048,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
     { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
       gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr,                                         \
       gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, PRO_LNX> }
-#define MT2_X3H_LDR_PLAIN(BM_, BN_, WM_, WN_, NL_, NST_)                                                                    \
-    { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
-      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr, nullptr }
-
-#define MT2_X3H_LDR_XC(BM_, BN_, WM_, WN_, NL_, NST_)                                                                             \
-    { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, 1>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, 1>, \
-      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, 1>, nullptr, nullptr,                                             \
-      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, PRO_LNX, 1> }
-#define MT2_X3H_LDR_XC_PLAIN(BM_, BN_, WM_, WN_, NL_, NST_)                                                                       \
-    { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE, 1>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU, 1>, \
-      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU, 1>, nullptr, nullptr, nullptr }
-
 #define MT2_X3H_KS(BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                                          \
     { gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_NONE>, gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_RELU>, \
       gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr,                                           \
@@ -1174,20 +1059,17 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
 
 X3hKernel x3h_kernel(int tile, int variant) {
     static void (*const kTable[kX3hTiles][6])(GemmP) = {
-        MT2_X3H_LDR(128, 128, 4, 2, 4, 3),          // X3H_LDR_128x128: 8 compute + 4 loader waves, 3 x 32 KiB (+ PRO_LNX)
-        // 64x64 per wave needs 2 x 64 accumulator registers: more than the 168 of a 12-wave workgroup (a 256x128 tile of 8 + 4 waves
-        // spills inside the K loop) - ONE compute wave per SIMD + 4 loaders = 8 waves, 211 registers, no spill; 4-deep ring (128 KiB)
-        MT2_X3H_LDR_PLAIN(128, 128, 2, 2, 4, 4),    // X3H_LDR_128x128_W4_S4
+        // X3H_LDR_128x128: 8 compute + 4 loader waves, 4 x 32 KiB (+ PRO_LNX).  Retired beside it in round 6, each measured slower on
+        // every shape of the model (profiles/r06_gemm_sweep_x3hxc_v2_buffer_loads.txt): the one-barrier-per-chunk loop of the same
+        // tile (3 x 32 KiB), the cross-chunk form with a 3-deep ring (one chunk-time of DMA latency), and the 64x64-per-wave forms
+        // (one compute wave per SIMD + 4 loaders, 211..227 registers) in both loops
+        MT2_X3H_LDR(128, 128, 4, 2, 4, 4),
         MT2_X3H_KS(32, 64, 1, 2, 4, 8, 2),          // X3H_KS_32x64_K4: the 84 tile (8 compute + 8 loader waves)
         MT2_X3H_KS(64, 64, 2, 2, 2, 8, 3),          // X3H_KS_64x64_K2: the 85 tile
         MT2_X3H_KS(32, 32, 1, 1, 8, 8, 2),          // X3H_KS_32x32_K8: the 86 tile
         MT2_X3H_WIN(2, 256, 64, 8, 1, 3, 4),        // X3H_WIN_256x64: the 58 tile (8 compute + 4 loader waves)
         MT2_X3H_WIN(4, 128, 128, 4, 2, 2, 4),       // X3H_WIN_128x128: the 59 tile
-        MT2_X3H_LDR_XC(128, 128, 4, 2, 4, 4),       // X3H_LDR_128x128_XC4: cross-chunk fragment pipeline, 4 x 32 KiB
-        MT2_X3H_LDR_XC(128, 128, 4, 2, 4, 3),       // X3H_LDR_128x128_XC3
-        MT2_X3H_LDR_XC_PLAIN(128, 128, 2, 2, 4, 4), // X3H_LDR_128x128_W4_XC4
-        // (measured and not kept, round 6: the 8 + 4 tile with a 4-deep ring - no gain; the 4 + 4 tile with a 3-deep ring - the
-        // 4-deep one is never slower; the 32-channel window convolution - 3..19 % slower than its x6 form)
+        // (measured and not kept, round 6: the 32-channel window convolution - 3..19 % slower than its x6 form)
     };
     if (tile < 0 || tile >= kX3hTiles || variant < 0 || variant >= 6) return nullptr;
     return kTable[tile][variant];

@@ -101,12 +101,11 @@ struct EngineOpts {
     bool x6_conv = true;         // ... on the bf16 matrix pipe, f32-equivalent 3-way split (6 products), where W3 planes exist
     bool x6_gemm = true;         // the implicit GEMMs likewise (loader-wave and K-split tiles)
     bool x6_splitk = true;       // K slices (through the next LayerNorm) to give the N = d AR GEMMs enough x6 tiles
-    int x3h = 15;                // f32-equivalent THREE-product form on the fp16 pipe (gemm_x3h.hip) wherever an x6 tile has one and the
-                                 // weights come with fp16 planes (GemmP::Wh); bits: 1 the 128x128 loader tiles, 2 the K-split tiles of the
-                                 // AR steps, 4 the window convolutions, 8 the loader tile in its cross-chunk form; 0: everything stays x6
+    int x3h = 7;                 // f32-equivalent THREE-product form on the fp16 pipe (gemm_x3h.hip) wherever an x6 tile has one and the
+                                 // weights come with fp16 planes (GemmP::Wh); bits: 1 the 128x128 loader tile, 2 the K-split tiles of the
+                                 // AR steps, 4 the window convolutions; 0: everything stays x6
     int* x3h_flag = nullptr;     // device word of the range guard (GemmP::x3h_flag); the model handle owns one
     int t_x3h_128 = 72;          // x3h: from this many 128x128 tiles on the loader tile instead of the K-split tiles (t_x6_128's role)
-    int t_x3h_w4 = 400, x3h_w4_mink = 1536;   // x3h: from this many 128x128 tiles and this K on the 64x64-per-wave form (tile 94) instead of 91
     int t_x6_256 = 160, t_x6_128 = 72;   // ... from this many 256x128 / 128x128 tiles on (profiles/r02_gemm_sweep_x6.txt)
     int x6_ks = 4;               // x6 arithmetic + eight loader waves for the AR steps' K-split tiles (gemm_x6_ks_kernel): 0 off;
                                  // 1, 3: the 32x64 k4 and 64x64 k2/k4 tiles (84, 85); 2, 4: + the 32x32 k8 tile (86); 5: the
@@ -147,8 +146,7 @@ struct EngineOpts {
 hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
 // gemm_x3h.hip: the kernels of the fp16-pipe form by tile id and variant (prologue none / relu / leaky relu / - / - / pair statistics);
 // nullptr: no such variant
-enum X3hTile : int { X3H_LDR_128x128 = 0, X3H_LDR_128x128_W4_S4, X3H_KS_32x64_K4, X3H_KS_64x64_K2, X3H_KS_32x32_K8, X3H_WIN_256x64,
-                     X3H_WIN_128x128, X3H_LDR_128x128_XC4, X3H_LDR_128x128_XC3, X3H_LDR_128x128_W4_XC4, kX3hTiles };
+enum X3hTile : int { X3H_LDR_128x128 = 0, X3H_KS_32x64_K4, X3H_KS_64x64_K2, X3H_KS_32x32_K8, X3H_WIN_256x64, X3H_WIN_128x128, kX3hTiles };
 typedef void (*X3hKernel)(GemmP);
 X3hKernel x3h_kernel(int tile, int variant);
 // gemm_skinny.hip: weight-streaming linear layer for M <= 64 rows (taps = 1, no rowbase, K a multiple of 32)

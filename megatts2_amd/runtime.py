@@ -775,7 +775,7 @@ def op_gemm_x6_ln(X, W, bias=None, R=None, M=None, a_mul=1, shift0=0, epi_act=AC
         ln_nt = pairs.shape[1]
     W = W.contiguous()
     W3 = split_bf16x3(W).to(dev)
-    if x3h:      # the same launch with the fp16 planes as well (mt2_op_gemm_x3h_ln): the fp16-pipe tiles 91 / 92
+    if x3h:      # the same launch with the fp16 planes as well (mt2_op_gemm_x3h_ln): the fp16-pipe tiles 103 / 95-97
         ph, inv = split_f16x2_rows(W)
         ph, inv = ph.to(dev), inv.to(dev)
         _check(lib.mt2_op_gemm_x3h_ln(_stream(), _ptr(X), K, X.shape[0], a_mul, shift0, _ptr(W), _ptr(W3), _ptr(ph), _ptr(inv),

@@ -32,15 +32,15 @@ if mode == "x6":       # the bf16-pipe (f32-equivalent) configurations against t
               ("plm_ff1", 864, 1024, 4096, 1), ("plm_out", 1728, 1024, 1024, 1), ("adm_qkv", 2240, 2304, 768, 1),
               ("adm_qkv", 1120, 2304, 768, 1), ("adm_ff0", 2240, 1024, 768, 1), ("adm_out", 2240, 768, 768, 1),
               ("big", 4096, 4096, 4096, 1)]
-elif mode == "x3h":    # round 6: the fp16-pipe three-product tiles (91-94) against the x6 loader tiles they replace (55, 51) - VERDICT r5 gate shapes first
-    cfgs = [55, 91, 94, 51]
+elif mode == "x3h":    # round 6: the fp16-pipe three-product loader tile (103; 91-94 until they were retired) against the x6 loader tiles they replace (55, 51) - VERDICT r5 gate shapes first
+    cfgs = [55, 103, 51]
     shapes = [("plm_ff0", 864, 4096, 1024, 1), ("big", 4096, 4096, 4096, 1), ("plm_ff0", 1728, 4096, 1024, 1), ("plm_ff0", 432, 4096, 1024, 1),
               ("plm_qkv", 1728, 3072, 1024, 1), ("plm_qkv", 864, 3072, 1024, 1), ("plm_ff1", 1728, 1024, 4096, 1),
               ("plm_ff1", 864, 1024, 4096, 1), ("plm_out", 1728, 1024, 1024, 1), ("adm_qkv", 2240, 2304, 768, 1),
               ("adm_qkv", 1120, 2304, 768, 1), ("adm_ff0", 2240, 1024, 768, 1), ("adm_out", 2240, 768, 768, 1),
               ("mrte_stack", 14064, 512, 1536, 3), ("decoder", 13858, 512, 2560, 5), ("vqpe", 13858, 384, 1920, 5),
               ("hifi_s1", 111000, 256, 1792, 7), ("hifi_s1k11", 111000, 256, 2816, 11)]
-elif mode == "x3hxc":  # round 6: the loader tiles with the fragment pipeline across the chunk boundary (103-105) against 91 / 94
+elif mode == "x3hxc":  # round 6: the loader tiles with the fragment pipeline across the chunk boundary (103-105) against 91 / 94 (all but 103 retired since)
     cfgs = [91, 103, 104, 94, 105]
     shapes = [("plm_ff0", 864, 4096, 1024, 1), ("big", 4096, 4096, 4096, 1), ("plm_ff0", 1728, 4096, 1024, 1), ("plm_ff0", 432, 4096, 1024, 1),
               ("plm_qkv", 864, 3072, 1024, 1), ("plm_ff1", 864, 1024, 4096, 1), ("plm_out", 1728, 1024, 1024, 1),
@@ -53,7 +53,7 @@ elif mode == "x3hk_short":   # the K-split x3h tiles alone at a few AR shapes (v
               ("plm_out", 448, 1024, 1024, 1), ("plm_out", 864, 1024, 1024, 1), ("adm_qkv", 280, 2304, 768, 1), ("adm_out", 1120, 768, 768, 1),
               ("adm_ff1", 1120, 768, 1024, 1)]
 elif mode == "x3hk":   # round 6: the K-split tiles on the fp16 pipe (95-97) against their x6 forms (84-86) and the 128x128 tiles
-    cfgs = [84, 95, 85, 96, 86, 97, 55, 91]
+    cfgs = [84, 95, 85, 96, 86, 97, 55, 103]
     shapes = [("plm_qkv", 96, 3072, 1024, 1), ("plm_qkv", 224, 3072, 1024, 1), ("plm_qkv", 448, 3072, 1024, 1), ("plm_qkv", 672, 3072, 1024, 1),
               ("plm_ff0", 224, 4096, 1024, 1), ("plm_ff0", 448, 4096, 1024, 1), ("plm_ff0", 672, 4096, 1024, 1),
               ("plm_ff1", 224, 1024, 4096, 1), ("plm_ff1", 448, 1024, 4096, 1), ("plm_ff1", 864, 1024, 4096, 1),

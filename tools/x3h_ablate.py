@@ -8,7 +8,7 @@ from megatts2_amd import runtime as rt
 
 rt.device_check()
 LABEL = sys.argv[1] if len(sys.argv) > 1 else "prod"
-CASES = [(name, M, N, K, taps, cfg) for cfg in (91, 103) for name, M, N, K, taps in
+CASES = [(name, M, N, K, taps, cfg) for cfg in (103,) for name, M, N, K, taps in
          [("big", 4096, 4096, 4096, 1), ("plm_ff0", 864, 4096, 1024, 1), ("plm_qkv", 448, 3072, 1024, 1), ("adm_qkv", 1120, 2304, 768, 1),
           ("adm_out", 2240, 768, 768, 1), ("decoder", 13858, 512, 2560, 5), ("hifi_s1", 111000, 256, 1792, 7)]]
 for name, M, N, K, taps, cfg in CASES:

@@ -7,9 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from megatts2_amd import runtime as rt
 
 rt.device_check()
-CASES = [("adm_qkv", 280, 2304, 768, 96), ("adm_qkv", 560, 2304, 768, 96), ("adm_qkv", 1120, 2304, 768, 91), ("adm_ff0", 560, 1024, 768, 96),
+CASES = [("adm_qkv", 280, 2304, 768, 96), ("adm_qkv", 560, 2304, 768, 96), ("adm_qkv", 1120, 2304, 768, 103), ("adm_ff0", 560, 1024, 768, 96),
          ("adm_ff0", 1120, 1024, 768, 96), ("adm_out", 560, 768, 768, 95), ("adm_out", 1120, 768, 768, 96), ("adm_ff1", 1120, 768, 1024, 96),
-         ("plm_qkv", 224, 3072, 1024, 96), ("plm_qkv", 448, 3072, 1024, 91), ("plm_qkv", 864, 3072, 1024, 91), ("plm_ff0", 864, 4096, 1024, 91),
+         ("plm_qkv", 224, 3072, 1024, 96), ("plm_qkv", 448, 3072, 1024, 103), ("plm_qkv", 864, 3072, 1024, 103), ("plm_ff0", 864, 4096, 1024, 103),
          ("plm_out", 448, 1024, 1024, 95), ("plm_out", 864, 1024, 1024, 96), ("plm_ff1s", 864, 1024, 1024, 96), ("plm_out", 224, 1024, 1024, 97)]
 for name, M, N, K, cfg in CASES:
     for flags in (4, 4 | 2):

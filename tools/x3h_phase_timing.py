@@ -6,9 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from megatts2_amd import runtime as rt
 
 rt.device_check()
-for name, M, N, K, taps, cfg in [("plm_ff0", 864, 4096, 1024, 1, 91),
+for name, M, N, K, taps, cfg in [("plm_ff0", 432, 4096, 1024, 1, 103),
                                  ("plm_ff0", 864, 4096, 1024, 1, 103), ("adm_qkv", 1120, 2304, 768, 1, 103), ("big", 4096, 4096, 4096, 1, 103),
-                                 ("decoder", 13858, 512, 2560, 5, 103), ("plm_ff0", 864, 4096, 1024, 1, 104), ("plm_ff0", 864, 4096, 1024, 1, 105),
+                                 ("decoder", 13858, 512, 2560, 5, 103), 
                                  ("plm_ff0", 224, 4096, 1024, 1, 96), ("plm_out", 864, 1024, 1024, 1, 96), ("adm_qkv", 280, 2304, 768, 1, 96),
                                  ("plm_ff1", 448, 1024, 4096, 1, 95), ("plm_out", 448, 1024, 1024, 1, 95), ("plm_out", 224, 1024, 1024, 1, 97)]:
     ms, cn, ghz = rt.bench_gemm(M, N, K, taps=taps, force_cfg=cfg, iters=4, w_copies=2, flags=4)

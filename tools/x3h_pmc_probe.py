@@ -4,7 +4,7 @@ ordered and the summary groups by dispatch order:  python tools/x3h_pmc_probe.py
 import sys, os, csv, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CASES = [(name, M, N, K, taps, cfg) for name, M, N, K, taps in
-         [("plm_ff0", 864, 4096, 1024, 1), ("big", 4096, 4096, 4096, 1), ("decoder", 13858, 512, 2560, 5)] for cfg in (91, 103, 94)]
+         [("plm_ff0", 864, 4096, 1024, 1), ("big", 4096, 4096, 4096, 1), ("decoder", 13858, 512, 2560, 5)] for cfg in (103,)]
 ITERS = 3
 if len(sys.argv) > 2 and sys.argv[1] == "summary":
     rows = [r for r in csv.DictReader(open(sys.argv[2])) if "gemm_x3h_ldr_kernel" in r["Kernel_Name"]]

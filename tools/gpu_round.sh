@@ -128,6 +128,13 @@ profstage)
 bench1)
   timeout 600 python bench.py --workload C1 --steps 5 --warmup 2 > gpurun_out/bench_c1.log 2>&1
   echo "bench1 rc=$?"; tail -1 gpurun_out/bench_c1.log | cut -c1-1200 ;;
+conc)
+  # kernel concurrency per stage of one C3 step (tools/trace_concurrency.py on a kernel trace with stage markers)
+  rm -rf gpurun_out/conc
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace -f csv -d $GRAFT_REPO_ROOT/gpurun_out/conc -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-sub-workloads --stage-markers ${CONC_OPT:-}) > gpurun_out/conc.log 2>&1
+  echo "conc rc=$?"; f=$(find gpurun_out/conc -name "*kernel_trace.csv" | head -1)
+  [ -n "$f" ] && python tools/trace_concurrency.py "$f" | tee gpurun_out/trace_concurrency.txt
+  find gpurun_out/conc -name "*.csv" -size +2M -delete ;;
 prof3)
   rm -rf gpurun_out/prof3
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/gpurun_out/prof3 -o bench -- python $GRAFT_REPO_ROOT/bench.py --workload C3 --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-sub-workloads) > gpurun_out/prof3.log 2>&1

@@ -24,14 +24,14 @@ rep = {
 # dominant kernel from the kernel stats (2 steps traced)
 rows = list(csv.DictReader(open('profiles/r06_c3_kernel_stats.csv')))
 tot = sum(float(r["TotalDurationNs"]) for r in rows) / 2e6
-dom = [r for r in rows if "gemm_x3h_ldr_kernel<128, 128, 4, 2, 4, 3" in r["Name"]]
+dom = [r for r in rows if "gemm_x3h_ldr_kernel<128, 128, 4, 2, 4, 4" in r["Name"]]
 dcalls = sum(int(r["Calls"]) for r in dom) / 2
 dms = sum(float(r["TotalDurationNs"]) for r in dom) / 2e6
 pc = {r["config"]: r for r in rf["per_config"]}
-r91 = pc.get("x3hldr128x128_4x2+4_s3", {})
+r91 = pc.get("x3hldr128x128_4x2+4_s4xc", {})
 rep["@DOMK@"] = (f"{dcalls:.0f} launches per step, {dms:.1f} ms of kernel time per step ({dms * 1e3 / max(dcalls, 1):.1f} µs average); the traced step of this run "
-                 f"prices its launches at {r91.get('tflops', 0):.0f} TF/s while two chains share the chip (isolated: 208 TF/s at 864×4096×1024 = 0.25 of 833.3, "
-                 f"0.43 of the ceiling at the 1.9–2.0 GHz such launches sustain)")
+                 f"prices its launches at {r91.get('tflops', 0):.0f} TF/s while two chains share the chip (isolated: 243 TF/s at 864×4096×1024 = 0.29 of 833.3, "
+                 f"0.36 of the ceiling at the 1.9–2.0 GHz such launches sustain)")
 rep["@SUMK@"] = f"{tot:.0f}"
 pm = json.load(open('profiles/r06_pmc_c3_latest.json'))
 ws = pm["whole_step"]

@@ -1938,6 +1938,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     const int tiles = ((p.M + c->bm - 1) / c->bm) * ((p.N + c->bn - 1) / c->bn);
     p.epi_t4 = o.epi_t4 ? 1 : 0;
     p.ldr_prio = o.ldr_prio;
+    p.ldr64 = o.ldr64 ? 1 : 0;
     dim3 grid(tiles, 1, p.groups), block(c->threads);
     if (opts) opts->last_cfg = c->name;
     if (opts && opts->trace_on) {

@@ -150,7 +150,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         // global_load form below (v_mad_i64, compares, selects: ~10 VALU instructions per piece, ~950 cycles per chunk and loader
         // wave on the SIMDs the compute waves split their fragments on) was the longest phase of a loader's chunk
         // (profiles/r06_x3h_phase_timing_v3_loader.txt).
-        const bool fast32 = MT2_BUFFER_LOADS && fast && (long long)Rx * ldx * 4 + (long long)Kt * 4 < 0x7fffffffll && (long long)p.N * p.wh_ldb < 0x7fffffffll;
+        const bool fast32 = MT2_BUFFER_LOADS && !p.ldr64 && fast && (long long)Rx * ldx * 4 + (long long)Kt * 4 < 0x7fffffffll && (long long)p.N * p.wh_ldb < 0x7fffffffll;
         constexpr unsigned kOut = 0x80000000u;
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, (int)kOut, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wh), 0, (int)kOut, 0x00020000);
@@ -583,7 +583,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
         // operands below 2 GiB: buffer loads - per piece a 32-bit lane offset (row + slot + the K group's chunk), the round as the
         // scalar offset, zero rows as the out-of-range offset 2^31 (gemm_x3h_ldr_kernel's loader, above)
         constexpr unsigned kOut = 0x80000000u;
-        const bool fast32 = MT2_BUFFER_LOADS && (long long)p.Rx * p.ldx * 4 + (long long)p.K * 4 < 0x7fffffffll && (long long)p.N * p.wh_ldb < 0x7fffffffll;
+        const bool fast32 = MT2_BUFFER_LOADS && !p.ldr64 && (long long)p.Rx * p.ldx * 4 + (long long)p.K * 4 < 0x7fffffffll && (long long)p.N * p.wh_ldb < 0x7fffffffll;
         const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Xb), 0, (int)kOut, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wb), 0, (int)kOut, 0x00020000);
         unsigned vo[LW];
@@ -851,7 +851,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
     }
     // weights below 2 GiB: buffer loads (32-bit lane offset, the chunk as the scalar offset, rows beyond N out of range = zeros)
     constexpr unsigned kOut = 0x80000000u;
-    const bool fast32 = MT2_BUFFER_LOADS && (long long)p.N * p.wh_ldb < 0x7fffffffll;
+    const bool fast32 = MT2_BUFFER_LOADS && !p.ldr64 && (long long)p.N * p.wh_ldb < 0x7fffffffll;
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(Wh), 0, (int)kOut, 0x00020000);
     unsigned vob[B_IT];
 #pragma unroll

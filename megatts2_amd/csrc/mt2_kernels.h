@@ -48,6 +48,7 @@ struct GemmP {
     unsigned long long* dbg = nullptr;   // MT2_PHASE_TIMING builds only: per-phase cycle sums of one wave (tools/x6_phase_timing.py)
     int epi_t4 = 1;             // 16-byte-store epilogue where the layout allows it (set by launch_gemm from EngineOpts::epi_t4)
     int sk_nw = 8;              // gemm_skinny_tm_kernel: waves per workgroup that split K (8; 16 = option skinny_nw, set by launch_gemm)
+    int ldr64 = 0;              // x3h loaders: 1 = the 64-bit global_load_lds form even where buffer loads would do (EngineOpts::ldr64)
     int ldr_prio = 0;           // s_setprio of the loader waves of the loader-wave kernels (set by launch_gemm from EngineOpts::ldr_prio)
     const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like
     long long w3_plane = 0;     // W (same ldw / strideW, in bf16 elements), planes w3_plane elements apart (0: N * ldw) -
@@ -112,6 +113,7 @@ struct EngineOpts {
                                  // 64x64 tile only.  Default 4: isolated launches +10..50 %
                                  // (profiles/r03_gemm_sweep_x6k.txt), C3 step -1.6 % (profiles/r03_ab_interleaved_v1.txt)
     bool epi_t4 = true;          // DPP-transposed 16-byte-store epilogue for wave tiles without epilogue prefetch
+    bool ldr64 = false;          // tests / measurement: the x3h loaders' 64-bit global_load_lds form (what operands of 2 GiB or more get)
     int ldr_prio = 3;            // issue priority (s_setprio 0..3) of the loader waves (gemm_x6_ldr / gemm_x6_ks / conv_win_x6 kernels)
     int skinny_rows = 64;        // linear layers with at most this many rows (<= 64) run on the weight-streaming kernel of
     int attn_lds_min = 640;      // attention: from this many queries per sequence on the LDS-tiled kernel (AttnP::lds_min_qlen; 0 never)

@@ -325,6 +325,34 @@ def test_gemm_x3h_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
     assert w3 <= 2.0 * w32 + 2.0 ** -23, (w3, w32)
 
 
+@pytest.mark.parametrize("cfg,M,N,taps,cin,dil", [(103, 300, 512, 1, 256, 1), (103, 1000, 384, 5, 384, 1), (103, 515, 256, 7, 256, 3),
+                                                 (96, 200, 192, 1, 512, 1), (95, 77, 320, 1, 1024, 1), (97, 150, 96, 1, 768, 1),
+                                                 (99, 2000, 64, 7, 64, 3), (100, 1500, 128, 3, 128, 5)])
+def test_gemm_x3h_loader_address_forms_agree_bit_for_bit(rt, cfg, M, N, taps, cin, dil):
+    """Round 6: the x3h loaders move their pieces with BUFFER loads (32-bit lane offset computed once per tap, the K walk in the
+    instruction's scalar offset, rows outside the operand as the out-of-range offset = zeros) and keep the 64-bit global_load_lds
+    form for operands of 2 GiB or more.  Both forms deliver the same bytes: the same launch with configuration + 1000 (the 64-bit
+    form forced) is bit-identical - M / N tails (zero rows), halo rows of a dilated convolution above and below the operand, masked
+    rows - on the loader tile, the K-split tiles and the window convolutions."""
+    rng = np.random.default_rng(cfg + M + N + taps)
+    K = taps * cin
+    G = ((taps - 1) // 2) * dil
+    X = rng.standard_normal((M, cin)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+    valid = (rng.random(M) > 0.1).astype(np.int32)
+    kw = dict(valid=dev(valid), shift0=-G, taps=taps, dil=dil, Cin=cin, pro_act=rt.ACT_LRELU, pro_slope=0.1, epi_act=rt.ACT_NONE)
+    a = rt.op_conv_x3h(dev(X), dev(W), dev(b), dev(R), force_cfg=cfg, **kw).cpu().numpy()
+    c = rt.op_conv_x3h(dev(X), dev(W), dev(b), dev(R), force_cfg=cfg + 1000, **kw).cpu().numpy()
+    assert np.isfinite(a).all() and np.array_equal(a, c)
+    xp = np.zeros((M + 2 * G, cin), np.float64)
+    xp[G:G + M] = np.where(X > 0, X, 0.1 * X)
+    ref = sum(xp[t * dil:t * dil + M] @ W[:, t * cin:(t + 1) * cin].T.astype(np.float64) for t in range(taps))
+    ref = (ref + b + R) * valid[:, None]
+    assert rel(a, ref) < 2e-6
+
+
 @pytest.mark.parametrize("cfg", [103, 96])
 def test_gemm_x3h_range_guard_and_corner_cases(rt, cfg):
     """The fp16 form's range behaviour, documented in gemm_x3h.hip: (1) activations up to 6e4 and weights of any magnitude (1e-30

@@ -1650,8 +1650,8 @@ static const TileCfg kCfgs[] = {
     MT2_X3HK(X3H_KS_32x32_K8, 32, 32, 1, 1, 8, 8, 2),             // 97: the 86 tile, 128 KiB
     // ... and the window convolutions of the vocoder's resblocks (conv_win_x3h_kernel)
     MT2_RETIRED("x3hwin256x32_8x1+0_s3"),                   // 98: the 34 tile
-    MT2_X3HW(X3H_WIN_256x64, 2, 256, 64, 8, 1, 3, 4),             // 99: the 58 tile
-    MT2_X3HW(X3H_WIN_128x128, 4, 128, 128, 4, 2, 2, 4),           // 100: the 59 tile
+    MT2_X3HW(X3H_WIN_256x64, 2, 256, 64, 8, 1, 4, 4),             // 99: the 58 tile
+    MT2_X3HW(X3H_WIN_128x128, 4, 128, 128, 4, 2, 3, 4),           // 100: the 59 tile
     // ... the loader tiles with ONE barrier per 64-deep super-chunk (4 stages = 2 super-stages, 128 KiB): +1 % isolated, +2.4 % SLOWER
     // in the model (profiles/r06_experiment_x3h_superchunk.patch)
     MT2_RETIRED("x3hldr128x128_4x2+4_s4c2"),                // 101: the 91 tile

@@ -788,22 +788,23 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
 // The WINDOW convolution (conv_win_x6_kernel, gemm_f32.hip: narrow square "same" convolutions of the vocoder's resblocks, Cin =
 // Cout = 32 QS; the f32 input window of the row tile sits in LDS once, the weights stream through the ring) in the x3h form: the
 // weights arrive as two fp16 planes (2 x BN x 64 B per chunk), every A fragment is split into two fp16 planes in registers.
-// NL > 0: NL loader waves refill the weight ring (and help load the window).
+// NL loader waves refill the weight ring (and help load the window); the compute waves' fragment pipeline runs across the chunk
+// barrier (gemm_x3h_ldr_kernel's cross-chunk form).
 template <int QS, int BM, int BN, int WGM, int WGN, int NST, int PRO, int NL>
 __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(GemmP p) {
     constexpr int NW = WGM * WGN;
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int BPIECES = BN / 8;                       // 1-KiB pieces of one weight chunk: 8 rows x 128 B ([hi | lo] blocks)
-    constexpr int NI = NL > 0 ? NL : NW;                  // waves that issue the ring refill
+    constexpr int NI = NL;                                // waves that issue the ring refill: the NL loader waves
     constexpr int B_IT = (BPIECES + NI - 1) / NI;
     constexpr int STAGE_B = B_IT * NI * 1024;             // BYTES per ring stage (dummy slots included)
-    static_assert(WTM % 32 == 0 && WTN % 32 == 0 && NST >= 2 && (NST - 2) * B_IT < 64 && BN == 32 * QS, "config");
+    static_assert(NL > 0 && WTM % 32 == 0 && WTN % 32 == 0 && NST >= 3 && (NST - 2) * B_IT < 64 && BN == 32 * QS, "config");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = NL > 0 && wave_all >= NW;
+    const bool loader = wave_all >= NW;
     const int wave = loader ? wave_all - NW : wave_all;   // index among the loaders / among the compute waves
     const int wm = wave / WGN, wn = wave % WGN;
     const int taps = p.taps, dil = p.dil;
@@ -871,26 +872,27 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
                                              (__attribute__((address_space(3))) void*)(Bs + j * NI * 1024), 16, 0, 0);
         }
     };
-    if (NL > 0 && loader) {        // ---- loader wave: window pieces above, then nothing but the ring
+    if (loader) {                  // ---- loader wave: window pieces above, then nothing but the ring
         loader_priority(p.ldr_prio);
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < nk) issue(st, st);
-        int st = 0;
+        // cross-chunk form (the compute waves' K loop below, gemm_x3h_ldr_kernel's): at barrier c the weights of chunk c-1 are still
+        // being read - the stage that is free is chunk c-2's, and chunk c + NST - 2 goes there
+        static_assert(NST >= 3, "cross-chunk form: chunk c-1 is still being read at barrier c");
         for (int c = 0; c < nk; ++c) {
-            if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * B_IT>();   // window pieces (older) and chunk c have landed
+            if (c == 0) { if (NST - 2 < nk) wait_vmcnt<(NST - 2) * B_IT>(); else wait_vmcnt<0>(); }   // window pieces (older) and chunk 0
+            else if (c + NST - 3 < nk) wait_vmcnt<(NST - 3) * B_IT>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
-            st = st + 1 == NST ? 0 : st + 1;
+            if (c >= 1 && c + NST - 2 < nk) issue(c + NST - 2, (c + NST - 2) % NST);
         }
         return;
     }
-    // (the 16-byte-store epilogue that pays in the loader-wave GEMM measured SLOWER here - 128 channels with residual 1 109 vs 1 029 us,
-    // 64 channels 763 vs 661: these launches need the residual in flight during the K loop; profiles/r06_vocx_win_t4_epilogue.txt)
-    constexpr bool PRET = TM * TN <= 2;
-    EpiPreT<PRET ? TM : 1, PRET ? TN : 1> pret;
-    if constexpr (PRET) epi_prefetch_t<TM, TN>(p, pret, 0, m0 + wm * WTM, wn * WTN, lane);
+    // (No epilogue operand is requested before or during the K loop.  The one-barrier-per-chunk loop this kernel had until round 6
+    // prefetched bias / residual / row masks there - 50 registers that did not fit beside the fragment pipeline: hipcc spilled them
+    // one by one, each load behind its own vmcnt(0), and reloaded them one by one in the epilogue, ~10 us per tile once the pipeline
+    // below took the registers.  The 16-byte-store epilogue issues all its operand loads together at its start instead.)
     float inv_s[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -906,13 +908,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; acl[i][j][e] = 0.0f; }
 
-    if constexpr (NL == 0) {
-#pragma unroll
-        for (int st = 0; st < NST - 1; ++st)
-            if (st < nk) issue(st, st);
-    } else {
-        wait_vmcnt<0>();               // this compute wave's window pieces, before the first barrier
-    }
+    wait_vmcnt<0>();                   // this compute wave's window pieces, before the first barrier
 
     const float pro_slope = p.pro_slope;
     const int half = lane >> 5;
@@ -931,106 +927,133 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
     const int arow0 = wm * WTM + (lane & 31);
     float amax = 0.0f;
 
-    int st = 0, tap = 0, q = 0;
-    for (int c = 0; c < nk; ++c) {
-        if constexpr (NL == 0) {
-            if (c + NST - 2 < nk) wait_vmcnt<(NST - 2) * B_IT>();
-            else wait_vmcnt<0>();
+    // Cross-chunk fragment pipeline, as in gemm_x3h_ldr_kernel (its comment has the protocol): the stream of k blocks q = 2 c + b is
+    // pipelined without regard to chunks - step (q, i) = split of the next fragment || products of fragment (q, i); A(q+2) comes from
+    // the resident window at the start of step (q, TM-1) (behind the barrier "the weights of chunk c+1 have landed" when q is even),
+    // B(q+2) from the ring at its end.  The one-barrier-per-chunk loop this replaces started every chunk with all eight compute waves
+    // waiting on the barrier, the first fragment's LDS latency and its split before the first matrix instruction.
+    constexpr int FS = 2 * TM, NMF = 3 * TN, SPLIT_VALU = 28 + (PRO == ACT_RELU || PRO == ACT_LRELU ? 8 : 0);
+    constexpr int VPM = (SPLIT_VALU + NMF - 1) / NMF, N1 = 2 * TM + 2 * TN;
+    static_assert(N1 <= 15, "lgkmcnt is four bits wide");
+    f32x4 ra[2][TM][2];
+    u32x4 rb[2][2][TN];
+    u32x4 pln[2][2];
+    // (sa, swza): window address and slot swizzle of the A rows of a chunk = (tap, q)
+    auto fetch_a = [&](int b, unsigned sa, int swza) __attribute__((always_inline)) {
+        const unsigned va0 = sa + (unsigned)(((b * 4 + half * 2) ^ swza) * 16), va1 = sa + (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
+        static_for(std::make_integer_sequence<int, TM>{}, [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            ra[b][i][0] = lds_read_b128_imm<i * 32 * BK * 4>(va0);
+            ra[b][i][1] = lds_read_b128_imm<i * 32 * BK * 4>(va1);
+        });
+    };
+    auto fetch_b = [&](int b, unsigned sb) __attribute__((always_inline)) {
+        const unsigned vb0 = sb + koffb[b][0], vb1 = sb + koffb[b][1];
+        static_for(std::make_integer_sequence<int, TN>{}, [&](auto ic) {
+            constexpr int j = decltype(ic)::value;
+            rb[b][0][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb0));
+            rb[b][1][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb1));
+        });
+    };
+    auto products = [&](int b, int i, const u32x4* pp) __attribute__((always_inline)) {
+        const f16x8 Ah = __builtin_bit_cast(f16x8, pp[0]), Al = __builtin_bit_cast(f16x8, pp[1]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][1][j]), acl[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][0][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8, rb[b][0][j]), acl[i][j], 0, 0, 0);
+    };
+    auto tie = [&](int b, int i) __attribute__((always_inline)) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
+    auto tie_a = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) tie(b, i);
+    };
+    auto tie_b = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
+    };
+    auto pattern = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NMF; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
         }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const int arow = arow0 + tap * dil;
+    };
+    __builtin_amdgcn_s_barrier();                         // the window and the weights of chunk 0 have landed
+    asm volatile("" ::: "memory");
+    {
+        const unsigned sa0 = lds_win + (unsigned)(arow0 * BK) * 4;
+        const int swz0 = (arow0 >> 1) & 7;
+        fetch_a(0, sa0, swz0); fetch_b(0, b_lane); fetch_a(1, sa0, swz0); fetch_b(1, b_lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N1) : "memory");
+    tie_a(0); tie_b(0);
+    split2_f16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], amax);
+    __builtin_amdgcn_sched_barrier(0);
+    int stn = 1 % NST, tapn = 0, qn = 1;                  // chunk c + 1: its ring stage, tap and 32-channel slice
+    if (qn == QS) { qn = 0; tapn = 1; }
+    auto chunk = [&](auto last_c) __attribute__((always_inline)) {
+        constexpr bool last = decltype(last_c)::value;
+        const int arow = arow0 + tapn * dil;
         const int swza = (arow >> 1) & 7;
-        const unsigned sa = lds_win + (unsigned)((q * WRp + arow) * BK) * 4;
-        const unsigned sb = b_lane + (unsigned)st * STAGE_B;
-        // the stage consumed in the previous iteration is free once everyone has passed the barrier: refill it first
-        if (NL == 0 && c + NST - 1 < nk) issue(c + NST - 1, st == 0 ? NST - 1 : st - 1);
-        f32x4 ra[2][TM][2];
-        u32x4 rb[2][2][TN];
-        auto fetch = [&](int b) {
-            const unsigned va0 = sa + (unsigned)(((b * 4 + half * 2) ^ swza) * 16), va1 = sa + (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
-            const unsigned vb0 = sb + koffb[b][0], vb1 = sb + koffb[b][1];
-            static_for(std::make_integer_sequence<int, TM>{}, [&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                ra[b][i][0] = lds_read_b128_imm<i * 32 * BK * 4>(va0);
-                ra[b][i][1] = lds_read_b128_imm<i * 32 * BK * 4>(va1);
-            });
-            static_for(std::make_integer_sequence<int, TN>{}, [&](auto ic) {
-                constexpr int j = decltype(ic)::value;
-                rb[b][0][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb0));
-                rb[b][1][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb1));
-            });
-        };
-        constexpr int F = 2 * TM, NMF = 3 * TN, SPLIT_VALU = 28 + (PRO == ACT_RELU || PRO == ACT_LRELU ? 8 : 0);
-        constexpr int VPM = (SPLIT_VALU + NMF - 1) / NMF;
-        u32x4 pln[2][2];
-        auto products = [&](int b, int i, const u32x4* pp) {
-            const f16x8 Ah = __builtin_bit_cast(f16x8, pp[0]), Al = __builtin_bit_cast(f16x8, pp[1]);
+        const unsigned sa = lds_win + (unsigned)((qn * WRp + arow) * BK) * 4;
+        const unsigned sb = b_lane + (unsigned)stn * STAGE_B;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][1][j]), acl[i][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][0][j]), acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8, rb[b][0][j]), acl[i][j], 0, 0, 0);
-        };
-        auto tie = [&](int b, int i) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
-        auto wait_block = [&](int b) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < TM; ++i) tie(b, i);
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
-        };
-        fetch(0);
-        __builtin_amdgcn_sched_barrier(0);
-        wait_block(0);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(1);
-        if constexpr (TM * TN == 1) {
-            // one tile per wave: split and multiply in turn and let the other wave of the SIMD fill the gaps
-            __builtin_amdgcn_sched_barrier(0);
-            split2_f16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], amax);
-            products(0, 0, pln[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            wait_block(1);
-            __builtin_amdgcn_sched_barrier(0);
-            split2_f16<PRO>(ra[1][0][0], ra[1][0][1], pro_slope, pln[1][0], pln[1][1], amax);
-            products(1, 0, pln[1]);
-        } else {
-            split2_f16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], amax);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < F; ++s) {
-                const int b = s / TM, i = s % TM;
-                if (s + 1 < F) {
-                    const int b2 = (s + 1) / TM, i2 = (s + 1) % TM;
-                    if (b2 != b) {                   // block 1's fragments were requested a whole step ago
-                        wait_block(b2);
-                        __builtin_amdgcn_sched_barrier(0);
-                    } else {
-                        tie(b2, i2);                 // keeps this split inside this step's scheduling region
-                    }
-                    split2_f16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], amax);
-                }
-                products(b, i, pln[s & 1]);
-                if (s + 1 < F) {
-#pragma unroll
-                    for (int k = 0; k < NMF; ++k) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-                    }
-                }
+        for (int s = 0; s < FS; ++s) {
+            const int b = s / TM, i = s % TM;
+            if (i == 0 && TM > 1) {                       // B(q) must have landed
+                if constexpr (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N1) : "memory");
+                tie_b(b);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (i == TM - 1) {
+                if constexpr (!last) {
+                    if (b == 0) {
+                        __builtin_amdgcn_s_barrier();     // the weights of chunk c + 1 have landed
+                        asm volatile("" ::: "memory");
+                    }
+                    fetch_a(b, sa, swza);                 // A(q + 2)
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N1) : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                tie_a(b ^ 1);                             // A(q + 1)
+                if (TM == 1) tie_b(b);                    // B(q): issued before A(q + 1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const bool more = s + 1 < FS || !last;
+            if (more) {
+                const int s2 = (s + 1) % FS, b2 = s2 / TM, i2 = s2 % TM;
+                if (b2 == b) tie(b2, i2);
+                split2_f16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], amax);
+                products(b, i, pln[s & 1]);
+                pattern();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                products(b, i, pln[s & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (!last) {
+                if (i == TM - 1) {
+                    fetch_b(b, sb);                       // B(q + 2)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
-        st = st + 1 == NST ? 0 : st + 1;
-        if (++q == QS) { q = 0; ++tap; }
-    }
+        stn = stn + 1 == NST ? 0 : stn + 1;
+        if (++qn == QS) { qn = 0; ++tapn; }
+    };
+    for (int c = 0; c + 1 < nk; ++c) chunk(std::false_type{});
+    chunk(std::true_type{});
     if (p.x3h_flag != nullptr && __builtin_amdgcn_ballot_w64(amax >= kX3hMaxIn) != 0ull && lane == 0) atomicOr(p.x3h_flag, 1);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -1038,7 +1061,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = __builtin_fmaf(acl[i][j][e], kX3hLoInv, acc[i][j][e]) * inv_s[j];
-    if constexpr (PRET) epilogue_pre_t<TM, TN>(p, acc, pret, 0, m0 + wm * WTM, wn * WTN, lane);
+    if (epilogue_t4_ok(p)) epilogue_t4<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, 0, m0 + wm * WTM, wn * WTN, lane);
 }
 
@@ -1067,8 +1090,8 @@ X3hKernel x3h_kernel(int tile, int variant) {
         MT2_X3H_KS(32, 64, 1, 2, 4, 8, 2),          // X3H_KS_32x64_K4: the 84 tile (8 compute + 8 loader waves)
         MT2_X3H_KS(64, 64, 2, 2, 2, 8, 3),          // X3H_KS_64x64_K2: the 85 tile
         MT2_X3H_KS(32, 32, 1, 1, 8, 8, 2),          // X3H_KS_32x32_K8: the 86 tile
-        MT2_X3H_WIN(2, 256, 64, 8, 1, 3, 4),        // X3H_WIN_256x64: the 58 tile (8 compute + 4 loader waves)
-        MT2_X3H_WIN(4, 128, 128, 4, 2, 2, 4),       // X3H_WIN_128x128: the 59 tile
+        MT2_X3H_WIN(2, 256, 64, 8, 1, 4, 4),        // X3H_WIN_256x64: the 58 tile (8 compute + 4 loader waves), cross-chunk form: one more stage
+        MT2_X3H_WIN(4, 128, 128, 4, 2, 3, 4),       // X3H_WIN_128x128: the 59 tile
         // (measured and not kept, round 6: the 32-channel window convolution - 3..19 % slower than its x6 form)
     };
     if (tile < 0 || tile >= kX3hTiles || variant < 0 || variant >= 6) return nullptr;

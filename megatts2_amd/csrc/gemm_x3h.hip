@@ -56,6 +56,23 @@ constexpr float kX3hLoScale = 2048.0f, kX3hLoInv = 1.0f / 2048.0f, kX3hMaxIn = 6
 // (lo, hi) = 8 consecutive f32 of one A row -> two planes of 8 fp16 (element 2i / 2i+1 in dword i).  6 VALU per element pair:
 // v_cvt_pk_f16_f32, 2 v_mul_f32, 2 v_fma_mix_f32 (reads the fp16 halves in place), v_cvt_pk_f16_f32 - and one v_max3_f32 for
 // the range guard; the bf16 split of x6 takes 11 per pair.
+// Prologue activation of a value that is about to be SPLIT (its consumers are VALU instructions).  One v_max_f32: fmaxf() costs a
+// second one in front of it, the canonicalisation IEEE mode asks of an operand that may be a signalling NaN - 8 of the 44 VALU
+// instructions of a leaky-ReLU fragment split.  v_max_f32 returns the other operand for one NaN and NaN for two: fmaxf's result on
+// every input (NaN * slope is NaN).  NOT for values that feed a matrix instruction directly: the compiler does not see the VALU write
+// inside the asm statement and leaves out the wait states a VALU -> MFMA operand dependency needs (the f32-MFMA kernels keep fmaxf).
+template <int ACT>
+__device__ __forceinline__ float apply_act_split(float v, float slope) {
+    if (ACT == ACT_RELU) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v)); return r; }
+    if (ACT == ACT_LRELU) {            // 0 < slope < 1: identical to v >= 0 ? v : v*slope
+        float r;
+        const float w = v * slope;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(w));
+        return r;
+    }
+    return apply_act<ACT>(v, slope);
+}
+
 template <int PRO>
 __device__ __forceinline__ void split2_f16(const f32x4& lo, const f32x4& hi, float slope, u32x4& ph, u32x4& pl, float& amax) {
 #if MT2_ABL_NOSPLIT     // ablation: no split arithmetic (wrong numbers, same MFMA / LDS / DMA work)
@@ -64,8 +81,8 @@ __device__ __forceinline__ void split2_f16(const f32x4& lo, const f32x4& hi, flo
 #endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float x = apply_act<PRO>(i < 2 ? lo[2 * i] : hi[2 * i - 4], slope);
-        const float y = apply_act<PRO>(i < 2 ? lo[2 * i + 1] : hi[2 * i - 3], slope);
+        const float x = apply_act_split<PRO>(i < 2 ? lo[2 * i] : hi[2 * i - 4], slope);
+        const float y = apply_act_split<PRO>(i < 2 ? lo[2 * i + 1] : hi[2 * i - 3], slope);
         amax = fmaxf(fmaxf(fabsf(x), fabsf(y)), amax);
         const f16x2 h = __builtin_convertvector((f32x2){x, y}, f16x2);            // round to nearest even
         const float rx = __builtin_fmaf((float)h[0], -kX3hLoScale, x * kX3hLoScale);   // (x - h) * 2^11, exact

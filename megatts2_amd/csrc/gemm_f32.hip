@@ -1649,7 +1649,7 @@ static const TileCfg kCfgs[] = {
     MT2_X3HK(X3H_KS_64x64_K2, 64, 64, 2, 2, 2, 8, 3),             // 96: the 85 tile, 96 KiB
     MT2_X3HK(X3H_KS_32x32_K8, 32, 32, 1, 1, 8, 8, 2),             // 97: the 86 tile, 128 KiB
     // ... and the window convolutions of the vocoder's resblocks (conv_win_x3h_kernel)
-    MT2_RETIRED("x3hwin256x32_8x1+0_s3"),                   // 98: the 34 tile
+    MT2_X3HW(X3H_WIN_256x32, 1, 256, 32, 8, 1, 4, 4),             // 98: the 34 tile (32 channels)
     MT2_X3HW(X3H_WIN_256x64, 2, 256, 64, 8, 1, 4, 4),             // 99: the 58 tile
     MT2_X3HW(X3H_WIN_128x128, 4, 128, 128, 4, 2, 3, 4),           // 100: the 59 tile
     // ... the loader tiles with ONE barrier per 64-deep super-chunk (4 stages = 2 super-stages, 128 KiB): +1 % isolated, +2.4 % SLOWER
@@ -1775,9 +1775,11 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
             // the bf16-pipe forms: 34 (32 channels), and with loader waves 58 / 59 (64 / 128 channels: +5..14 % / +2..6 % over the
             // self-refilling forms 35 / 36, retired in round 6)
             bi = bi == 30 ? 34 : (bi == 31 ? 58 : 59);
-            // the fp16-pipe forms of the 64- and 128-channel tiles (profiles/r06_gemm_sweep_x3hwin_v1.txt: +19..37 % and +35..40 %; the
-            // 32-channel convolutions are HBM-side launches - 98 measured 3..19 % SLOWER than 34 - and stay on x6)
-            if ((o.x3h & 4) && x3h_ok) bi = bi == 58 ? 99 : (bi == 59 ? 100 : bi);
+            // the fp16-pipe forms of the 64- and 128-channel tiles (profiles/r06_gemm_sweep_x3hwin_v1.txt: +19..37 % and +35..40 %, and
+            // +11..18 % more with the cross-chunk pipeline, _v3_cross_chunk.txt).  The 32-channel convolutions are HBM-side launches: with 3
+            // taps the two forms are equal (355 vs 363 us at 3.55 M rows, residual + mask) and stay on x6; with 7 / 11 taps the x3h
+            // tile in its cross-chunk form is 9 / 14 % faster (the first x3h build of this tile was 3..19 % SLOWER)
+            if ((o.x3h & 4) && x3h_ok) bi = bi == 58 ? 99 : (bi == 59 ? 100 : (bi == 34 && p.taps >= 5 ? 98 : bi));
         }
         *idx_out = bi;
         return &kCfgs[bi];

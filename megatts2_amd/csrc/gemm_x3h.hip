@@ -1109,6 +1109,7 @@ X3hKernel x3h_kernel(int tile, int variant) {
         MT2_X3H_KS(32, 32, 1, 1, 8, 8, 2),          // X3H_KS_32x32_K8: the 86 tile
         MT2_X3H_WIN(2, 256, 64, 8, 1, 4, 4),        // X3H_WIN_256x64: the 58 tile (8 compute + 4 loader waves), cross-chunk form: one more stage
         MT2_X3H_WIN(4, 128, 128, 4, 2, 3, 4),       // X3H_WIN_128x128: the 59 tile
+        MT2_X3H_WIN(1, 256, 32, 8, 1, 4, 4),        // X3H_WIN_256x32: the 34 tile with loader waves
         // (measured and not kept, round 6: the 32-channel window convolution - 3..19 % slower than its x6 form)
     };
     if (tile < 0 || tile >= kX3hTiles || variant < 0 || variant >= 6) return nullptr;

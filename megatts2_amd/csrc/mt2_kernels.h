@@ -148,7 +148,7 @@ struct EngineOpts {
 hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
 // gemm_x3h.hip: the kernels of the fp16-pipe form by tile id and variant (prologue none / relu / leaky relu / - / - / pair statistics);
 // nullptr: no such variant
-enum X3hTile : int { X3H_LDR_128x128 = 0, X3H_KS_32x64_K4, X3H_KS_64x64_K2, X3H_KS_32x32_K8, X3H_WIN_256x64, X3H_WIN_128x128, kX3hTiles };
+enum X3hTile : int { X3H_LDR_128x128 = 0, X3H_KS_32x64_K4, X3H_KS_64x64_K2, X3H_KS_32x32_K8, X3H_WIN_256x64, X3H_WIN_128x128, X3H_WIN_256x32, kX3hTiles };
 typedef void (*X3hKernel)(GemmP);
 X3hKernel x3h_kernel(int tile, int variant);
 // gemm_skinny.hip: weight-streaming linear layer for M <= 64 rows (taps = 1, no rowbase, K a multiple of 32)

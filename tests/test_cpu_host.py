@@ -41,7 +41,7 @@ def test_tile_configuration_table_matches_the_indices_the_chooser_uses():
             84: "x6ks32x64_1x2_k4+8_s2", 85: "x6ks64x64_2x2_k2+8_s3", 86: "x6ks32x32_1x1_k8+8_s2", 87: "skinny32_f32",
             88: "skinny64_f32", 89: "skinnytm32_f32", 90: "skinnytm64_f32", 91: "retired:x3hldr128x128_4x2+4_s3",
             92: "retired:x3hldr128x128_4x2+4_s4", 94: "retired:x3hldr128x128_2x2+4_s4", 95: "x3hks32x64_1x2_k4+8_s2",
-            96: "x3hks64x64_2x2_k2+8_s3", 97: "x3hks32x32_1x1_k8+8_s2", 99: "x3hwin256x64_8x1+4_s4", 100: "x3hwin128x128_4x2+4_s3",
+            96: "x3hks64x64_2x2_k2+8_s3", 97: "x3hks32x32_1x1_k8+8_s2", 98: "x3hwin256x32_8x1+4_s4", 99: "x3hwin256x64_8x1+4_s4", 100: "x3hwin128x128_4x2+4_s3",
             103: "x3hldr128x128_4x2+4_s4xc", 104: "retired:x3hldr128x128_4x2+4_s3xc", 105: "retired:x3hldr128x128_2x2+4_s4xc"}
     for i, name in want.items():
         assert names[i] == name, (i, names[i], name)

@@ -59,13 +59,13 @@ def test_retired_configurations_answer_not_supported(rt):
     live = [i for i in range(len(names)) if i not in retired]
     # round 6: the f32 tiles the chooser never picks, the self-refilling x6 forms, the MP / XP / FR pipeline forms, the small and
     # four-loader tiles and three x3h experiments went the way of round 3's thirty (profiles/r06_retired_kernel_forms_and_options.patch)
-    assert live == [3, 12, 15, 16, 17, 18, 20, 22, 23, 28, 30, 31, 32, 34, 51, 55, 58, 59, 84, 85, 86, 87, 88, 89, 90, 95, 96, 97, 99, 100,
-                    103], live
+    assert live == [3, 12, 15, 16, 17, 18, 20, 22, 23, 28, 30, 31, 32, 34, 51, 55, 58, 59, 84, 85, 86, 87, 88, 89, 90, 95, 96, 97, 98, 99,
+                    100, 103], live
     X = dev(np.ones((64, 64), np.float32))
     for cfg in (49, 37, 67, 75, 64, 79):
         with pytest.raises(rt.NativeError):
             rt.op_conv_x6(X, X, None, None, force_cfg=cfg)
-    for cfg in (91, 92, 93, 94, 98, 101, 102, 104, 105):
+    for cfg in (91, 92, 93, 94, 101, 102, 104, 105):
         with pytest.raises(rt.NativeError):
             rt.op_conv_x3h(X, X, None, None, force_cfg=cfg)
     for cfg in (0, 8, 21, 29, 33):
@@ -196,6 +196,7 @@ def test_gemm_strided_conv_rowbase(rt, cfg):
 @pytest.mark.parametrize("k,dil,C,cfg", [(3, 1, 32, 34), (7, 3, 32, 34), (11, 5, 32, -1), (7, 1, 64, -1), (7, 5, 128, -1),
                                          (3, 5, 64, 58), (11, 5, 64, 58), (7, 1, 64, 58), (3, 3, 128, 59), (11, 5, 128, 59),
                                          (7, 5, 128, 59), (11, 1, 128, 59),
+                                         (3, 1, 32, 98), (7, 3, 32, 98), (11, 5, 32, 98),
                                          (3, 5, 64, 99), (11, 5, 64, 99), (7, 1, 64, 99),
                                          (3, 3, 128, 100), (11, 5, 128, 100), (7, 5, 128, 100), (11, 1, 128, 100)])
 @pytest.mark.parametrize("pro", ["none", "lrelu"])
@@ -327,7 +328,7 @@ def test_gemm_x3h_is_f32_equivalent(rt, cfg, M, N, taps, cin, dil):
 
 @pytest.mark.parametrize("cfg,M,N,taps,cin,dil", [(103, 300, 512, 1, 256, 1), (103, 1000, 384, 5, 384, 1), (103, 515, 256, 7, 256, 3),
                                                  (96, 200, 192, 1, 512, 1), (95, 77, 320, 1, 1024, 1), (97, 150, 96, 1, 768, 1),
-                                                 (99, 2000, 64, 7, 64, 3), (100, 1500, 128, 3, 128, 5)])
+                                                 (99, 2000, 64, 7, 64, 3), (100, 1500, 128, 3, 128, 5), (98, 3000, 32, 11, 32, 5)])
 def test_gemm_x3h_loader_address_forms_agree_bit_for_bit(rt, cfg, M, N, taps, cin, dil):
     """Round 6: the x3h loaders move their pieces with BUFFER loads (32-bit lane offset computed once per tap, the K walk in the
     instruction's scalar offset, rows outside the operand as the out-of-range offset = zeros) and keep the 64-bit global_load_lds

@@ -671,7 +671,7 @@ def main() -> None:
             "bound": "mfma",
             "kernel": "gemm_x3h_ldr_kernel / gemm_x3h_ks_kernel / conv_win_x3h_kernel (implicit-GEMM conv/linear engine on the fp16 matrix "
                       "pipe, f32-equivalent three-product form, loader waves; K-split tiles for the AR steps) + the x6 forms where no "
-                      "x3h form exists (32-channel window convolutions) + gemm_skinny_tm_kernel (f32 MFMA 16x16x4 on tile-major "
+                      "x3h form exists or pays (32-channel window convolutions with 3 taps) + gemm_skinny_tm_kernel (f32 MFMA 16x16x4 on tile-major "
                       "weights, LayerNorm prologue) for launches of at most 64 rows",
             "achieved": round(achieved, 2), "peak": round(PEAK, 1), "unit": "TFLOP/s",
             "frac": round(achieved / PEAK, 4), "traffic": traffic, "traffic_detail": traffic_detail,

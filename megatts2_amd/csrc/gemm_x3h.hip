@@ -23,8 +23,11 @@
 // |a| < 2^-14 makes a_hi subnormal, a_lo still holds the residual down to 2^-36 ABSOLUTE (fp16 subnormals are honoured by
 // v_cvt_pk_f16_f32 and by the MFMA: tools/ubench/mfma_f16_denorm.hip) - such elements lose relative, not normwise accuracy.
 //
-// Operand path, tile map, loader waves, LDS swizzles, epilogues: gemm_x6_ldr_kernel's (gemm_f32.hip) - the weights arrive as
-// 2 x BN x 64 B per chunk instead of 3 x, a stage of the 128x128 tile is 32 KiB instead of 40.
+// Operand path, tile map, loader waves, LDS swizzles: gemm_x6_ldr_kernel's (gemm_f32.hip) - the weights arrive as one 128-byte
+// [hi | lo] block per row and chunk (x3h_planes.h), a stage of the 128x128 tile is 32 KiB instead of 40.  Differences that matter
+// (round 6): the loaders issue BUFFER loads (32-bit lane offset computed once, the K walk in the scalar
+// offset, out of range = zero rows); the compute waves of the loader tile and of the window convolution run their fragment
+// pipeline ACROSS the chunk barrier; the epilogue is the 16-byte-store one with all operand loads at its start.
 #include "gemm_common.h"
 
 #include <atomic>

@@ -1776,10 +1776,10 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
             // self-refilling forms 35 / 36, retired in round 6)
             bi = bi == 30 ? 34 : (bi == 31 ? 58 : 59);
             // the fp16-pipe forms of the 64- and 128-channel tiles (profiles/r06_gemm_sweep_x3hwin_v1.txt: +19..37 % and +35..40 %, and
-            // +11..18 % more with the cross-chunk pipeline, _v3_cross_chunk.txt).  The 32-channel convolutions are HBM-side launches: with 3
-            // taps the two forms are equal (355 vs 363 us at 3.55 M rows, residual + mask) and stay on x6; with 7 / 11 taps the x3h
-            // tile in its cross-chunk form is 9 / 14 % faster (the first x3h build of this tile was 3..19 % SLOWER)
-            if ((o.x3h & 4) && x3h_ok) bi = bi == 58 ? 99 : (bi == 59 ? 100 : (bi == 34 && p.taps >= 5 ? 98 : bi));
+            // +11..18 % more with the cross-chunk pipeline, _v3_cross_chunk.txt, +10..35 % more with the window converted to fp16
+            // planes once per tile, _v4_planes_in_lds.txt).  The 32-channel convolutions too since then: 94 vs 72 TF/s with 3 taps,
+            // 221 vs 123 with 11 (the first x3h build of that tile was 3..19 % SLOWER than x6)
+            if ((o.x3h & 4) && x3h_ok) bi = bi == 58 ? 99 : (bi == 59 ? 100 : (bi == 34 ? 98 : bi));
         }
         *idx_out = bi;
         return &kCfgs[bi];

@@ -892,16 +892,71 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
                                              (__attribute__((address_space(3))) void*)(Bs + j * NI * 1024), 16, 0, 0);
         }
     };
-    if (loader) {                  // ---- loader wave: window pieces above, then nothing but the ring
+    if (loader) {                  // ---- loader wave: its window pieces above, then the first ring stages
         loader_priority(p.ldr_prio);
 #pragma unroll
         for (int st = 0; st < NST - 1; ++st)
             if (st < nk) issue(st, st);
-        // cross-chunk form (the compute waves' K loop below, gemm_x3h_ldr_kernel's): at barrier c the weights of chunk c-1 are still
-        // being read - the stage that is free is chunk c-2's, and chunk c + NST - 2 goes there
+        if (nk >= NST - 1) wait_vmcnt<(NST - 1) * B_IT>();      // the window pieces (older than the ring's) have landed
+        else wait_vmcnt<0>();
+    } else {
+        wait_vmcnt<0>();               // this compute wave's window pieces
+    }
+    // ---- the window becomes fp16 planes IN PLACE, once: every 128-byte row block (32 channels of one window row) turns from 32 f32
+    // into [32 hi | 32 lo] (logical 16-byte slots 0-3: hi of k = 8 s .., 4-7: lo - the layout of a weight row's block), prologue
+    // activation and range guard included.  The K loop then reads BOTH operands as ready fp16 fragments: no split arithmetic, no
+    // activation, no guard in it - a window element used to be fetched and split taps x WGN times (7 x 2 on a 7-tap 128-channel tile),
+    // ~2 000 VALU instructions per wave and tile beside the matrix instructions; the pass costs ~120 per wave.  All waves take part
+    // (read everything, barrier, write: slot j and 4 + j of a row block are other tasks' inputs).
+    float amax = 0.0f;
+    {
+        constexpr int NT = (NW + NL) * 64;
+        constexpr int MAXT = (QS * (BM + 64) * 4 + NT - 1) / NT;          // tasks per thread at the widest window (launch_gemm: span <= 64)
+        const unsigned lds_w = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)win;
+        const int ntask = QS * WRp * 4;                                   // (row block, j): f32 slots 2 j, 2 j + 1 -> hi slot j, lo slot 4 + j
+        f32x4 in[MAXT][2];
+        __builtin_amdgcn_s_barrier();                                     // every wave's window pieces have landed
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            const int t = tid + u * NT;
+            const int tt = t < ntask ? t : 0;
+            const int rbk = tt >> 2, j = tt & 3;
+            const int row = rbk % WRp;
+            const int swz = (row >> 1) & 7;
+            const unsigned base = lds_w + (unsigned)rbk * 128;
+            in[u][0] = lds_read_b128(base + (unsigned)(((2 * j) ^ swz) * 16));
+            in[u][1] = lds_read_b128(base + (unsigned)(((2 * j + 1) ^ swz) * 16));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) asm volatile("" : "+v"(in[u][0]), "+v"(in[u][1]));
+        __builtin_amdgcn_s_barrier();                                     // everything has been read
+        asm volatile("" ::: "memory");
+        const float slope0 = p.pro_slope;
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) {
+            const int t = tid + u * NT;
+            if (t < ntask) {
+                const int rbk = t >> 2, j = t & 3;
+                const int row = rbk % WRp;
+                const int swz = (row >> 1) & 7;
+                u32x4 ph, pl;
+                split2_f16<PRO>(in[u][0], in[u][1], slope0, ph, pl, amax);
+                char* dst = reinterpret_cast<char*>(win) + (size_t)rbk * 128;
+                *reinterpret_cast<u32x4*>(dst + ((j ^ swz) * 16)) = ph;
+                *reinterpret_cast<u32x4*>(dst + (((4 + j) ^ swz) * 16)) = pl;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the planes are in LDS before this wave's next barrier
+    }
+    if (p.x3h_flag != nullptr && __builtin_amdgcn_ballot_w64(amax >= kX3hMaxIn) != 0ull && lane == 0) atomicOr(p.x3h_flag, 1);
+    if (loader) {
+        // cross-chunk form (the compute waves' K loop below): at barrier c the weights of chunk c-1 are still being read - the stage
+        // that is free is chunk c-2's, and chunk c + NST - 2 goes there
         static_assert(NST >= 3, "cross-chunk form: chunk c-1 is still being read at barrier c");
         for (int c = 0; c < nk; ++c) {
-            if (c == 0) { if (NST - 2 < nk) wait_vmcnt<(NST - 2) * B_IT>(); else wait_vmcnt<0>(); }   // window pieces (older) and chunk 0
+            if (c == 0) { if (NST - 2 < nk) wait_vmcnt<(NST - 2) * B_IT>(); else wait_vmcnt<0>(); }
             else if (c + NST - 3 < nk) wait_vmcnt<(NST - 3) * B_IT>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
@@ -912,7 +967,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
     // (No epilogue operand is requested before or during the K loop.  The one-barrier-per-chunk loop this kernel had until round 6
     // prefetched bias / residual / row masks there - 50 registers that did not fit beside the fragment pipeline: hipcc spilled them
     // one by one, each load behind its own vmcnt(0), and reloaded them one by one in the epilogue, ~10 us per tile once the pipeline
-    // below took the registers.  The 16-byte-store epilogue issues all its operand loads together at its start instead.)
+    // took the registers.  The 16-byte-store epilogue issues all its operand loads together at its start instead.)
     float inv_s[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -928,13 +983,10 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
 #pragma unroll
             for (int e = 0; e < 16; ++e) { acc[i][j][e] = 0.0f; acl[i][j][e] = 0.0f; }
 
-    wait_vmcnt<0>();                   // this compute wave's window pieces, before the first barrier
-
-    const float pro_slope = p.pro_slope;
     const int half = lane >> 5;
     const unsigned lds_ring = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ring;
     const unsigned lds_win = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)win;
-    // B fragment of k block b (16 k): logical slot plane * 4 + b * 2 + half of row n = wn*WTN + j*32 + (lane & 31)
+    // fragment of k block b (16 k) of a 128-byte block: hi = logical slot b * 2 + half, lo = 4 + b * 2 + half - window rows and weight rows alike
     const int nrow = wn * WTN + (lane & 31);
     const unsigned b_lane = lds_ring + nrow * 128;
     const int swzb = (nrow >> 1) & 7;
@@ -945,26 +997,22 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
         koffb[b][1] = (unsigned)(((4 + b * 2 + half) ^ swzb) * 16);
     }
     const int arow0 = wm * WTM + (lane & 31);
-    float amax = 0.0f;
 
-    // Cross-chunk fragment pipeline, as in gemm_x3h_ldr_kernel (its comment has the protocol): the stream of k blocks q = 2 c + b is
-    // pipelined without regard to chunks - step (q, i) = split of the next fragment || products of fragment (q, i); A(q+2) comes from
-    // the resident window at the start of step (q, TM-1) (behind the barrier "the weights of chunk c+1 have landed" when q is even),
-    // B(q+2) from the ring at its end.  The one-barrier-per-chunk loop this replaces started every chunk with all eight compute waves
-    // waiting on the barrier, the first fragment's LDS latency and its split before the first matrix instruction.
-    constexpr int FS = 2 * TM, NMF = 3 * TN, SPLIT_VALU = 28 + (PRO == ACT_RELU || PRO == ACT_LRELU ? 8 : 0);
-    constexpr int VPM = (SPLIT_VALU + NMF - 1) / NMF, N1 = 2 * TM + 2 * TN;
+    // Cross-chunk fragment pipeline without a split stage: k block q = 2 c + b lives in register set b (A hi / lo of TM row tiles, B
+    // hi / lo of TN column tiles).  Step q: lgkmcnt <= 2 TM + 2 TN (set b has landed, set b ^ 1 may be in flight), the 3 TM TN products
+    // of the block, [q even: s_barrier - the weights of chunk c + 1 have landed - behind the products], then A(q+2) from the window and
+    // B(q+2) from the ring into set b: every LDS read is in flight for a whole step.  At barrier c + 1 the weights of chunk c are still
+    // being read: the free stage is chunk c - 1's (the loader's protocol above).
+    constexpr int N1 = 2 * TM + 2 * TN;
     static_assert(N1 <= 15, "lgkmcnt is four bits wide");
-    f32x4 ra[2][TM][2];
+    u32x4 ra[2][TM][2];
     u32x4 rb[2][2][TN];
-    u32x4 pln[2][2];
-    // (sa, swza): window address and slot swizzle of the A rows of a chunk = (tap, q)
     auto fetch_a = [&](int b, unsigned sa, int swza) __attribute__((always_inline)) {
-        const unsigned va0 = sa + (unsigned)(((b * 4 + half * 2) ^ swza) * 16), va1 = sa + (unsigned)(((b * 4 + half * 2 + 1) ^ swza) * 16);
+        const unsigned vh = sa + (unsigned)(((b * 2 + half) ^ swza) * 16), vl = sa + (unsigned)(((4 + b * 2 + half) ^ swza) * 16);
         static_for(std::make_integer_sequence<int, TM>{}, [&](auto ic) {
             constexpr int i = decltype(ic)::value;
-            ra[b][i][0] = lds_read_b128_imm<i * 32 * BK * 4>(va0);
-            ra[b][i][1] = lds_read_b128_imm<i * 32 * BK * 4>(va1);
+            ra[b][i][0] = __builtin_bit_cast(u32x4, lds_read_b128_imm<i * 32 * BK * 4>(vh));
+            ra[b][i][1] = __builtin_bit_cast(u32x4, lds_read_b128_imm<i * 32 * BK * 4>(vl));
         });
     };
     auto fetch_b = [&](int b, unsigned sb) __attribute__((always_inline)) {
@@ -975,47 +1023,37 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
             rb[b][1][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb1));
         });
     };
-    auto products = [&](int b, int i, const u32x4* pp) __attribute__((always_inline)) {
-        const f16x8 Ah = __builtin_bit_cast(f16x8, pp[0]), Al = __builtin_bit_cast(f16x8, pp[1]);
+    auto tie_set = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-            acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][1][j]), acl[i][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][0][j]), acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-            acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8, rb[b][0][j]), acl[i][j], 0, 0, 0);
-    };
-    auto tie = [&](int b, int i) __attribute__((always_inline)) { asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1])); };
-    auto tie_a = [&](int b) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) tie(b, i);
-    };
-    auto tie_b = [&](int b) __attribute__((always_inline)) {
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1]));
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
             for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
     };
-    auto pattern = [&]() __attribute__((always_inline)) {
+    // cross terms first (into the low accumulators), column tiles innermost: consecutive MFMAs never wait on each other's accumulator
+    auto products = [&](int b) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < NMF; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        for (int i = 0; i < TM; ++i) {
+            const f16x8 Ah = __builtin_bit_cast(f16x8, ra[b][i][0]), Al = __builtin_bit_cast(f16x8, ra[b][i][1]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][1][j]), acl[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][0][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8, rb[b][0][j]), acl[i][j], 0, 0, 0);
         }
     };
-    __builtin_amdgcn_s_barrier();                         // the window and the weights of chunk 0 have landed
+    __builtin_amdgcn_s_barrier();                         // the window's planes are written and the weights of chunk 0 have landed
     asm volatile("" ::: "memory");
     {
         const unsigned sa0 = lds_win + (unsigned)(arow0 * BK) * 4;
         const int swz0 = (arow0 >> 1) & 7;
         fetch_a(0, sa0, swz0); fetch_b(0, b_lane); fetch_a(1, sa0, swz0); fetch_b(1, b_lane);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N1) : "memory");
-    tie_a(0); tie_b(0);
-    split2_f16<PRO>(ra[0][0][0], ra[0][0][1], pro_slope, pln[0][0], pln[0][1], amax);
     __builtin_amdgcn_sched_barrier(0);
     int stn = 1 % NST, tapn = 0, qn = 1;                  // chunk c + 1: its ring stage, tap and 32-channel slice
     if (qn == QS) { qn = 0; tapn = 1; }
@@ -1026,47 +1064,21 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
         const unsigned sa = lds_win + (unsigned)((qn * WRp + arow) * BK) * 4;
         const unsigned sb = b_lane + (unsigned)stn * STAGE_B;
 #pragma unroll
-        for (int s = 0; s < FS; ++s) {
-            const int b = s / TM, i = s % TM;
-            if (i == 0 && TM > 1) {                       // B(q) must have landed
-                if constexpr (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N1) : "memory");
-                tie_b(b);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (i == TM - 1) {
-                if constexpr (!last) {
-                    if (b == 0) {
-                        __builtin_amdgcn_s_barrier();     // the weights of chunk c + 1 have landed
-                        asm volatile("" ::: "memory");
-                    }
-                    fetch_a(b, sa, swza);                 // A(q + 2)
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N1) : "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                tie_a(b ^ 1);                             // A(q + 1)
-                if (TM == 1) tie_b(b);                    // B(q): issued before A(q + 1)
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const bool more = s + 1 < FS || !last;
-            if (more) {
-                const int s2 = (s + 1) % FS, b2 = s2 / TM, i2 = s2 % TM;
-                if (b2 == b) tie(b2, i2);
-                split2_f16<PRO>(ra[b2][i2][0], ra[b2][i2][1], pro_slope, pln[(s + 1) & 1][0], pln[(s + 1) & 1][1], amax);
-                products(b, i, pln[s & 1]);
-                pattern();
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                products(b, i, pln[s & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int b = 0; b < 2; ++b) {
+            if (last && b == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N1) : "memory");
+            tie_set(b);
+            __builtin_amdgcn_sched_barrier(0);
+            products(b);
+            __builtin_amdgcn_sched_barrier(0);
             if constexpr (!last) {
-                if (i == TM - 1) {
-                    fetch_b(b, sb);                       // B(q + 2)
-                    __builtin_amdgcn_sched_barrier(0);
+                if (b == 0) {
+                    __builtin_amdgcn_s_barrier();         // the weights of chunk c + 1 have landed
+                    asm volatile("" ::: "memory");
                 }
+                fetch_a(b, sa, swza);                     // A(q + 2), B(q + 2)
+                fetch_b(b, sb);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         stn = stn + 1 == NST ? 0 : stn + 1;
@@ -1074,7 +1086,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
     };
     for (int c = 0; c + 1 < nk; ++c) chunk(std::false_type{});
     chunk(std::true_type{});
-    if (p.x3h_flag != nullptr && __builtin_amdgcn_ballot_w64(amax >= kX3hMaxIn) != 0ull && lane == 0) atomicOr(p.x3h_flag, 1);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll

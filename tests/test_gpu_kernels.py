@@ -196,7 +196,7 @@ def test_gemm_strided_conv_rowbase(rt, cfg):
 @pytest.mark.parametrize("k,dil,C,cfg", [(3, 1, 32, 34), (7, 3, 32, 34), (11, 5, 32, -1), (7, 1, 64, -1), (7, 5, 128, -1),
                                          (3, 5, 64, 58), (11, 5, 64, 58), (7, 1, 64, 58), (3, 3, 128, 59), (11, 5, 128, 59),
                                          (7, 5, 128, 59), (11, 1, 128, 59),
-                                         (3, 1, 32, 98), (7, 3, 32, 98), (11, 5, 32, 98),
+                                         (3, 1, 32, 98), (7, 3, 32, 98), (11, 5, 32, 98), (3, 5, 32, -1),
                                          (3, 5, 64, 99), (11, 5, 64, 99), (7, 1, 64, 99),
                                          (3, 3, 128, 100), (11, 5, 128, 100), (7, 5, 128, 100), (11, 1, 128, 100)])
 @pytest.mark.parametrize("pro", ["none", "lrelu"])

@@ -392,7 +392,8 @@ __device__ __forceinline__ void epilogue_t4(const GemmP& p, f32x16 (&acc)[TM][TN
 }
 
 constexpr int BK = 32;   // K chunk (floats)
-constexpr int PRO_LN = 3;   // prologue kind: LayerNorm of the A rows (value of GemmP::pro_act)
+constexpr int PRO_LN = 3;   // prologue kind: LayerNorm of the A rows (value of GemmP::pro_act; the <= 64-row weight-streaming kernel only)
+constexpr int PRO_APL = 3;  // variant index of the x3h tiles whose A operand ARRIVES as fp16 planes (GemmP::a_planes; no prologue)
 constexpr int PRO_LNA = 4;  // LayerNorm of the A rows, ALGEBRAIC form: statistics in the prologue, correction in the epilogue
 constexpr int PRO_LNX = 5;  // ... ALGEBRAIC form on PAIR statistics written by the producer GEMM's epilogue (GemmP::ln_stat): no pass over K
 

@@ -1512,13 +1512,13 @@ static void x3h_variant_exists(GemmP) {}
 #define MT2_X3HL(ID_, BM_, BN_, WM_, WN_, NL_, NST_, HAS_LNX_)                                                     \
     { BM_, BN_, (WM_* WN_ + NL_) * 64, (size_t)NST_ * ((size_t)BM_ * BK * 4 + (size_t)(2 * BN_ / 16) * 1024),       \
       "x3hldr" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "+" #NL_ "_s" #NST_ "xc",                                            \
-      { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr,                               \
+      { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr,                    \
         (HAS_LNX_) ? x3h_variant_exists : nullptr }, 0, true, 0, (HAS_LNX_) ? (BN_) / (WN_) : 0, ID_ }
 
 #define MT2_X3HK(ID_, BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                           \
     { BM_, BN_, (WM_* WN_ * KS_ + NL_) * 64, (size_t)KS_ * NST_ * ((size_t)BM_ * BK * 4 + (size_t)(2 * BN_ / 16) * 1024), \
       "x3hks" #BM_ "x" #BN_ "_" #WM_ "x" #WN_ "_k" #KS_ "+" #NL_ "_s" #NST_,                                        \
-      { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, nullptr, x3h_variant_exists }, 0, true, KS_, 32, ID_ }
+      { x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, x3h_variant_exists, nullptr, x3h_variant_exists }, 0, true, KS_, 32, ID_ }
 
 #define MT2_X3HW(ID_, QS_, BM_, BN_, WM_, WN_, NST_, NL_)                                                           \
     { BM_, BN_, (WM_* WN_ + NL_) * 64,                                                                               \
@@ -1825,6 +1825,21 @@ static const TileCfg* choose_cfg(const GemmP& p, const EngineOpts& o, int* idx_o
     return &kCfgs[bi];
 }
 
+bool gemm_takes_planes(const GemmP& p_in, const EngineOpts& o) {
+    GemmP p = p_in;
+    if (p.taps <= 0) p.taps = 1;
+    if (p.groups <= 0) p.groups = 1;
+    if (p.a_mul == 0) p.a_mul = 1;
+    p.K = p.taps * p.Cin;
+    if (p.ldw == 0) p.ldw = p.K;
+    if (!(o.x3h & 3) || o.force_cfg >= 0 || p.M <= 64 || p.groups != 1 || p.pro_act != ACT_NONE || p.stat_out || p.taps != 1 || (p.K % BK) != 0 ||
+        (p.ldx % BK) != 0 || p.a_mul != 1 || p.shift0 != 0 || p.rowbase || !p.Wh || !p.wh_inv || (((unsigned long long)p.X) & 127))
+        return false;
+    int idx = -1;
+    const TileCfg* c = choose_cfg(p, o, &idx);
+    return c && c->x3h >= 0 && !c->win_qs && c->fn[PRO_APL] != nullptr;
+}
+
 hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     static const EngineOpts kDefaults;
     const EngineOpts& o = opts ? *opts : kDefaults;
@@ -1839,7 +1854,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     // a handful of rows: the weight-streaming kernel (gemm_skinny.hip) instead of a tile configuration
     const bool sk_forced = o.force_cfg == kSkinny32 || o.force_cfg == kSkinny64;
     const bool tm_forced = o.force_cfg == kSkinnyTm32 || o.force_cfg == kSkinnyTm64;
-    if (tm_forced || (o.skinny_tm && o.skinny_rows > 0 && o.force_cfg < 0 && p.groups >= o.skinny_groups &&
+    if (tm_forced || (!p.a_planes && o.skinny_tm && o.skinny_rows > 0 && o.force_cfg < 0 && p.groups >= o.skinny_groups &&
                       gemm_skinny_tm_eligible(p, o.skinny_rows))) {
         if (!gemm_skinny_tm_eligible(p, 64)) return hipErrorInvalidValue;
         p.sk_nw = o.skinny_nw;
@@ -1905,7 +1920,11 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
         }
     }
     // variant index: pair statistics (consumer and / or producer side) run the PRO_LNX instantiation - the K loop of ACT_NONE
-    const int fi = (p.pro_act == PRO_LNX || p.stat_out) ? PRO_LNX : p.pro_act;
+    // ... an A operand that arrives as fp16 planes (a_planes) runs the PRO_APL instantiation: x3h loader / K-split tiles only
+    if (p.a_planes && (c->x3h < 0 || c->win_qs || p.pro_act != ACT_NONE || p.stat_out || p.taps != 1 || (p.K % BK) != 0 || (p.ldx % BK) != 0 ||
+                       (((unsigned long long)p.X) & 127)))
+        return hipErrorNotSupported;
+    const int fi = p.a_planes ? PRO_APL : ((p.pro_act == PRO_LNX || p.stat_out) ? PRO_LNX : p.pro_act);
     // LayerNorm as a prologue of the f32 tiles (pro_act 3 / 4: rounds 1-2, measured slower than LayerNorm + GEMM) is retired: callers
     // fall back on NotSupported; the <= 64-row weight-streaming kernel (above) keeps its own LayerNorm prologue
     if (p.pro_act == PRO_LN || p.pro_act == PRO_LNA) return hipErrorNotSupported;

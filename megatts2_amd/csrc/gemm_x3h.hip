@@ -345,6 +345,102 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
     }
 
     float amax = 0.0f;
+    // clock probe (two scalar reads when requested): shader cycles (s_memtime) and constant-rate ticks (s_memrealtime) across
+    // the whole K loop of one wave -> the clock the matrix pipe actually sustained (bench.py)
+    const bool probe = p.dbg != nullptr && bid == (int)(gridDim.x / 2) && wave == 0;
+    unsigned long long treal0 = 0, tcyc0 = 0;
+    if (probe) {
+        treal0 = __builtin_amdgcn_s_memrealtime();
+        tcyc0 = __builtin_readcyclecounter();
+        if (lane == 0) p.dbg[9] = treal0 - t_entry;
+    }
+    // A operand as fp16 planes (GemmP::a_planes: the producer - a LayerNorm kernel - wrote [32 hi | 32 lo] per 32 k of a row, a weight
+    // row's layout; same bytes, same strides as f32): the loaders move them unchanged, the compute waves read BOTH operands as ready
+    // fragments - no split, no guard (the producer's), nothing but LDS reads and matrix instructions in the K loop.  Cross-chunk
+    // pipeline without a split stage: k block q = 2 c + b lives in register set b; step q: lgkmcnt <= 2 TM + 2 TN (set b has landed),
+    // the 3 TM TN products, [q even: s_barrier - chunk c + 1 has landed - behind the products], then A(q+2), B(q+2) into set b.  At
+    // barrier c + 1 chunk c is still being read: the free stage is chunk c - 1's (the loader's protocol above).
+    if constexpr (PRO == PRO_APL) {
+        constexpr int N1 = 2 * TM + 2 * TN;
+        static_assert(N1 <= 15, "lgkmcnt is four bits wide");
+        u32x4 ra[2][TM][2];
+        u32x4 rb[2][2][TN];
+        unsigned koffah[2][2];                            // A fragment of k block b: hi = logical slot b * 2 + half, lo = 4 + b * 2 + half
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            koffah[b][0] = (unsigned)(((b * 2 + half) ^ swza) * 16);
+            koffah[b][1] = (unsigned)(((4 + b * 2 + half) ^ swza) * 16);
+        }
+        auto fetch_a = [&](int b, unsigned sa) __attribute__((always_inline)) {
+            const unsigned vh = sa + koffah[b][0], vl = sa + koffah[b][1];
+            static_for(std::make_integer_sequence<int, TM>{}, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                ra[b][i][0] = __builtin_bit_cast(u32x4, lds_read_b128_imm<i * 32 * BK * 4>(vh));
+                ra[b][i][1] = __builtin_bit_cast(u32x4, lds_read_b128_imm<i * 32 * BK * 4>(vl));
+            });
+        };
+        auto fetch_b = [&](int b, unsigned sb) __attribute__((always_inline)) {
+            const unsigned vb0 = sb + koffb[b][0], vb1 = sb + koffb[b][1];
+            static_for(std::make_integer_sequence<int, TN>{}, [&](auto ic) {
+                constexpr int j = decltype(ic)::value;
+                rb[b][0][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb0));
+                rb[b][1][j] = __builtin_bit_cast(u32x4, lds_read_b128_imm<j * 32 * 128>(vb1));
+            });
+        };
+        auto tie_set = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(ra[b][i][0]), "+v"(ra[b][i][1]));
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[b][pl][j]));
+        };
+        auto products = [&](int b) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const f16x8 Ah = __builtin_bit_cast(f16x8, ra[b][i][0]), Al = __builtin_bit_cast(f16x8, ra[b][i][1]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][1][j]), acl[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, __builtin_bit_cast(f16x8, rb[b][0][j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, __builtin_bit_cast(f16x8, rb[b][0][j]), acl[i][j], 0, 0, 0);
+            }
+        };
+        __builtin_amdgcn_s_barrier();                     // chunk 0 has landed
+        asm volatile("" ::: "memory");
+        fetch_a(0, a_lane); fetch_b(0, b_lane); fetch_a(1, a_lane); fetch_b(1, b_lane);
+        __builtin_amdgcn_sched_barrier(0);
+        int stn = 1 % NST;                                // stage of chunk c + 1
+        auto chunk = [&](auto last_c) __attribute__((always_inline)) {
+            constexpr bool last = decltype(last_c)::value;
+            const unsigned sa = a_lane + (unsigned)stn * STAGE, sb = b_lane + (unsigned)stn * STAGE;    // chunk c + 1
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                if (last && b == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N1) : "memory");
+                tie_set(b);
+                __builtin_amdgcn_sched_barrier(0);
+                products(b);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (!last) {
+                    if (b == 0) {
+                        __builtin_amdgcn_s_barrier();     // chunk c + 1 has landed
+                        asm volatile("" ::: "memory");
+                    }
+                    fetch_a(b, sa);                       // A(q + 2), B(q + 2)
+                    fetch_b(b, sb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            stn = stn + 1 == NST ? 0 : stn + 1;
+        };
+        for (int c = 0; c + 1 < nk; ++c) chunk(std::false_type{});
+        chunk(std::true_type{});
+    } else {
     f32x4 ra[2][TM][2];
     u32x4 rb[2][2][TN];
     u32x4 pln[2][2];
@@ -379,15 +475,6 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
             __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
         }
     };
-    // clock probe (two scalar reads when requested): shader cycles (s_memtime) and constant-rate ticks (s_memrealtime) across
-    // the whole K loop of one wave -> the clock the matrix pipe actually sustained (bench.py)
-    const bool probe = p.dbg != nullptr && bid == (int)(gridDim.x / 2) && wave == 0;
-    unsigned long long treal0 = 0, tcyc0 = 0;
-    if (probe) {
-        treal0 = __builtin_amdgcn_s_memrealtime();
-        tcyc0 = __builtin_readcyclecounter();
-        if (lane == 0) p.dbg[9] = treal0 - t_entry;
-    }
     constexpr int FS = 2 * TM;                            // fragments per chunk (two 16-deep k blocks)
     {
         // Cross-chunk form.  The one-barrier-per-chunk loop below starts every chunk with all eight compute waves waiting on the
@@ -491,6 +578,7 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         };
         for (int c = 0; c + 1 < nk; ++c) chunk(std::false_type{});
         chunk(std::true_type{});
+    }
     }
     unsigned long long t_loop_end = 0;
     if (probe) {
@@ -694,9 +782,11 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
     float amax = 0.0f;
     f32x4 ra[2][2];
     u32x4 rb[2][2], pln[2];
+    // (PRO_APL - GemmP::a_planes: the A rows arrive as [32 hi | 32 lo] fp16 per 32 k, a weight row's layout: the fragment of k block
+    // b is the hi slot b * 2 + half and the lo slot 4 + b * 2 + half, and there is nothing to split)
     auto fetch = [&](int b, unsigned sa, unsigned sb) {
-        ra[b][0] = lds_read_b128(sa + koffa[b][0]);
-        ra[b][1] = lds_read_b128(sa + koffa[b][1]);
+        ra[b][0] = lds_read_b128(sa + (PRO == PRO_APL ? (unsigned)(((b * 2 + half) ^ swza) * 16) : koffa[b][0]));
+        ra[b][1] = lds_read_b128(sa + (PRO == PRO_APL ? (unsigned)(((4 + b * 2 + half) ^ swza) * 16) : koffa[b][1]));
         rb[b][0] = __builtin_bit_cast(u32x4, lds_read_b128(sb + koffb[b][0]));
         rb[b][1] = __builtin_bit_cast(u32x4, lds_read_b128(sb + koffb[b][1]));
     };
@@ -733,10 +823,12 @@ __global__ __launch_bounds__((WGM * WGN * KS + NL) * 64) void gemm_x3h_ks_kernel
         wait_block(0);
         wait_block(1);
         __builtin_amdgcn_sched_barrier(0);
-        split2_f16<PRO>(ra[0][0], ra[0][1], pro_slope, pln[0], pln[1], amax);
+        if constexpr (PRO == PRO_APL) { pln[0] = __builtin_bit_cast(u32x4, ra[0][0]); pln[1] = __builtin_bit_cast(u32x4, ra[0][1]); }
+        else split2_f16<PRO>(ra[0][0], ra[0][1], pro_slope, pln[0], pln[1], amax);
         products(0);
         __builtin_amdgcn_sched_barrier(0);
-        split2_f16<PRO>(ra[1][0], ra[1][1], pro_slope, pln[0], pln[1], amax);
+        if constexpr (PRO == PRO_APL) { pln[0] = __builtin_bit_cast(u32x4, ra[1][0]); pln[1] = __builtin_bit_cast(u32x4, ra[1][1]); }
+        else split2_f16<PRO>(ra[1][0], ra[1][1], pro_slope, pln[0], pln[1], amax);
         products(1);
         __builtin_amdgcn_sched_barrier(0);
         st = st + 1 == NST ? 0 : st + 1;
@@ -1100,11 +1192,11 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_win_x3h_kernel(Gem
 // host side: the kernels of this unit by tile id and prologue (the tile table lives in gemm_f32.hip)
 #define MT2_X3H_LDR(BM_, BN_, WM_, WN_, NL_, NST_)                                                                          \
     { gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_NONE>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_RELU>, \
-      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, nullptr, nullptr,                                         \
+      gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, ACT_LRELU>, gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, PRO_APL>, nullptr, \
       gemm_x3h_ldr_kernel<BM_, BN_, WM_, WN_, NL_, NST_, PRO_LNX> }
 #define MT2_X3H_KS(BM_, BN_, WM_, WN_, KS_, NL_, NST_)                                                                          \
     { gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_NONE>, gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_RELU>, \
-      gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, nullptr, nullptr,                                           \
+      gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, ACT_LRELU>, gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, PRO_APL>, nullptr, \
       gemm_x3h_ks_kernel<BM_, BN_, WM_, WN_, KS_, NL_, NST_, PRO_LNX> }
 
 #define MT2_X3H_WIN(QS_, BM_, BN_, WM_, WN_, NST_, NL_)                                                                         \

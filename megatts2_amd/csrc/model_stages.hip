@@ -125,11 +125,23 @@ static void gemm(const Ctx& c, GemmP p) {
 // y[M, N] = x[M, K] @ W^T + b  (F.linear)
 static void linear(const Ctx& c, const float* x, int ldx, int M, const float* W, const float* b, int N, int K,
                    float* y, int ldy, const float* R = nullptr, int ldr = 0, const int* valid = nullptr,
-                   int epi_act = ACT_NONE) {
+                   int epi_act = ACT_NONE, bool a_planes = false) {
     GemmP p{};
     p.X = x; p.ldx = ldx; p.Rx = M; p.Cin = K; p.W = W; p.bias = b; p.R = R; p.ldr = ldr; p.valid = valid;
-    p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.epi_act = epi_act;
+    p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.epi_act = epi_act; p.a_planes = a_planes ? 1 : 0;
     gemm(c, p);
+}
+// Will linear(x -> y) run on an x3h tile that takes x as fp16 planes (GemmP::a_planes)?  Then the LayerNorm that produces x writes
+// planes (LnP::out_planes / LnReduceP::h_planes: same bytes, same row stride) and the GEMM's K loop holds no split arithmetic - in
+// the loader tile that arithmetic is 8..18 % of a launch (profiles/r06_x3h_ablate_v3_split.txt).
+static bool linear_takes_planes(const Ctx& c, const float* x, int ldx, int M, const float* W, const float* b, int N, int K,
+                                float* y, int ldy, int epi_act) {
+    if (!c.m.opts.a_planes) return false;
+    GemmP p{};
+    p.X = x; p.ldx = ldx; p.Rx = M; p.Cin = K; p.W = W; p.bias = b; p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.epi_act = epi_act;
+    p.taps = 1; p.dil = 1; p.a_mul = 1; p.groups = 1; p.out_scale = 1.0f; p.K = K; p.ldw = K;
+    attach_planes(c.m, p);
+    return gemm_takes_planes(p, c.m.opts);
 }
 
 // y[M, N] = act(LN(x_rows)[M, K] @ W^T + b), x_rows[m] = x + (m * a_mul + shift0) * ldx.  Three forms, same result
@@ -194,11 +206,12 @@ static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, 
         if (e == hipSuccess) return;
         if (e != hipErrorNotSupported) MT2_HIP(e);
     }
+    const bool planes = linear_takes_planes(c, h_scratch, K, M, w.W, w.bias, N, K, y, ldy, epi_act);
     LnP q{};
     q.x = x + (long long)shift0 * ldx; q.ldx = ldx * p.a_mul; q.gamma = w.g; q.beta = w.b; q.out = h_scratch; q.ldo = K;
-    q.M = M; q.C = K; q.eps = 1e-5f; q.act = ACT_NONE;
+    q.M = M; q.C = K; q.eps = 1e-5f; q.act = ACT_NONE; q.out_planes = planes ? 1 : 0; q.x3h_flag = c.m.opts.x3h_flag;
     MT2_HIP(launch_layernorm(q, c.s));
-    linear(c, h_scratch, K, M, w.W, w.bias, N, K, y, ldy, nullptr, 0, nullptr, epi_act);
+    linear(c, h_scratch, K, M, w.W, w.bias, N, K, y, ldy, nullptr, 0, nullptr, epi_act, planes);
 }
 static LnOps ln1_qkv(const EncLayerW& w, int d, int n0 = 0) {
     return ln_ops(w.ln1g, w.ln1b, w.wqkv, w.bqkv, w.wqkv_l, w.sqkv, w.cqkv, n0, d);
@@ -378,12 +391,26 @@ static void linear_splitk(const Ctx& c, const float* x, int ldx, int M, const fl
 }
 // h = LayerNorm(x) after applying a pending update to x (in place)
 static void ln_pending(const Ctx& c, float* x, int d, int M, const Pending& in, const float* g, const float* b,
-                       float* h) {
-    if (in.S == 0) { layernorm(c, x, d, g, b, M, d, h, d); return; }
+                       float* h, bool h_planes = false) {
+    if (in.S == 0) {
+        LnP q{};
+        q.x = x; q.ldx = d; q.gamma = g; q.beta = b; q.out = h; q.ldo = d; q.M = M; q.C = d; q.eps = 1e-5f; q.act = ACT_NONE;
+        q.out_planes = h_planes ? 1 : 0; q.x3h_flag = c.m.opts.x3h_flag;
+        MT2_HIP(launch_layernorm(q, c.s));
+        return;
+    }
     LnReduceP p{};
     p.parts = in.parts; p.pstride = in.pstride; p.S = in.S; p.bias = in.bias; p.R = x; p.ldr = d;
     p.gamma = g; p.beta = b; p.xout = x; p.ldx = d; p.hout = h; p.ldh = d; p.M = M; p.C = d; p.eps = 1e-5f;
+    p.h_planes = h_planes ? 1 : 0; p.x3h_flag = c.m.opts.x3h_flag;
     MT2_HIP(launch_ln_reduce(p, c.s));
+}
+// h = LN(x (+ the pending split-K update)), y = act(h W^T + b): h travels as fp16 planes when the GEMM takes them
+static void ln_pending_linear(const Ctx& c, float* x, int d, int M, const Pending& in, const float* g, const float* b, float* h,
+                              const float* W, const float* bias, int N, float* y, int ldy, int epi_act = ACT_NONE) {
+    const bool planes = M <= 4096 && linear_takes_planes(c, h, d, M, W, bias, N, d, y, ldy, epi_act);
+    ln_pending(c, x, d, M, in, g, b, h, planes);
+    linear(c, h, d, M, W, bias, N, d, y, ldy, nullptr, 0, nullptr, epi_act, planes);
 }
 // everything after attention for M full rows: x += out_proj(att); h = LN2(x); f = relu(ff0(h));
 // x += ff1(f) - the last update is returned as pending when it was split
@@ -414,8 +441,7 @@ static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, fl
     if (S1 > 1) {
         linear_splitk(c, att, d, M, w.wo, d, d, S1, s.parts);
         Pending p1{s.parts, (long long)M * d, S1, w.bo};
-        ln_pending(c, x, d, M, p1, w.ln2g, w.ln2b, s.h);
-        linear(c, s.h, d, M, w.ff0w, w.ff0b, e.ff, d, s.f, e.ff, nullptr, 0, nullptr, ACT_RELU);
+        ln_pending_linear(c, x, d, M, p1, w.ln2g, w.ln2b, s.h, w.ff0w, w.ff0b, e.ff, s.f, e.ff, ACT_RELU);
     } else {
         const Pending p1 = linear_residual(c, att, d, M, w.wo, w.bo, d, d, x, s.stat);                 // x += out_proj(att)
         ln_linear(c, x, d, M, 1, 0, M, ln2_ff0(w, d), e.ff, d, s.f, e.ff, s.h, ACT_RELU, &p1);         // LN2 -> ff.0
@@ -435,8 +461,7 @@ static Pending encoder_layer_ar(const Ctx& c, const EncW& e, const EncLayerW& w,
     MT2_REQUIRE(!e.conv_ff, "AR step layers use the Linear feed-forward");
     const int d = e.d;
     if (in.S) {
-        ln_pending(c, x, d, M, in, w.ln1g, w.ln1b, s.h);
-        linear(c, s.h, d, M, w.wqkv, w.bqkv, 3 * d, d, s.qkv, 3 * d);
+        ln_pending_linear(c, x, d, M, in, w.ln1g, w.ln1b, s.h, w.wqkv, w.bqkv, 3 * d, s.qkv, 3 * d);
     } else {
         ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d), 3 * d, d, s.qkv, 3 * d, s.h, ACT_NONE, &in);     // LN1 -> QKV
     }

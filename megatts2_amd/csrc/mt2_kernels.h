@@ -48,6 +48,8 @@ struct GemmP {
     unsigned long long* dbg = nullptr;   // MT2_PHASE_TIMING builds only: per-phase cycle sums of one wave (tools/x6_phase_timing.py)
     int epi_t4 = 1;             // 16-byte-store epilogue where the layout allows it (set by launch_gemm from EngineOpts::epi_t4)
     int sk_nw = 8;              // gemm_skinny_tm_kernel: waves per workgroup that split K (8; 16 = option skinny_nw, set by launch_gemm)
+    int a_planes = 0;           // 1: X holds fp16 planes ([32 hi | 32 lo] per 32 k of a row, x3h_planes.h's block layout without a row scale)
+                                // written by a producer kernel (LnP::out_planes): x3h loader / K-split tiles only, no prologue, taps = 1, K % 32 = 0
     int ldr64 = 0;              // x3h loaders: 1 = the 64-bit global_load_lds form even where buffer loads would do (EngineOpts::ldr64)
     int ldr_prio = 0;           // s_setprio of the loader waves of the loader-wave kernels (set by launch_gemm from EngineOpts::ldr_prio)
     const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like
@@ -113,6 +115,8 @@ struct EngineOpts {
                                  // 64x64 tile only.  Default 4: isolated launches +10..50 %
                                  // (profiles/r03_gemm_sweep_x6k.txt), C3 step -1.6 % (profiles/r03_ab_interleaved_v1.txt)
     bool epi_t4 = true;          // DPP-transposed 16-byte-store epilogue for wave tiles without epilogue prefetch
+    bool a_planes = true;        // LayerNorm -> Linear pairs of the AR layers: the LayerNorm kernel writes its output as fp16 planes and the x3h
+                                 // GEMM takes them as they are (GemmP::a_planes) wherever gemm_takes_planes() says so
     bool ldr64 = false;          // tests / measurement: the x3h loaders' 64-bit global_load_lds form (what operands of 2 GiB or more get)
     int ldr_prio = 3;            // issue priority (s_setprio 0..3) of the loader waves (gemm_x6_ldr / gemm_x6_ks / conv_win_x6 kernels)
     int skinny_rows = 64;        // linear layers with at most this many rows (<= 64) run on the weight-streaming kernel of
@@ -146,6 +150,8 @@ struct EngineOpts {
                                  // +0.46 % for the ADM alone at 2048, +0.1 % at 1280)
 };
 hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
+// would launch_gemm run this launch (planes attached, no prologue) on an x3h tile that takes its A operand as fp16 planes (a_planes)?
+bool gemm_takes_planes(const GemmP& p, const EngineOpts& o);
 // gemm_x3h.hip: the kernels of the fp16-pipe form by tile id and variant (prologue none / relu / leaky relu / - / - / pair statistics);
 // nullptr: no such variant
 enum X3hTile : int { X3H_LDR_128x128 = 0, X3H_KS_32x64_K4, X3H_KS_64x64_K2, X3H_KS_32x32_K8, X3H_WIN_256x64, X3H_WIN_128x128, X3H_WIN_256x32, kX3hTiles };
@@ -178,6 +184,9 @@ struct LnP {
     const int* valid; int valid_rows;
     float* out; int ldo;
     int M, C; float eps; int act;
+    int out_planes = 0;         // 1: `out` receives fp16 planes ([32 hi | 32 lo] per 32 channels, the A operand of a GemmP::a_planes launch;
+                                // same bytes and row stride as f32; C % 32 == 0) instead of f32; x3h_flag: the range guard's device word
+    int* x3h_flag = nullptr;
 };
 hipError_t launch_layernorm(const LnP& p, hipStream_t s);
 
@@ -189,6 +198,8 @@ struct LnReduceP {
     const float* gamma; const float* beta;
     float* xout; int ldx; float* hout; int ldh;
     int M, C; float eps;
+    int h_planes = 0;           // 1: hout receives fp16 planes (LnP::out_planes); the one-row-per-workgroup kernel only (M <= 4096)
+    int* x3h_flag = nullptr;
 };
 hipError_t launch_ln_reduce(const LnReduceP& p, hipStream_t s);
 

@@ -21,6 +21,22 @@ __device__ __forceinline__ float act_rt2(int act, float v) {
     }
 }
 
+// Four consecutive channels c .. c + 3 of a row as fp16 planes (LnP::out_planes; x3h_planes.h's block layout without a row scale: per 32
+// channels a 128-byte block [32 hi | 32 lo], hi = fp16_rn(v), lo = fp16_rn((v - hi) * 2^11) - what gemm_x3h.hip's split produces in
+// registers).  Returns max |v| for the range guard.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float store_planes4(float* __restrict__ row, int c, const float4& y) {
+    const f16x2_t h01 = __builtin_convertvector((f32x2_t){y.x, y.y}, f16x2_t), h23 = __builtin_convertvector((f32x2_t){y.z, y.w}, f16x2_t);
+    const float s = 2048.0f;
+    const f16x2_t l01 = __builtin_convertvector((f32x2_t){__builtin_fmaf((float)h01[0], -s, y.x * s), __builtin_fmaf((float)h01[1], -s, y.y * s)}, f16x2_t);
+    const f16x2_t l23 = __builtin_convertvector((f32x2_t){__builtin_fmaf((float)h23[0], -s, y.z * s), __builtin_fmaf((float)h23[1], -s, y.w * s)}, f16x2_t);
+    char* blk = reinterpret_cast<char*>(row) + (c >> 5) * 128 + (c & 31) * 2;
+    *reinterpret_cast<uint2*>(blk) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+    *reinterpret_cast<uint2*>(blk + 64) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
+    return fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
+}
+
 // ---------------------------------------------------------------------------------------------------
 // LayerNorm: F.layer_norm(x, (C,), gamma, beta, eps=1e-5) at reference modules/convnet.py:29,
 // modules/transformer.py:94-99, modules/mrte.py:168.  Two-pass (mean, then centred variance) in
@@ -87,7 +103,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnP p) {
                 const float4 r = *reinterpret_cast<const float4*>(p.R2 + (long long)m * p.ldr2 + c);
                 y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
             }
-            *reinterpret_cast<float4*>(out + c) = y;
+            if (p.out_planes) { if (store_planes4(out, c, y) >= 65504.0f && p.x3h_flag) atomicOr(p.x3h_flag, 1); }
+            else *reinterpret_cast<float4*>(out + c) = y;
         }
     }
 }
@@ -198,12 +215,14 @@ __global__ __launch_bounds__(256) void ln_reduce_row_kernel(LnReduceP p) {
         y.y = a.y * rstd * gv.y + bv.y;
         y.z = a.z * rstd * gv.z + bv.z;
         y.w = a.w * rstd * gv.w + bv.w;
-        *reinterpret_cast<float4*>(p.hout + (long long)m * p.ldh + c) = y;
+        if (p.h_planes) { if (store_planes4(p.hout + (long long)m * p.ldh, c, y) >= 65504.0f && p.x3h_flag) atomicOr(p.x3h_flag, 1); }
+        else *reinterpret_cast<float4*>(p.hout + (long long)m * p.ldh + c) = y;
     }
 }
 hipError_t launch_ln_reduce(const LnReduceP& p, hipStream_t s) {
     if (p.M <= 0) return hipSuccess;
     if (p.C > 1024 || (p.C & 3) || (p.ldx & 3) || (p.ldh & 3) || (p.ldr & 3) || p.S < 1) return hipErrorInvalidValue;
+    if (p.h_planes && (p.M > 4096 || (p.C & 31))) return hipErrorInvalidValue;
     if (p.M <= 4096)      // every AR step: one row per workgroup
         hipLaunchKernelGGL(ln_reduce_row_kernel, dim3(p.M), dim3(256), 0, s, p);
     else
@@ -214,6 +233,7 @@ hipError_t launch_ln_reduce(const LnReduceP& p, hipStream_t s) {
 hipError_t launch_layernorm(const LnP& p, hipStream_t s) {
     if (p.M <= 0) return hipSuccess;
     if (p.C > 1024 || (p.C & 3) || (p.ldx & 3) || (p.ldo & 3)) return hipErrorInvalidValue;
+    if (p.out_planes && ((p.C & 31) || p.R1 || p.R2 || p.act != ACT_NONE)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(layernorm_kernel, dim3((p.M + 3) / 4), dim3(256), 0, s, p);
     return hipGetLastError();
 }

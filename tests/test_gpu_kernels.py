@@ -354,6 +354,35 @@ def test_gemm_x3h_loader_address_forms_agree_bit_for_bit(rt, cfg, M, N, taps, ci
     assert rel(a, ref) < 2e-6
 
 
+@pytest.mark.parametrize("cfg,M,N,K", [(103, 864, 3072, 1024), (103, 333, 512, 768), (96, 224, 1024, 1024), (95, 100, 320, 1024),
+                                       (97, 200, 96, 768)])
+def test_layernorm_planes_feed_the_x3h_gemm_bit_for_bit(rt, cfg, M, N, K):
+    """Round 6: a LayerNorm whose only consumer is an x3h GEMM writes its output as fp16 planes (LnP::out_planes: per 32 channels a
+    128-byte block [32 hi | 32 lo], hi = fp16(v), lo = fp16((v - hi) * 2^11): exactly what the GEMM's compute waves produce in
+    registers from f32) and the GEMM takes them as they are (GemmP::a_planes; no split arithmetic in its K loop).  Same values, same
+    order of products: the result is bit-identical to LayerNorm (f32) -> GEMM; the planes themselves are pinned against numpy."""
+    import torch
+    rng = np.random.default_rng(cfg + M + N)
+    X = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-2, 2, (M, 1))) + rng.standard_normal((M, 1))).astype(np.float32)
+    g, b = (1 + 0.2 * rng.standard_normal(K)).astype(np.float32), (0.1 * rng.standard_normal(K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    h = rt.op_layernorm(dev(X), dev(g), dev(b))
+    hp = rt.op_layernorm(dev(X), dev(g), dev(b), act=100)            # the same rows as planes (same bytes per row)
+    hn = h.cpu().numpy()
+    hi = hn.astype(np.float16)
+    lo = ((hn - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    want = np.concatenate([hi.reshape(M, K // 32, 1, 32), lo.reshape(M, K // 32, 1, 32)], axis=2).reshape(M, 2 * K)
+    got = hp.cpu().numpy().view(np.float16).reshape(M, 2 * K)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    kw = dict(shift0=0, taps=1, dil=1, Cin=K, pro_act=rt.ACT_NONE, epi_act=rt.ACT_RELU)
+    y0 = rt.op_conv_x3h(h, dev(W), dev(bias), None, force_cfg=cfg, **kw).cpu().numpy()
+    y1 = rt.op_conv_x3h(hp, dev(W), dev(bias), None, force_cfg=cfg + 2000, **kw).cpu().numpy()
+    assert np.isfinite(y0).all() and np.array_equal(y0, y1)
+    ref = np.maximum(hn.astype(np.float64) @ W.T.astype(np.float64) + bias, 0)
+    assert rel(y0, ref) < 2e-6
+
+
 @pytest.mark.parametrize("cfg", [103, 96])
 def test_gemm_x3h_range_guard_and_corner_cases(rt, cfg):
     """The fp16 form's range behaviour, documented in gemm_x3h.hip: (1) activations up to 6e4 and weights of any magnitude (1e-30

@@ -734,7 +734,9 @@ def x3h_split_native(W):
 def op_conv_x3h(X, W, bias=None, R=None, valid=None, shift0=0, taps=1, dil=1, Cin=None, pro_act=ACT_NONE, pro_slope=0.0,
                 epi_act=ACT_NONE, force_cfg=-1, want_flag=False):
     """mt2_op_gemm_x3h: one GEMM / convolution launch with the weights given as f32, as bf16 planes and as fp16 planes (so that
-    every tile configuration can be forced): X [rows, Cin] f32, W [N, taps*Cin] f32.  want_flag -> (out, range flag)."""
+    every tile configuration can be forced): X [rows, Cin] f32, W [N, taps*Cin] f32.  want_flag -> (out, range flag).
+    Test conventions of the entry point: force_cfg + 1000 = the same launch with the loaders' 64-bit address form; + 2000 = X holds
+    fp16 planes written by op_layernorm(..., act=100) (GemmP::a_planes)."""
     import torch
     lib = load_library()
     Cin = Cin or X.shape[1]

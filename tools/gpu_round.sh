@@ -17,6 +17,10 @@
 #   graph newtests                   hipGraph replay vs stream launches (boundary ubench); this round's new parity tests (TEST_K)
 #   gridsync cpuinfo                 phase-boundary ubench (launch chain vs in-kernel grid barrier); host CPU limits of the box
 #   strong                           bench.py --scaling strong on one rank (C4: 256 ragged utterances in one call)
+#   vbench vsweep                    C3 bench / a GEMM sweep in measurement builds (tools/build_variant.sh) interleaved with the production library
+#   phase3h ablate3h overheads3h pmcx3h   x3h kernels: phase timers (compute + loader wave), ablation builds, launch overheads, SQ counters
+#   sweep_x3h sweep_x3hk sweep_x3hxc  x3h tile sweeps (loader tile / K-split + window tiles / cross-chunk forms)
+#   power conc                       package power + shader clock while C3 runs (sysfs); kernel concurrency per stage of a traced step
 # everything is written under gpurun_out/ (scratch); summaries worth keeping are copied to profiles/ by hand.
 mkdir -p gpurun_out
 export TMPDIR=/tmp

@@ -1,5 +1,6 @@
-"""Where a wave of the x3h loader-wave GEMM (gemm_x3h_ldr_kernel) spends its cycles: per-phase s_memtime sums of one compute wave
-per 32-deep chunk (barrier, first fragment fetch, second fetch + first split, LDS wait of k-block 1, products).  Needs a library
+"""Where the waves of the x3h GEMMs spend their cycles: s_memtime sums of loader wave 0 per chunk / round (vmcnt wait, barrier, issue) for
+gemm_x3h_ldr_kernel and gemm_x3h_ks_kernel (the compute-wave phases of the one-barrier-per-chunk loop - barrier, first fragment fetch,
+split, products - were measured with the same build until that loop was retired: profiles/r06_x3h_phase_timing_v1.txt).  Needs a library
 built with -DMT2_PHASE_TIMING (tools/build_variant.sh h_phase "-DMT2_PHASE_TIMING"; tools/gpu_round.sh phase3h)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1832,8 +1832,8 @@ bool gemm_takes_planes(const GemmP& p_in, const EngineOpts& o) {
     if (p.a_mul == 0) p.a_mul = 1;
     p.K = p.taps * p.Cin;
     if (p.ldw == 0) p.ldw = p.K;
-    if (!(o.x3h & 3) || o.force_cfg >= 0 || p.M <= 64 || p.groups != 1 || p.pro_act != ACT_NONE || p.stat_out || p.taps != 1 || (p.K % BK) != 0 ||
-        (p.ldx % BK) != 0 || p.a_mul != 1 || p.shift0 != 0 || p.rowbase || !p.Wh || !p.wh_inv || (((unsigned long long)p.X) & 127))
+    if (!(o.x3h & 3) || o.force_cfg >= 0 || p.M <= 64 || p.pro_act != ACT_NONE || p.stat_out || (p.Cin % BK) != 0 || (p.ldx % BK) != 0 ||
+        (p.groups > 1 && (p.strideX % BK) != 0) || p.a_mul != 1 || p.rowbase || !p.Wh || !p.wh_inv || (((unsigned long long)p.X) & 127))
         return false;
     int idx = -1;
     const TileCfg* c = choose_cfg(p, o, &idx);
@@ -1921,8 +1921,8 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     }
     // variant index: pair statistics (consumer and / or producer side) run the PRO_LNX instantiation - the K loop of ACT_NONE
     // ... an A operand that arrives as fp16 planes (a_planes) runs the PRO_APL instantiation: x3h loader / K-split tiles only
-    if (p.a_planes && (c->x3h < 0 || c->win_qs || p.pro_act != ACT_NONE || p.stat_out || p.taps != 1 || (p.K % BK) != 0 || (p.ldx % BK) != 0 ||
-                       (((unsigned long long)p.X) & 127)))
+    if (p.a_planes && (c->x3h < 0 || c->win_qs || p.pro_act != ACT_NONE || p.stat_out || (p.Cin % BK) != 0 || (p.ldx % BK) != 0 ||
+                       (p.groups > 1 && (p.strideX % BK) != 0) || p.a_mul != 1 || p.rowbase || (((unsigned long long)p.X) & 127)))
         return hipErrorNotSupported;
     const int fi = p.a_planes ? PRO_APL : ((p.pro_act == PRO_LNX || p.stat_out) ? PRO_LNX : p.pro_act);
     // LayerNorm as a prologue of the f32 tiles (pro_act 3 / 4: rounds 1-2, measured slower than LayerNorm + GEMM) is retired: callers

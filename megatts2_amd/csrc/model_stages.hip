@@ -234,11 +234,12 @@ static void conv_same(const Ctx& c, const float* x, int ldx, int R, const ConvW&
 static void layernorm(const Ctx& c, const float* x, int ldx, const float* g, const float* b, int M, int C,
                       float* out, int ldo, const int* valid = nullptr, int valid_rows = 0,
                       const float* R1 = nullptr, int ldr1 = 0, int r1_rows = 0, int rows_per_group = 0,
-                      int act = ACT_NONE) {
+                      int act = ACT_NONE, bool out_planes = false) {
     LnP p{};
     p.x = x; p.ldx = ldx; p.gamma = g; p.beta = b; p.rows_per_group = rows_per_group;
     p.R1 = R1; p.ldr1 = ldr1; p.r1_rows = r1_rows; p.valid = valid; p.valid_rows = valid_rows;
     p.out = out; p.ldo = ldo; p.M = M; p.C = C; p.eps = 1e-5f; p.act = act;
+    p.out_planes = out_planes ? 1 : 0; p.x3h_flag = c.m.opts.x3h_flag;
     MT2_HIP(launch_layernorm(p, c.s));
 }
 
@@ -261,25 +262,39 @@ static float* run_stack(const Ctx& c, const StackW& w, const float* x_in, bool s
         const float* bin = cur;
         bool bin_shared = cur_shared;
         bool bin_relued = false;    // a block output with ONE consumer (the next block's conv) is stored ReLU'd
-        for (int blk = 0; blk < w.nblock; ++blk) {
+        bool bin_planes = false;    // ... and as fp16 planes when that conv runs on an x3h tile that takes them (GemmP::a_planes)
+        auto block_conv = [&](int blk, const float* in, bool in_shared, bool relued, bool planes) {
             const size_t e = w.idx(st, blk);
             GemmP p{};
-            p.X = bin; p.strideX = bin_shared ? 0 : (long long)per; p.ldx = C; p.Rx = R;
+            p.X = in; p.strideX = in_shared ? 0 : (long long)per; p.ldx = C; p.Rx = R;
             p.taps = w.k; p.shift0 = -((w.k - 1) / 2); p.Cin = C;
             p.W = w.w + e * wsz; p.strideW = (long long)wsz;
             p.bias = w.b + e * C; p.strideB = C;
             p.valid = valid; p.C = T; p.strideC = (long long)per; p.ldc = C; p.M = R; p.N = C; p.groups = G;
-            p.pro_act = bin_relued ? ACT_NONE : ACT_RELU;
-            gemm(c, p);
+            p.pro_act = relued ? ACT_NONE : ACT_RELU;
+            p.a_planes = planes ? 1 : 0;
+            return p;
+        };
+        for (int blk = 0; blk < w.nblock; ++blk) {
+            const size_t e = w.idx(st, blk);
+            gemm(c, block_conv(blk, bin, bin_shared, bin_relued, bin_planes));
             const bool last = blk == w.nblock - 1;
+            bool planes = false;
+            if (!last && c.m.opts.a_planes) {       // will the next block's conv take Y as planes?
+                GemmP q = block_conv(blk + 1, Y, false, true, false);
+                q.dil = 1; q.a_mul = 1; q.out_scale = 1.0f; q.K = q.taps * q.Cin; q.ldw = q.K;
+                attach_planes(c.m, q);
+                planes = gemm_takes_planes(q, c.m.opts);
+            }
             if (last)
                 layernorm(c, T, C, w.g + e * C, w.be + e * C, R * G, C, nxt, C, valid, R, cur, C,
                           cur_shared ? R : 0, R);
             else   // next ConvBlock starts with ReLU (convnet.py:24): fold it into this LayerNorm's store
-                layernorm(c, T, C, w.g + e * C, w.be + e * C, R * G, C, Y, C, valid, R, nullptr, 0, 0, R, ACT_RELU);
+                layernorm(c, T, C, w.g + e * C, w.be + e * C, R * G, C, Y, C, valid, R, nullptr, 0, 0, R, ACT_RELU, planes);
             bin = Y;
             bin_shared = false;
             bin_relued = !last;
+            bin_planes = planes;
         }
         cur = nxt;
         cur_shared = false;

@@ -49,7 +49,7 @@ struct GemmP {
     int epi_t4 = 1;             // 16-byte-store epilogue where the layout allows it (set by launch_gemm from EngineOpts::epi_t4)
     int sk_nw = 8;              // gemm_skinny_tm_kernel: waves per workgroup that split K (8; 16 = option skinny_nw, set by launch_gemm)
     int a_planes = 0;           // 1: X holds fp16 planes ([32 hi | 32 lo] per 32 k of a row, x3h_planes.h's block layout without a row scale)
-                                // written by a producer kernel (LnP::out_planes): x3h loader / K-split tiles only, no prologue, taps = 1, K % 32 = 0
+                                // written by a producer kernel (LnP::out_planes): x3h loader / K-split tiles only, no prologue, Cin % 32 = 0
     int ldr64 = 0;              // x3h loaders: 1 = the 64-bit global_load_lds form even where buffer loads would do (EngineOpts::ldr64)
     int ldr_prio = 0;           // s_setprio of the loader waves of the loader-wave kernels (set by launch_gemm from EngineOpts::ldr_prio)
     const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like

@@ -233,7 +233,7 @@ hipError_t launch_ln_reduce(const LnReduceP& p, hipStream_t s) {
 hipError_t launch_layernorm(const LnP& p, hipStream_t s) {
     if (p.M <= 0) return hipSuccess;
     if (p.C > 1024 || (p.C & 3) || (p.ldx & 3) || (p.ldo & 3)) return hipErrorInvalidValue;
-    if (p.out_planes && ((p.C & 31) || p.R1 || p.R2 || p.act != ACT_NONE)) return hipErrorInvalidValue;
+    if (p.out_planes && ((p.C & 31) || p.R1 || p.R2)) return hipErrorInvalidValue;      // (planes of act(LN(x)): the activation is applied first)
     hipLaunchKernelGGL(layernorm_kernel, dim3((p.M + 3) / 4), dim3(256), 0, s, p);
     return hipGetLastError();
 }

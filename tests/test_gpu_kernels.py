@@ -383,6 +383,30 @@ def test_layernorm_planes_feed_the_x3h_gemm_bit_for_bit(rt, cfg, M, N, K):
     assert rel(y0, ref) < 2e-6
 
 
+@pytest.mark.parametrize("M,C,taps", [(3000, 512, 3), (1500, 384, 5)])
+def test_layernorm_relu_planes_feed_a_convolution_bit_for_bit(rt, M, C, taps):
+    """The same hand-over inside the conv stacks (ConvBlock = ReLU -> Conv1d -> LayerNorm, modules/convnet.py:23-31): the LayerNorm of
+    a block stores ReLU(LN(x)) for the next block's convolution - as fp16 planes when that convolution runs on the x3h loader tile
+    (taps > 1: halo rows above and below the operand, tap boundaries at whole 32-channel blocks).  Bit-identical to the f32 hand-over."""
+    rng = np.random.default_rng(M + C + taps)
+    G = (taps - 1) // 2
+    X = (rng.standard_normal((M, C)) * np.exp(rng.uniform(-2, 2, (M, 1)))).astype(np.float32)
+    g, b = (1 + 0.2 * rng.standard_normal(C)).astype(np.float32), (0.1 * rng.standard_normal(C)).astype(np.float32)
+    W = (rng.standard_normal((C, taps * C)) / math.sqrt(taps * C)).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32)
+    h = rt.op_layernorm(dev(X), dev(g), dev(b), act=rt.ACT_RELU)
+    hp = rt.op_layernorm(dev(X), dev(g), dev(b), act=rt.ACT_RELU + 100)
+    kw = dict(shift0=-G, taps=taps, dil=1, Cin=C, pro_act=rt.ACT_NONE, epi_act=rt.ACT_NONE)
+    y0 = rt.op_conv_x3h(h, dev(W), dev(bias), None, force_cfg=103, **kw).cpu().numpy()
+    y1 = rt.op_conv_x3h(hp, dev(W), dev(bias), None, force_cfg=103 + 2000, **kw).cpu().numpy()
+    assert np.isfinite(y0).all() and np.array_equal(y0, y1)
+    hn = h.cpu().numpy().astype(np.float64)
+    ap = np.zeros((M + 2 * G, C))
+    ap[G:G + M] = hn
+    ref = sum(ap[t:t + M] @ W[:, t * C:(t + 1) * C].T.astype(np.float64) for t in range(taps)) + bias
+    assert rel(y0, ref) < 2e-6
+
+
 @pytest.mark.parametrize("cfg", [103, 96])
 def test_gemm_x3h_range_guard_and_corner_cases(rt, cfg):
     """The fp16 form's range behaviour, documented in gemm_x3h.hip: (1) activations up to 6e4 and weights of any magnitude (1e-30

@@ -310,7 +310,9 @@ int mt2_op_attention(void* stream, const float* Q, int ldq, const float* K, int 
 /* ... with the kernel choice exposed: lds_min_qlen = first query count served by the LDS-tiled kernel (0 never, < 0 default),
  * lds_waves = its query tiles per workgroup (8, otherwise 4); x6_min_qlen = first query count served by the bf16-pipe
  * kernel (f32-equivalent six-product form, head dims 64 / 96; 0 never, < 0 default); lds_waves + 32: the register kernel instead of the
- * head-dim-split kernel that serves D = 64 / 96 with at most 128 keys; max_kvlen: longest key range of the launch (0 = unknown). */
+ * head-dim-split kernel that serves D = 64 / 96 with at most 128 keys; lds_waves + 64: O receives fp16 planes (the operand format the
+ * out-projection's x3h GEMM takes as it is: per 32 columns 32 hi | 32 lo fp16, same bytes per row; ldo % 32 == 0, O on 128 bytes);
+ * max_kvlen: longest key range of the launch (0 = unknown). */
 int mt2_op_attention_tuned(void* stream, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                            float* O, int ldo, const int32_t* q_start, const int32_t* q_len, const int32_t* kv_start,
                            const int32_t* kv_len, int B, int H, int D, int max_qlen, float scale, int lds_min_qlen,

@@ -23,7 +23,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmegatts2_hip.so")
 UNITS = ["gemm_f32.hip", "gemm_x3h.hip", "gemm_skinny.hip", "attention.hip", "rowops.hip", "model_load.hip", "model_stages.hip"]
 AUDITED = ["gemm_f32.hip", "gemm_x3h.hip"]      # units whose device assembly is audited (inline-asm LDS reads in loops)
-DEPS = ["mt2_kernels.h", "mt2_model.h", "gemm_common.h", "x3h_planes.h", "capi.inc", os.path.join("..", "..", "include", "megatts2_hip.h")]
+DEPS = ["mt2_kernels.h", "mt2_model.h", "gemm_common.h", "x3h_planes.h", "planes_store.h", "capi.inc", os.path.join("..", "..", "include", "megatts2_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 FLAGS += os.environ.get("MT2_EXTRA_HIPCC_FLAGS", "").split()      # e.g. -DMT2_PHASE_TIMING (tools/x6_phase_timing.py)
 # per unit: the fp16 split of gemm_x3h.hip wants scalar f32 VALU (v_mul_f32 + v_fma_mix_f32), not hipcc's SLP-packed v_pk_* forms

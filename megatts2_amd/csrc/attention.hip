@@ -23,11 +23,20 @@
 // (utterance, head, 32 queries)), so what matters is that a tile costs one memory round trip, not D/8.
 // attn_f32_kernel<DT> is the streaming form for the wide heads (2x256 phone encoder, 1x512 cross).
 #include "mt2_kernels.h"
+#include "planes_store.h"
 #include <math.h>
 
 namespace mt2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// four consecutive head-dim columns of an output row: f32, or fp16 planes for an out-projection that takes them (AttnP::o_planes)
+__device__ __forceinline__ void attn_store4(const AttnP& p, float* __restrict__ row, int c, const float4& v) {
+    if (p.o_planes) {
+        if (store_planes4(row, c, v) >= 65504.0f && p.x3h_flag) atomicOr(p.x3h_flag, 1);
+    } else
+        *reinterpret_cast<float4*>(row + c) = v;
+}
 
 template <int DT>   // DT 32-column tiles of the head dim per wave
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
@@ -107,7 +116,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
     }
     if (!qok) return;
     const float inv = 1.0f / l_run;
-    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo + h * D + d0 + 4 * half;
+    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo;
+    const int oc = h * D + d0 + 4 * half;
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnP p) {
             v.y = o[t][4 * e4 + 1] * inv;
             v.z = o[t][4 * e4 + 2] * inv;
             v.w = o[t][4 * e4 + 3] * inv;
-            *reinterpret_cast<float4*>(orow + t * 32 + 8 * e4) = v;
+            attn_store4(p, orow, oc + t * 32 + 8 * e4, v);
         }
 }
 
@@ -255,7 +265,8 @@ __global__ __launch_bounds__(256) void attn_f32_reg_kernel(AttnP p) {
     }
     if (!qok) return;
     const float inv = 1.0f / l_run;
-    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo + h * D + 4 * half;
+    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo;
+    const int oc = h * D + 4 * half;
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(256) void attn_f32_reg_kernel(AttnP p) {
             v.y = o[t][4 * e4 + 1] * inv;
             v.z = o[t][4 * e4 + 2] * inv;
             v.w = o[t][4 * e4 + 3] * inv;
-            *reinterpret_cast<float4*>(orow + t * 32 + 8 * e4) = v;
+            attn_store4(p, orow, oc + t * 32 + 8 * e4, v);
         }
 }
 
@@ -385,7 +396,8 @@ __global__ __launch_bounds__(768) void attn_f32_ds_kernel(AttnP p) {
     }
     if (!qok) return;
     const float inv = 1.0f / l_run;
-    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo + h * D + ds * 32 + 4 * half;
+    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo;
+    const int oc = h * D + ds * 32 + 4 * half;
 #pragma unroll
     for (int e4 = 0; e4 < 4; ++e4) {
         float4 v;
@@ -393,7 +405,7 @@ __global__ __launch_bounds__(768) void attn_f32_ds_kernel(AttnP p) {
         v.y = o[4 * e4 + 1] * inv;
         v.z = o[4 * e4 + 2] * inv;
         v.w = o[4 * e4 + 3] * inv;
-        *reinterpret_cast<float4*>(orow + 8 * e4) = v;
+        attn_store4(p, orow, oc + 8 * e4, v);
     }
 }
 template <int D>
@@ -540,7 +552,8 @@ __global__ __launch_bounds__(64 * NWQ) void attn_f32_lds_kernel(AttnP p) {
     }
     if (!active || !qok) return;
     const float inv = 1.0f / l_run;
-    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo + h * D + 4 * half;
+    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo;
+    const int oc = h * D + 4 * half;
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -550,7 +563,7 @@ __global__ __launch_bounds__(64 * NWQ) void attn_f32_lds_kernel(AttnP p) {
             v.y = o[t][4 * e4 + 1] * inv;
             v.z = o[t][4 * e4 + 2] * inv;
             v.w = o[t][4 * e4 + 3] * inv;
-            *reinterpret_cast<float4*>(orow + t * 32 + 8 * e4) = v;
+            attn_store4(p, orow, oc + t * 32 + 8 * e4, v);
         }
 }
 
@@ -809,7 +822,8 @@ __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) v
     }
     if (!active || !qok) return;
     const float inv = 1.0f / l_run;
-    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo + h * D + 4 * half;
+    float* __restrict__ orow = p.O + (long long)(os + qrow) * p.ldo;
+    const int oc = h * D + 4 * half;
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
@@ -819,7 +833,7 @@ __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) v
             v.y = o[t][4 * e4 + 1] * inv;
             v.z = o[t][4 * e4 + 2] * inv;
             v.w = o[t][4 * e4 + 3] * inv;
-            *reinterpret_cast<float4*>(orow + t * 32 + 8 * e4) = v;
+            attn_store4(p, orow, oc + t * 32 + 8 * e4, v);
         }
 }
 
@@ -845,6 +859,7 @@ static hipError_t launch_attn_x6_d(const AttnP& p, hipStream_t s) {
 hipError_t launch_attention(const AttnP& p, hipStream_t s) {
     if (p.B <= 0 || p.H <= 0 || p.max_qlen <= 0) return hipSuccess;
     if (p.D % 32 != 0 || (p.ldq & 3) || (p.ldk & 3) || (p.ldo & 3)) return hipErrorInvalidValue;
+    if (p.o_planes && ((p.ldo & 31) || (((unsigned long long)p.O) & 127))) return hipErrorInvalidValue;      // whole 128-byte blocks per row
     if ((p.D == 64 || p.D == 96) && p.x6_min_qlen > 0 && p.max_qlen >= p.x6_min_qlen && ((p.ldq | p.ldk) & 3) == 0)
         return p.D == 64 ? launch_attn_x6_d<64>(p, s) : launch_attn_x6_d<96>(p, s);
     if (p.D <= 128 && p.max_qlen >= p.lds_min_qlen && p.lds_min_qlen > 0 && (p.ldv & 3) == 0) {

@@ -3,6 +3,7 @@
 // row-statistics pairs), the LayerNorm pair merge, LDS read / counted-wait / loader-priority primitives.
 #pragma once
 #include "mt2_kernels.h"
+#include "planes_store.h"
 #include <type_traits>
 #include <utility>
 
@@ -295,7 +296,8 @@ __device__ __forceinline__ bool epilogue_t4_ok(const GemmP& p) {
 // STAT (GemmP::stat_out, one 32-row block per wave): the (mean, M2) pair of every output row over the wave tile's 32 TN columns - after
 // the transposition a lane holds 4 consecutive columns of row 8 q + rr, the row's other columns sit in the 7 lanes that differ in lane
 // bits 2-4: three butterfly steps per quantity, fixed order.
-template <int TM, int TN, bool STAT = false>
+// PLN: the kernel may be asked for fp16 planes instead of f32 (GemmP::c_planes; x3h loader tile).
+template <int TM, int TN, bool STAT = false, bool PLN = false>
 __device__ __forceinline__ void epilogue_t4(const GemmP& p, f32x16 (&acc)[TM][TN], int g, int mw, int nw, int lane) {
     static_assert(!STAT || TM == 1, "row statistics: one 32-row block per wave");
     float* __restrict__ C = p.C + (long long)g * p.strideC;
@@ -361,6 +363,9 @@ __device__ __forceinline__ void epilogue_t4(const GemmP& p, f32x16 (&acc)[TM][TN
                         for (int e = 0; e < 4; ++e) v[e] += rv[i][j][q][e];
                     }
                     if (vm[i][q] == 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (PLN && p.c_planes) {
+                        if (store_planes4(C + (long long)m * p.ldc, n, v[0], v[1], v[2], v[3]) >= 65504.0f && p.x3h_flag) atomicOr(p.x3h_flag, 1);
+                    } else
                     *reinterpret_cast<f32x4*>(C + (long long)m * p.ldc + n) = v;
                 }
                 if constexpr (STAT) {                   // of the FINAL values (0 outside M x N)

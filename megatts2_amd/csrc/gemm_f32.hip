@@ -1840,6 +1840,24 @@ bool gemm_takes_planes(const GemmP& p_in, const EngineOpts& o) {
     return c && c->x3h >= 0 && !c->win_qs && c->fn[PRO_APL] != nullptr;
 }
 
+// C as fp16 planes (GemmP::c_planes): the x3h loader tile's 16-byte-store epilogue, whole 128-byte blocks per row, one group
+static bool c_planes_ok(const GemmP& p, const TileCfg* c) {
+    return c && c->x3h >= 0 && !c->x6_ks && !c->win_qs && p.groups == 1 && !p.R && !p.stat_out && (p.N & 31) == 0 && (p.ldc & 31) == 0 &&
+           (((unsigned long long)p.C) & 127) == 0 && (((unsigned long long)p.bias) & 15) == 0 && ((p.strideC | p.strideB) & 3) == 0 && p.Wh && p.wh_inv && p.M > 64;
+}
+bool gemm_writes_planes(const GemmP& p_in, const EngineOpts& o) {
+    GemmP p = p_in;
+    if (p.taps <= 0) p.taps = 1;
+    if (p.groups <= 0) p.groups = 1;
+    if (p.a_mul == 0) p.a_mul = 1;
+    p.K = p.taps * p.Cin;
+    if (p.ldw == 0) p.ldw = p.K;
+    if (!(o.x3h & 1) || o.force_cfg >= 0 || !o.epi_t4 || p.M <= 64) return false;
+    int idx = -1;
+    const TileCfg* c = choose_cfg(p, o, &idx);
+    return c_planes_ok(p, c);
+}
+
 hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     static const EngineOpts kDefaults;
     const EngineOpts& o = opts ? *opts : kDefaults;
@@ -1848,6 +1866,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     if ((p.Cin & 3) || (p.ldx & 3) || (p.ldw & 3) || p.K != p.taps * p.Cin) return hipErrorInvalidValue;
     if (p.pro_act < 0 || p.pro_act > PRO_LNX) return hipErrorInvalidValue;
     if (opts) opts->last_stat_nt = opts->last_stat_w = 0;
+    if (p.c_planes && p.M <= 64) return hipErrorNotSupported;      // (the <= 64-row kernels write f32)
     if (p.pro_act == PRO_LNX && (p.taps != 1 || p.groups != 1 || !p.ln_g || !p.ln_stat || p.ln_nt < 2 || p.ln_nt > 32 ||
                                  (p.ln_nt & 1) || p.ln_w <= 0 || p.ln_nt * p.ln_w != p.K || (((unsigned long long)p.ln_stat) & 15)))
         return hipErrorInvalidValue;
@@ -1924,6 +1943,7 @@ hipError_t launch_gemm(const GemmP& p_in, hipStream_t s, EngineOpts* opts) {
     if (p.a_planes && (c->x3h < 0 || c->win_qs || p.pro_act != ACT_NONE || p.stat_out || (p.Cin % BK) != 0 || (p.ldx % BK) != 0 ||
                        (p.groups > 1 && (p.strideX % BK) != 0) || p.a_mul != 1 || p.rowbase || (((unsigned long long)p.X) & 127)))
         return hipErrorNotSupported;
+    if (p.c_planes && !(c_planes_ok(p, c) && o.epi_t4)) return hipErrorNotSupported;
     const int fi = p.a_planes ? PRO_APL : ((p.pro_act == PRO_LNX || p.stat_out) ? PRO_LNX : p.pro_act);
     // LayerNorm as a prologue of the f32 tiles (pro_act 3 / 4: rounds 1-2, measured slower than LayerNorm + GEMM) is retired: callers
     // fall back on NotSupported; the <= 64-row weight-streaming kernel (above) keeps its own LayerNorm prologue

@@ -614,8 +614,8 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void gemm_x3h_ldr_kernel(Gem
         }
         // (launch_gemm admits the PRO_LNX variant only with N, ldc, ldr multiples of 4 and 16-byte aligned bases: epilogue_t4_ok)
         if (p.stat_out) epilogue_t4<TM, TN, true>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-        else epilogue_t4<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
-    } else if (p.epi_t4 && epilogue_t4_ok(p)) epilogue_t4<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+        else epilogue_t4<TM, TN, false, true>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
+    } else if (p.epi_t4 && epilogue_t4_ok(p)) epilogue_t4<TM, TN, false, true>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     else epilogue<TM, TN>(p, acc, g, m0 + wm * WTM, n0 + wn * WTN, lane);
     if (probe) {                                  // ticks spent in the epilogue (stores issued, not necessarily retired)
         __builtin_amdgcn_s_waitcnt(0);

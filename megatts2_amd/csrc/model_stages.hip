@@ -125,11 +125,23 @@ static void gemm(const Ctx& c, GemmP p) {
 // y[M, N] = x[M, K] @ W^T + b  (F.linear)
 static void linear(const Ctx& c, const float* x, int ldx, int M, const float* W, const float* b, int N, int K,
                    float* y, int ldy, const float* R = nullptr, int ldr = 0, const int* valid = nullptr,
-                   int epi_act = ACT_NONE, bool a_planes = false) {
+                   int epi_act = ACT_NONE, bool a_planes = false, bool c_planes = false) {
     GemmP p{};
     p.X = x; p.ldx = ldx; p.Rx = M; p.Cin = K; p.W = W; p.bias = b; p.R = R; p.ldr = ldr; p.valid = valid;
-    p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.epi_act = epi_act; p.a_planes = a_planes ? 1 : 0;
+    p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.epi_act = epi_act; p.a_planes = a_planes ? 1 : 0; p.c_planes = c_planes ? 1 : 0;
     gemm(c, p);
+}
+// the fields gemm() fills in before launch_gemm, for the queries gemm_takes_planes / gemm_writes_planes on a launch not yet made
+static GemmP planned(const Ctx& c, GemmP p) {
+    if (p.taps <= 0) p.taps = 1;
+    if (p.dil <= 0) p.dil = 1;
+    if (p.a_mul == 0) p.a_mul = 1;
+    if (p.groups <= 0) p.groups = 1;
+    if (p.out_scale == 0.0f) p.out_scale = 1.0f;
+    p.K = p.taps * p.Cin;
+    if (p.ldw == 0) p.ldw = p.K;
+    attach_planes(c.m, p);
+    return p;
 }
 // Will linear(x -> y) run on an x3h tile that takes x as fp16 planes (GemmP::a_planes)?  Then the LayerNorm that produces x writes
 // planes (LnP::out_planes / LnReduceP::h_planes: same bytes, same row stride) and the GEMM's K loop holds no split arithmetic - in
@@ -171,8 +183,10 @@ static LnOps ln_ops(const float* g, const float* b, const float* W, const float*
                  c ? c + n0 : nullptr};
 }
 static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, int shift0, int M, const LnOps& w, int N,
-                      int K, float* y, int ldy, float* h_scratch, int epi_act = ACT_NONE, const Pending* st = nullptr) {
+                      int K, float* y, int ldy, float* h_scratch, int epi_act = ACT_NONE, const Pending* st = nullptr,
+                      bool c_planes = false) {
     GemmP p{};
+    p.c_planes = c_planes ? 1 : 0;      // y as fp16 planes (the caller asked gemm_writes_planes; more than 64 rows)
     p.X = x; p.ldx = ldx; p.Rx = Rx; p.a_mul = a_mul ? a_mul : 1; p.shift0 = shift0; p.taps = 1; p.dil = 1; p.Cin = K;
     p.K = K; p.W = w.W; p.ldw = K; p.bias = w.bias; p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.groups = 1; p.out_scale = 1.0f;
     p.epi_act = epi_act; p.ln_eps = 1e-5f;
@@ -211,7 +225,7 @@ static void ln_linear(const Ctx& c, const float* x, int ldx, int Rx, int a_mul, 
     q.x = x + (long long)shift0 * ldx; q.ldx = ldx * p.a_mul; q.gamma = w.g; q.beta = w.b; q.out = h_scratch; q.ldo = K;
     q.M = M; q.C = K; q.eps = 1e-5f; q.act = ACT_NONE; q.out_planes = planes ? 1 : 0; q.x3h_flag = c.m.opts.x3h_flag;
     MT2_HIP(launch_layernorm(q, c.s));
-    linear(c, h_scratch, K, M, w.W, w.bias, N, K, y, ldy, nullptr, 0, nullptr, epi_act, planes);
+    linear(c, h_scratch, K, M, w.W, w.bias, N, K, y, ldy, nullptr, 0, nullptr, epi_act, planes, c_planes);
 }
 static LnOps ln1_qkv(const EncLayerW& w, int d, int n0 = 0) {
     return ln_ops(w.ln1g, w.ln1b, w.wqkv, w.bqkv, w.wqkv_l, w.sqkv, w.cqkv, n0, d);
@@ -322,8 +336,9 @@ static EncScratch enc_scratch(const Ctx& c, const EncW& e, int M) {
     s.stat = c.ws.get<float>((size_t)M * 128);     // row statistics handed from GEMM to GEMM: <= 64 (mean, M2) pairs per row
     return s;
 }
-static void attention_self(const Ctx& c, const EncW& e, const AttnGeom& g, const float* qkv, float* att) {
+static void attention_self(const Ctx& c, const EncW& e, const AttnGeom& g, const float* qkv, float* att, bool o_planes = false) {
     AttnP a{};
+    a.o_planes = o_planes ? 1 : 0; a.x3h_flag = c.m.opts.x3h_flag;
     const int d = e.d, D = d / e.heads;
     a.Q = qkv; a.ldq = 3 * d; a.K = qkv + d; a.ldk = 3 * d; a.V = qkv + 2 * d; a.ldv = 3 * d;
     a.O = att; a.ldo = d;
@@ -397,11 +412,16 @@ static int choose_split(const Ctx& c, int M, int N, int K) {
     return S;
 }
 // y_parts[g] = x[:, gK/S:(g+1)K/S] @ W[:, gK/S:(g+1)K/S]^T, g < S  (raw partial slabs [S][M, N])
-static void linear_splitk(const Ctx& c, const float* x, int ldx, int M, const float* W, int N, int K, int S,
-                          float* parts) {
+static GemmP splitk_params(const float* x, int ldx, int M, const float* W, int N, int K, int S, float* parts) {
     GemmP p{};
     p.X = x; p.strideX = K / S; p.ldx = ldx; p.Rx = M; p.Cin = K / S; p.W = W; p.strideW = K / S; p.ldw = K;
     p.C = parts; p.strideC = (long long)M * N; p.ldc = N; p.M = M; p.N = N; p.groups = S;
+    return p;
+}
+static void linear_splitk(const Ctx& c, const float* x, int ldx, int M, const float* W, int N, int K, int S,
+                          float* parts, bool a_planes = false) {
+    GemmP p = splitk_params(x, ldx, M, W, N, K, S, parts);
+    p.a_planes = a_planes ? 1 : 0;
     gemm(c, p);
 }
 // h = LayerNorm(x) after applying a pending update to x (in place)
@@ -422,17 +442,18 @@ static void ln_pending(const Ctx& c, float* x, int d, int M, const Pending& in, 
 }
 // h = LN(x (+ the pending split-K update)), y = act(h W^T + b): h travels as fp16 planes when the GEMM takes them
 static void ln_pending_linear(const Ctx& c, float* x, int d, int M, const Pending& in, const float* g, const float* b, float* h,
-                              const float* W, const float* bias, int N, float* y, int ldy, int epi_act = ACT_NONE) {
+                              const float* W, const float* bias, int N, float* y, int ldy, int epi_act = ACT_NONE,
+                              bool c_planes = false) {
     const bool planes = M <= 4096 && linear_takes_planes(c, h, d, M, W, bias, N, d, y, ldy, epi_act);
     ln_pending(c, x, d, M, in, g, b, h, planes);
-    linear(c, h, d, M, W, bias, N, d, y, ldy, nullptr, 0, nullptr, epi_act, planes);
+    linear(c, h, d, M, W, bias, N, d, y, ldy, nullptr, 0, nullptr, epi_act, planes, c_planes);
 }
 // everything after attention for M full rows: x += out_proj(att); h = LN2(x); f = relu(ff0(h));
 // x += ff1(f) - the last update is returned as pending when it was split
 // x += a @ W^T + b (residual update in the GEMM's epilogue); with ln_pairs the epilogue also leaves the row statistics of the
 // new x as pairs in `stat` where the chosen tile can - the returned Pending says whether it did
-static Pending linear_residual(const Ctx& c, const float* a, int lda, int M, const float* W, const float* b, int N, int K,
-                               float* x, float* stat, const float* res = nullptr, int ldr = 0) {
+static GemmP residual_params(const Ctx& c, const float* a, int lda, int M, const float* W, const float* b, int N, int K,
+                             float* x, float* stat, const float* res, int ldr) {
     GemmP p{};
     p.X = a; p.ldx = lda; p.Rx = M; p.Cin = K; p.W = W; p.bias = b; p.R = res ? res : x; p.ldr = res ? ldr : N; p.C = x; p.ldc = N;
     p.M = M; p.N = N;
@@ -440,34 +461,71 @@ static Pending linear_residual(const Ctx& c, const float* a, int lda, int M, con
     const bool want = stat != nullptr && c.m.opts.force_cfg < 0 &&
                       (small || (c.m.opts.ln_pairs > 0 && M > 64 && M <= c.m.opts.ln_pairs_maxm));
     if (want) p.stat_out = stat;
+    return p;
+}
+static Pending linear_residual(const Ctx& c, const float* a, int lda, int M, const float* W, const float* b, int N, int K,
+                               float* x, float* stat, const float* res = nullptr, int ldr = 0, bool a_planes = false) {
+    GemmP p = residual_params(c, a, lda, M, W, b, N, K, x, stat, res, ldr);
+    const bool want = p.stat_out != nullptr;
+    p.a_planes = a_planes ? 1 : 0;
     gemm(c, p);
     Pending r{};
     if (want && c.m.opts.last_stat_nt > 0) { r.stat = stat; r.stat_nt = c.m.opts.last_stat_nt; r.stat_w = c.m.opts.last_stat_w; }
     return r;
 }
-static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int M, const float* att,
-                             const EncScratch& s) {
+// K slices of the two residual GEMMs of an AR layer (out-projection K = d, ff.3 K = ff)
+static void ar_tail_splits(const Ctx& c, const EncW& e, int M, int& S1, int& S2) {
     const int d = e.d;
     // ln_pairs = 2: the residual GEMMs with a short K chain (<= 1024) are not K-split any more - a split hands its reduction
     // to a LayerNorm launch, the un-split GEMM hands the statistics to the next GEMM instead
     const bool unsplit = c.m.opts.ln_pairs >= 2 && M > 64 && M <= c.m.opts.ln_pairs_maxm && c.m.opts.force_cfg < 0;
-    int S1 = choose_split(c, M, d, d);
+    S1 = choose_split(c, M, d, d);
     if (unsplit && d <= c.m.opts.ln_pairs_maxk) S1 = 1;
-    if (S1 > 1) {
-        linear_splitk(c, att, d, M, w.wo, d, d, S1, s.parts);
-        Pending p1{s.parts, (long long)M * d, S1, w.bo};
-        ln_pending_linear(c, x, d, M, p1, w.ln2g, w.ln2b, s.h, w.ff0w, w.ff0b, e.ff, s.f, e.ff, ACT_RELU);
-    } else {
-        const Pending p1 = linear_residual(c, att, d, M, w.wo, w.bo, d, d, x, s.stat);                 // x += out_proj(att)
-        ln_linear(c, x, d, M, 1, 0, M, ln2_ff0(w, d), e.ff, d, s.f, e.ff, s.h, ACT_RELU, &p1);         // LN2 -> ff.0
-    }
-    int S2 = choose_split(c, M, d, e.ff);
+    S2 = choose_split(c, M, d, e.ff);
     if (unsplit && e.ff <= c.m.opts.ln_pairs_maxk) S2 = 1;
+}
+// attention -> out-projection: will the out-projection of ar_layer_tail take `att` as fp16 planes (then the attention kernel stores
+// them: AttnP::o_planes)?  The same hand-over as ff.0 -> ff.3 below, with the attention kernels as producers.
+static bool ar_outproj_takes_planes(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int M, const float* att,
+                                    const EncScratch& s) {
+    const int d = e.d;
+    if (!c.m.opts.a_planes || !(c.m.opts.c_planes & 2) || M <= 64 || M > 4096 || (d & 31) || ((d / e.heads) & 31)) return false;
+    int S1, S2;
+    ar_tail_splits(c, e, M, S1, S2);
+    const GemmP q = S1 > 1 ? splitk_params(att, d, M, w.wo, d, d, S1, s.parts)
+                           : residual_params(c, att, d, M, w.wo, w.bo, d, d, x, s.stat, nullptr, 0);
+    return gemm_takes_planes(planned(c, q), c.m.opts);
+}
+static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int M, const float* att,
+                             const EncScratch& s, bool att_planes = false) {
+    const int d = e.d;
+    int S1, S2;
+    ar_tail_splits(c, e, M, S1, S2);
+    // ff.0 -> ff.3: f = relu(ff.0(h)) has ONE consumer.  Where ff.0 runs on the x3h loader tile and ff.3 on an x3h tile that takes its A
+    // operand as fp16 planes, ff.0's epilogue stores f as planes (GemmP::c_planes: the split once per element, in the producer, instead of
+    // once per element and column tile in the consumer's K loop) - same values, bit-identical results
+    bool fpl = false;
+    if (c.m.opts.a_planes && (c.m.opts.c_planes & 1) && M > 64 && M <= 4096) {
+        GemmP q0{};
+        q0.X = s.h; q0.ldx = d; q0.Rx = M; q0.Cin = d; q0.W = w.ff0w; q0.bias = w.ff0b; q0.C = s.f; q0.ldc = e.ff; q0.M = M; q0.N = e.ff;
+        q0.epi_act = ACT_RELU;
+        const GemmP q3 = S2 > 1 ? splitk_params(s.f, e.ff, M, w.ff1w, d, e.ff, S2, s.parts)
+                                : residual_params(c, s.f, e.ff, M, w.ff1w, w.ff1b, d, e.ff, x, s.stat, nullptr, 0);
+        fpl = gemm_writes_planes(planned(c, q0), c.m.opts) && gemm_takes_planes(planned(c, q3), c.m.opts);
+    }
+    if (S1 > 1) {
+        linear_splitk(c, att, d, M, w.wo, d, d, S1, s.parts, att_planes);
+        Pending p1{s.parts, (long long)M * d, S1, w.bo};
+        ln_pending_linear(c, x, d, M, p1, w.ln2g, w.ln2b, s.h, w.ff0w, w.ff0b, e.ff, s.f, e.ff, ACT_RELU, fpl);
+    } else {
+        const Pending p1 = linear_residual(c, att, d, M, w.wo, w.bo, d, d, x, s.stat, nullptr, 0, att_planes);   // x += out_proj(att)
+        ln_linear(c, x, d, M, 1, 0, M, ln2_ff0(w, d), e.ff, d, s.f, e.ff, s.h, ACT_RELU, &p1, fpl);    // LN2 -> ff.0
+    }
     if (S2 > 1) {
-        linear_splitk(c, s.f, e.ff, M, w.ff1w, d, e.ff, S2, s.parts);
+        linear_splitk(c, s.f, e.ff, M, w.ff1w, d, e.ff, S2, s.parts, fpl);
         return Pending{s.parts, (long long)M * d, S2, w.ff1b};
     }
-    return linear_residual(c, s.f, e.ff, M, w.ff1w, w.ff1b, d, e.ff, x, s.stat);                      // x += ff.3(f)
+    return linear_residual(c, s.f, e.ff, M, w.ff1w, w.ff1b, d, e.ff, x, s.stat, nullptr, 0, fpl);     // x += ff.3(f)
 }
 
 // MIDDLE layer over M = A*n compact rows
@@ -480,8 +538,9 @@ static Pending encoder_layer_ar(const Ctx& c, const EncW& e, const EncLayerW& w,
     } else {
         ln_linear(c, x, d, M, 1, 0, M, ln1_qkv(w, d), 3 * d, d, s.qkv, 3 * d, s.h, ACT_NONE, &in);     // LN1 -> QKV
     }
-    attention_self(c, e, g, s.qkv, s.att);
-    return ar_layer_tail(c, e, w, x, M, s.att, s);
+    const bool opl = !g.start && ar_outproj_takes_planes(c, e, w, x, M, s.att, s);      // (uniform geometry: every row of att is written)
+    attention_self(c, e, g, s.qkv, s.att, opl);
+    return ar_layer_tail(c, e, w, x, M, s.att, s, opl);
 }
 
 // LAST layer: only row n-1 of each sequence is consumed downstream (models/megatts2.py:178,272).  LayerNorm
@@ -561,8 +620,10 @@ static Pending encoder_layer_first_cached(const Ctx& c, const EncW& e, const Enc
     a.B = A; a.H = e.heads; a.D = D; a.max_qlen = n; a.scale = 1.0f / std::sqrt((float)D);
     a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves; a.x6_min_qlen = c.m.opts.attn_x6_min;
     a.ds_short = c.m.opts.attn_ds;
+    const bool opl = ar_outproj_takes_planes(c, e, w, x, M, s.att, s);
+    a.o_planes = opl ? 1 : 0; a.x3h_flag = c.m.opts.x3h_flag;
     MT2_HIP(launch_attention(a, c.s));
-    return ar_layer_tail(c, e, w, x, M, s.att, s);
+    return ar_layer_tail(c, e, w, x, M, s.att, s, opl);
 }
 
 // One AR step of an encoder over A sequences of n positions (x: [A*n, d], overwritten); the rows the head

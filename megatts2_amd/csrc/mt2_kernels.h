@@ -50,6 +50,8 @@ struct GemmP {
     int sk_nw = 8;              // gemm_skinny_tm_kernel: waves per workgroup that split K (8; 16 = option skinny_nw, set by launch_gemm)
     int a_planes = 0;           // 1: X holds fp16 planes ([32 hi | 32 lo] per 32 k of a row, x3h_planes.h's block layout without a row scale)
                                 // written by a producer kernel (LnP::out_planes): x3h loader / K-split tiles only, no prologue, Cin % 32 = 0
+    int c_planes = 0;           // 1: C RECEIVES fp16 planes (the same block layout: the A operand of the next launch's a_planes) instead of f32 -
+                                // x3h loader tile only (16-byte-store epilogue), N % 32 = ldc % 32 = 0, C on 128 bytes, no residual, groups = 1
     int ldr64 = 0;              // x3h loaders: 1 = the 64-bit global_load_lds form even where buffer loads would do (EngineOpts::ldr64)
     int ldr_prio = 0;           // s_setprio of the loader waves of the loader-wave kernels (set by launch_gemm from EngineOpts::ldr_prio)
     const void* W3 = nullptr;   // optional: the same weights as three bf16 planes (truncation split, exact sum), addressed like
@@ -117,6 +119,10 @@ struct EngineOpts {
     bool epi_t4 = true;          // DPP-transposed 16-byte-store epilogue for wave tiles without epilogue prefetch
     bool a_planes = true;        // LayerNorm -> Linear pairs of the AR layers: the LayerNorm kernel writes its output as fp16 planes and the x3h
                                  // GEMM takes them as they are (GemmP::a_planes) wherever gemm_takes_planes() says so
+    int c_planes = 1;            // AR layers, more producers of fp16 planes: bit 0 = ff.0's epilogue stores relu(..) as planes (GemmP::c_planes) where
+                                 // ff.3 takes them; bit 1 = the attention kernels store their output as planes (AttnP::o_planes) where the
+                                 // out-projection takes them (bit-identical, measured neutral: off by default -
+                                 // profiles/r06_opts_ab_block4_planes_producers.txt)
     bool ldr64 = false;          // tests / measurement: the x3h loaders' 64-bit global_load_lds form (what operands of 2 GiB or more get)
     int ldr_prio = 3;            // issue priority (s_setprio 0..3) of the loader waves (gemm_x6_ldr / gemm_x6_ks / conv_win_x6 kernels)
     int skinny_rows = 64;        // linear layers with at most this many rows (<= 64) run on the weight-streaming kernel of
@@ -152,6 +158,8 @@ struct EngineOpts {
 hipError_t launch_gemm(const GemmP& p, hipStream_t s, EngineOpts* o = nullptr);
 // would launch_gemm run this launch (planes attached, no prologue) on an x3h tile that takes its A operand as fp16 planes (a_planes)?
 bool gemm_takes_planes(const GemmP& p, const EngineOpts& o);
+// would launch_gemm run this launch on an x3h loader tile whose epilogue can store C as fp16 planes (GemmP::c_planes)?
+bool gemm_writes_planes(const GemmP& p, const EngineOpts& o);
 // gemm_x3h.hip: the kernels of the fp16-pipe form by tile id and variant (prologue none / relu / leaky relu / - / - / pair statistics);
 // nullptr: no such variant
 enum X3hTile : int { X3H_LDR_128x128 = 0, X3H_KS_32x64_K4, X3H_KS_64x64_K2, X3H_KS_32x32_K8, X3H_WIN_256x64, X3H_WIN_128x128, X3H_WIN_256x32, kX3hTiles };
@@ -220,6 +228,8 @@ struct AttnP {
     int x6_min_qlen = 0;      // from this many queries on (D = 64 / 96) the f32-equivalent bf16-pipe kernel (attn_x6_kernel); 0: never
     int lds_waves = 0;        // query tiles per workgroup of that kernel: 8, otherwise 4
     int ds_short = 1;         // D = 64 / 96 and at most 128 keys: key tiles x head-dim slices per workgroup (attn_f32_ds_kernel)
+    int o_planes = 0;         // 1: O receives fp16 planes (planes_store.h: the A operand of the out-projection's GemmP::a_planes launch; same
+    int* x3h_flag = nullptr;  // bytes and row stride as f32; D % 32 == 0, ldo % 32 == 0, O on 128 bytes); x3h_flag: the range guard's device word
 };
 hipError_t launch_attention(const AttnP& p, hipStream_t s);
 

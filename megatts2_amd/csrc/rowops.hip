@@ -3,6 +3,7 @@
 // All of them move each byte once with float4 (16 B/lane) coalesced accesses; row reductions use wave64
 // shuffles (one wave per row), never LDS.
 #include "mt2_kernels.h"
+#include "planes_store.h"
 #include <math.h>
 
 namespace mt2 {
@@ -19,22 +20,6 @@ __device__ __forceinline__ float act_rt2(int act, float v) {
         case ACT_TANH: return tanhf(v);
         default: return v;
     }
-}
-
-// Four consecutive channels c .. c + 3 of a row as fp16 planes (LnP::out_planes; x3h_planes.h's block layout without a row scale: per 32
-// channels a 128-byte block [32 hi | 32 lo], hi = fp16_rn(v), lo = fp16_rn((v - hi) * 2^11) - what gemm_x3h.hip's split produces in
-// registers).  Returns max |v| for the range guard.
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float store_planes4(float* __restrict__ row, int c, const float4& y) {
-    const f16x2_t h01 = __builtin_convertvector((f32x2_t){y.x, y.y}, f16x2_t), h23 = __builtin_convertvector((f32x2_t){y.z, y.w}, f16x2_t);
-    const float s = 2048.0f;
-    const f16x2_t l01 = __builtin_convertvector((f32x2_t){__builtin_fmaf((float)h01[0], -s, y.x * s), __builtin_fmaf((float)h01[1], -s, y.y * s)}, f16x2_t);
-    const f16x2_t l23 = __builtin_convertvector((f32x2_t){__builtin_fmaf((float)h23[0], -s, y.z * s), __builtin_fmaf((float)h23[1], -s, y.w * s)}, f16x2_t);
-    char* blk = reinterpret_cast<char*>(row) + (c >> 5) * 128 + (c & 31) * 2;
-    *reinterpret_cast<uint2*>(blk) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
-    *reinterpret_cast<uint2*>(blk + 64) = make_uint2(__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23));
-    return fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w)));
 }
 
 // ---------------------------------------------------------------------------------------------------

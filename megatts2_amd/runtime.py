@@ -736,7 +736,8 @@ def op_conv_x3h(X, W, bias=None, R=None, valid=None, shift0=0, taps=1, dil=1, Ci
     """mt2_op_gemm_x3h: one GEMM / convolution launch with the weights given as f32, as bf16 planes and as fp16 planes (so that
     every tile configuration can be forced): X [rows, Cin] f32, W [N, taps*Cin] f32.  want_flag -> (out, range flag).
     Test conventions of the entry point: force_cfg + 1000 = the same launch with the loaders' 64-bit address form; + 2000 = X holds
-    fp16 planes written by op_layernorm(..., act=100) (GemmP::a_planes)."""
+    fp16 planes written by op_layernorm(..., act=100) (GemmP::a_planes); + 4000 = the OUTPUT is stored as such planes (GemmP::c_planes:
+    same bytes per row as f32; the x3h loader tile only)."""
     import torch
     lib = load_library()
     Cin = Cin or X.shape[1]

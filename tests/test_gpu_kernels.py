@@ -407,6 +407,39 @@ def test_layernorm_relu_planes_feed_a_convolution_bit_for_bit(rt, M, C, taps):
     assert rel(y0, ref) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,cfg2", [(864, 4096, 1024, 103), (333, 1024, 768, 103), (224, 1024, 1024, 96)])
+def test_gemm_epilogue_planes_feed_the_next_gemm_bit_for_bit(rt, M, N, K, cfg2):
+    """ff.0 -> ff.3 of an AR layer (modules/transformer.py:100-102: Linear, ReLU, Linear): the x3h loader tile's 16-byte-store epilogue
+    stores relu(x W0^T + b0) as fp16 planes (GemmP::c_planes: the block layout and the arithmetic of the consumer's in-register split) and
+    the second GEMM takes them as they are (a_planes).  The planes are pinned against numpy's split of the f32 result, the second GEMM
+    against the f32 hand-over, bit for bit; a producer that cannot write planes answers not-supported."""
+    rng = np.random.default_rng(M + N + K)
+    X = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-2, 2, (M, 1)))).astype(np.float32)
+    W0 = (rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float32)
+    b0 = rng.standard_normal(N).astype(np.float32)
+    W1 = (rng.standard_normal((K, N)) / math.sqrt(N)).astype(np.float32)
+    b1 = rng.standard_normal(K).astype(np.float32)
+    valid = (rng.uniform(size=M) > 0.1).astype(np.int32)
+    kw0 = dict(shift0=0, taps=1, dil=1, Cin=K, pro_act=rt.ACT_NONE, epi_act=rt.ACT_RELU, valid=dev(valid))
+    f = rt.op_conv_x3h(dev(X), dev(W0), dev(b0), None, force_cfg=103, **kw0)
+    fp = rt.op_conv_x3h(dev(X), dev(W0), dev(b0), None, force_cfg=103 + 4000, **kw0)
+    fn = f.cpu().numpy()
+    assert np.isfinite(fn).all() and (fn[valid == 0] == 0).all()
+    hi = fn.astype(np.float16)
+    lo = ((fn - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    want = np.concatenate([hi.reshape(M, N // 32, 1, 32), lo.reshape(M, N // 32, 1, 32)], axis=2).reshape(M, 2 * N)
+    got = fp.cpu().numpy().view(np.float16).reshape(M, 2 * N)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    kw1 = dict(shift0=0, taps=1, dil=1, Cin=N, pro_act=rt.ACT_NONE, epi_act=rt.ACT_NONE)
+    y0 = rt.op_conv_x3h(f, dev(W1), dev(b1), None, force_cfg=cfg2, **kw1).cpu().numpy()
+    y1 = rt.op_conv_x3h(fp, dev(W1), dev(b1), None, force_cfg=cfg2 + 2000, **kw1).cpu().numpy()
+    assert np.isfinite(y0).all() and np.array_equal(y0, y1)
+    ref = np.maximum(X.astype(np.float64) @ W0.T.astype(np.float64) + b0, 0) * valid[:, None]
+    assert rel(fn, ref) < 2e-6
+    with pytest.raises(RuntimeError):        # the K-split tiles' epilogue has no planes form
+        rt.op_conv_x3h(dev(X), dev(W0), dev(b0), None, force_cfg=96 + 4000, **kw0)
+
+
 @pytest.mark.parametrize("cfg", [103, 96])
 def test_gemm_x3h_range_guard_and_corner_cases(rt, cfg):
     """The fp16 form's range behaviour, documented in gemm_x3h.hip: (1) activations up to 6e4 and weights of any magnitude (1e-30
@@ -844,6 +877,39 @@ def test_attention_ragged(rt, H, D):
             p = np.exp(s - s.max(1, keepdims=True))
             ref = (p / p.sum(1, keepdims=True)) @ v[:, sl]
             assert rel(out[qs[b]:qs[b] + qlens[b], sl], ref) < 3e-6
+
+
+@pytest.mark.parametrize("kernel,H,D,n", [("ds", 16, 64, 70), ("ds", 8, 96, 100), ("reg", 16, 64, 70), ("generic", 2, 256, 50),
+                                          ("lds", 8, 96, 300), ("x6", 16, 64, 300)])
+def test_attention_output_as_planes_for_the_out_projection(rt, kernel, H, D, n):
+    """attention -> out-projection of an AR layer (modules/transformer.py:52-57): every attention kernel can store its output rows as
+    fp16 planes (AttnP::o_planes, planes_store.h) for an out-projection that runs on an x3h tile and takes them as they are.  The planes
+    are the numpy split of the same kernel's f32 output, bit for bit; rows outside the utterances stay untouched."""
+    import torch
+    rng = np.random.default_rng(H + D + n)
+    A, d = 5, H * D
+    M = A * n
+    Q, K, V = (rng.standard_normal((M, d)).astype(np.float32) for _ in range(3))
+    st = (np.arange(A) * n).astype(np.int32)
+    ln = np.full(A, n, np.int32)
+    ln[-1] = n - 3                      # the last three rows belong to no utterance
+    flags = {"ds": (-1, 0, 0), "reg": (-1, 32, 0), "generic": (-1, 0, 0), "lds": (128, 8, 0), "x6": (0, 0, 128)}[kernel]
+    kw = dict(lds_min_qlen=flags[0], x6_min_qlen=flags[2])
+    args = (dev(Q), dev(K), dev(V), dev(st), dev(ln), dev(st), dev(ln), H, D, 1.0 / math.sqrt(D))
+    o = rt.op_attention(*args, lds_waves=flags[1], **kw).cpu().numpy()
+    sentinel = torch.full((M, d), 7.0, device="cuda", dtype=torch.float32)
+    op = rt.op_attention(*args, lds_waves=flags[1] + 64, out=sentinel, **kw).cpu().numpy()
+    live = M - 3
+    hi = o[:live].astype(np.float16)
+    lo = ((o[:live] - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    want = np.concatenate([hi.reshape(live, d // 32, 1, 32), lo.reshape(live, d // 32, 1, 32)], axis=2).reshape(live, 2 * d)
+    got = op[:live].view(np.float16).reshape(live, 2 * d)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    assert (op[live:] == 7.0).all()
+    q, k, v = (x[:n, :D].astype(np.float64) for x in (Q, K, V))
+    sc = q @ k.T / math.sqrt(D)
+    pr = np.exp(sc - sc.max(1, keepdims=True))
+    assert rel(o[:n, :D], (pr / pr.sum(1, keepdims=True)) @ v) < 3e-6
 
 
 @pytest.mark.parametrize("waves", [0, 4, 8, "x6", "x6w4", "x6w8"])

@@ -148,7 +148,7 @@ static GemmP planned(const Ctx& c, GemmP p) {
 // the loader tile that arithmetic is 8..18 % of a launch (profiles/r06_x3h_ablate_v3_split.txt).
 static bool linear_takes_planes(const Ctx& c, const float* x, int ldx, int M, const float* W, const float* b, int N, int K,
                                 float* y, int ldy, int epi_act) {
-    if (!c.m.opts.a_planes) return false;
+    if (!(c.m.opts.a_planes & 1)) return false;
     GemmP p{};
     p.X = x; p.ldx = ldx; p.Rx = M; p.Cin = K; p.W = W; p.bias = b; p.C = y; p.ldc = ldy; p.M = M; p.N = N; p.epi_act = epi_act;
     p.taps = 1; p.dil = 1; p.a_mul = 1; p.groups = 1; p.out_scale = 1.0f; p.K = K; p.ldw = K;
@@ -294,7 +294,7 @@ static float* run_stack(const Ctx& c, const StackW& w, const float* x_in, bool s
             gemm(c, block_conv(blk, bin, bin_shared, bin_relued, bin_planes));
             const bool last = blk == w.nblock - 1;
             bool planes = false;
-            if (!last && c.m.opts.a_planes) {       // will the next block's conv take Y as planes?
+            if (!last && (c.m.opts.a_planes & 1)) {       // will the next block's conv take Y as planes?
                 GemmP q = block_conv(blk + 1, Y, false, true, false);
                 q.dil = 1; q.a_mul = 1; q.out_scale = 1.0f; q.K = q.taps * q.Cin; q.ldw = q.K;
                 attach_planes(c.m, q);
@@ -489,7 +489,7 @@ static void ar_tail_splits(const Ctx& c, const EncW& e, int M, int& S1, int& S2)
 static bool ar_outproj_takes_planes(const Ctx& c, const EncW& e, const EncLayerW& w, float* x, int M, const float* att,
                                     const EncScratch& s) {
     const int d = e.d;
-    if (!c.m.opts.a_planes || !(c.m.opts.c_planes & 2) || M <= 64 || M > 4096 || (d & 31) || ((d / e.heads) & 31)) return false;
+    if (!(c.m.opts.a_planes & 4) || M <= 64 || M > 4096 || (d & 31) || ((d / e.heads) & 31)) return false;
     int S1, S2;
     ar_tail_splits(c, e, M, S1, S2);
     const GemmP q = S1 > 1 ? splitk_params(att, d, M, w.wo, d, d, S1, s.parts)
@@ -505,7 +505,7 @@ static Pending ar_layer_tail(const Ctx& c, const EncW& e, const EncLayerW& w, fl
     // operand as fp16 planes, ff.0's epilogue stores f as planes (GemmP::c_planes: the split once per element, in the producer, instead of
     // once per element and column tile in the consumer's K loop) - same values, bit-identical results
     bool fpl = false;
-    if (c.m.opts.a_planes && (c.m.opts.c_planes & 1) && M > 64 && M <= 4096) {
+    if ((c.m.opts.a_planes & 2) && M > 64 && M <= 4096) {
         GemmP q0{};
         q0.X = s.h; q0.ldx = d; q0.Rx = M; q0.Cin = d; q0.W = w.ff0w; q0.bias = w.ff0b; q0.C = s.f; q0.ldc = e.ff; q0.M = M; q0.N = e.ff;
         q0.epi_act = ACT_RELU;

@@ -117,12 +117,11 @@ struct EngineOpts {
                                  // 64x64 tile only.  Default 4: isolated launches +10..50 %
                                  // (profiles/r03_gemm_sweep_x6k.txt), C3 step -1.6 % (profiles/r03_ab_interleaved_v1.txt)
     bool epi_t4 = true;          // DPP-transposed 16-byte-store epilogue for wave tiles without epilogue prefetch
-    bool a_planes = true;        // LayerNorm -> Linear pairs of the AR layers: the LayerNorm kernel writes its output as fp16 planes and the x3h
-                                 // GEMM takes them as they are (GemmP::a_planes) wherever gemm_takes_planes() says so
-    int c_planes = 1;            // AR layers, more producers of fp16 planes: bit 0 = ff.0's epilogue stores relu(..) as planes (GemmP::c_planes) where
-                                 // ff.3 takes them; bit 1 = the attention kernels store their output as planes (AttnP::o_planes) where the
-                                 // out-projection takes them (bit-identical, measured neutral: off by default -
-                                 // profiles/r06_opts_ab_block4_planes_producers.txt)
+    int a_planes = 3;            // producers of fp16 planes for x3h GEMMs that take their A operand as planes (GemmP::a_planes; wherever
+                                 // gemm_takes_planes() says so).  Bit 0: LayerNorm -> Linear pairs of the AR layers and LayerNorm -> Conv1d inside
+                                 // the conv stacks (LnP::out_planes); bit 1: ff.0's epilogue stores relu(..) as planes for ff.3 (GemmP::c_planes);
+                                 // bit 2: the attention kernels store their output as planes for the out-projection (AttnP::o_planes) -
+                                 // bit-identical, measured neutral, off by default (profiles/r06_opts_ab_block4_planes_producers.txt)
     bool ldr64 = false;          // tests / measurement: the x3h loaders' 64-bit global_load_lds form (what operands of 2 GiB or more get)
     int ldr_prio = 3;            // issue priority (s_setprio 0..3) of the loader waves (gemm_x6_ldr / gemm_x6_ks / conv_win_x6 kernels)
     int skinny_rows = 64;        // linear layers with at most this many rows (<= 64) run on the weight-streaming kernel of

@@ -99,7 +99,9 @@ struct GemmP {
 struct TraceRec { int cfg; double flops; hipEvent_t e0, e1; int M, N, K, groups; };
 struct EngineOpts {
     int force_cfg = -1;                                    // >= 0: tile configuration index for every GEMM launch
-    int t_ks4 = 256, t_ks2 = 640, t32 = 256, t32x32 = 256; // tile-choice thresholds in tiles (tools/gemm_sweep.py)
+    int t_ks4 = 256, t_ks2 = 640, t32 = 64, t32x32 = 160;  // tile-choice thresholds in tiles (tools/gemm_sweep.py; t32 / t32x32 re-swept in the model after
+                                                           // the x3h K-split tiles changed their ranking: the 64x64 k2 tile takes over from the 32x64 k4 and
+                                                           // 32x32 k8 tiles earlier - C2 -2.5 ... -3 %, C3 -0.5 %, profiles/r06_opts_ab_block5_ks_thresholds.txt)
     bool splitk = true;          // split-K through the LayerNorm in the AR layers
     int voc_streams = 3;         // resblock chains of a vocoder stage in flight (1 = serial)
     bool win_conv = true;        // window-convolution kernel for narrow square convs (Cin = Cout in {32, 64, 128})

@@ -312,11 +312,20 @@ int mt2_op_attention(void* stream, const float* Q, int ldq, const float* K, int 
  * kernel (f32-equivalent six-product form, head dims 64 / 96; 0 never, < 0 default); lds_waves + 32: the register kernel instead of the
  * head-dim-split kernel that serves D = 64 / 96 with at most 128 keys; lds_waves + 64: O receives fp16 planes (the operand format the
  * out-projection's x3h GEMM takes as it is: per 32 columns 32 hi | 32 lo fp16, same bytes per row; ldo % 32 == 0, O on 128 bytes);
+ * lds_waves + 128: the bf16-pipe kernel in its fp16-pipe form (two fp16 planes per operand, three products; Q / K / V beyond the fp16
+ * range are not reported through this entry point - the model's calls raise the handle's range guard);
  * max_kvlen: longest key range of the launch (0 = unknown). */
 int mt2_op_attention_tuned(void* stream, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
                            float* O, int ldo, const int32_t* q_start, const int32_t* q_len, const int32_t* kv_start,
                            const int32_t* kv_len, int B, int H, int D, int max_qlen, float scale, int lds_min_qlen,
                            int lds_waves, int x6_min_qlen, int max_kvlen);
+/* The long-sequence kernel in its fp16-pipe form (two fp16 planes per operand, three products; head dims 64 / 96) with the range guard
+ * exposed: range_flag (device int32) |= 1 when a Q / K / V value at or beyond 65504 was converted.  What mt2_synthesize_batch runs for
+ * sequences of attn_x6_min queries or more under option x3h & 8 (reference modules/transformer.py:52-57, F.scaled_dot_product_attention). */
+int mt2_op_attention_x3h(void* stream, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv,
+                         float* O, int ldo, const int32_t* q_start, const int32_t* q_len, const int32_t* kv_start,
+                         const int32_t* kv_len, int B, int H, int D, int max_qlen, float scale, int lds_waves, int max_kvlen,
+                         int32_t* range_flag);
 /* Launch trace of the GEMM/conv engine (measurement only): between begin and end every launch is
  * bracketed by HIP events on its own stream.  end() reports, per tile configuration, the number of
  * launches, the executed FLOPs (2*M*N*K*groups) and the summed kernel time in ms, plus a last entry named

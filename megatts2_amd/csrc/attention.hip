@@ -625,23 +625,58 @@ __device__ __forceinline__ void attn_x6(f32x16& acc, const au32x4 (&a)[3], const
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, a[PA[t]]), __builtin_bit_cast(abf16x8, b[PB[t]]), acc, 0, 0, 0);
 }
 
+// The fp16-pipe form of the same kernel ("x3h", round 6; gemm_x3h.hip has the derivation): every operand as TWO fp16 planes,
+// a = hi + 2^-11 lo with hi = fp16_rn(a), lo = fp16_rn((a - hi) * 2^11), THREE products per k block - hi hi into the main
+// accumulator, hi lo + lo hi into a second one that is merged with the weight 2^-11 (the dropped lo lo term is 2^-22 relative).
+// Half the matrix instructions of x6, two planes instead of three in LDS and in the split arithmetic.  fp16 has no f32 exponent
+// range: Q / K / V values at or beyond 65504 raise the handle's range-guard word (AttnP::x3h_flag) and the caller repeats the
+// call with x3h = 0, i.e. on the x6 kernel; P = exp(s - m) lies in [0, 1] (values below 2^-35 vanish: 2^-36 of the row maximum).
+typedef _Float16 af16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 af16x2 __attribute__((ext_vector_type(2)));
+typedef float af32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void attn_split2(const af32x4& lo, const af32x4& hi, au32x4& ph, au32x4& pl, float& amax) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = i < 2 ? lo[2 * i] : hi[2 * i - 4];
+        const float y = i < 2 ? lo[2 * i + 1] : hi[2 * i - 3];
+        amax = fmaxf(fmaxf(fabsf(x), fabsf(y)), amax);
+        const af16x2 h = __builtin_convertvector((af32x2){x, y}, af16x2);            // round to nearest even
+        const float rx = __builtin_fmaf((float)h[0], -2048.0f, x * 2048.0f);        // (x - h) * 2^11, exact
+        const float ry = __builtin_fmaf((float)h[1], -2048.0f, y * 2048.0f);
+        const af16x2 l = __builtin_convertvector((af32x2){rx, ry}, af16x2);
+        ph[i] = __builtin_bit_cast(unsigned, h);
+        pl[i] = __builtin_bit_cast(unsigned, l);
+    }
+}
+// acc += A_hi B_hi;  accl += A_hi B_lo + A_lo B_hi  (accl carries the weight 2^-11)
+__device__ __forceinline__ void attn_x3h(f32x16& acc, f32x16& accl, const au32x4 (&a)[2], const au32x4 (&b)[2]) {
+    const af16x8 ah = __builtin_bit_cast(af16x8, a[0]), al = __builtin_bit_cast(af16x8, a[1]);
+    const af16x8 bh = __builtin_bit_cast(af16x8, b[0]), bl = __builtin_bit_cast(af16x8, b[1]);
+    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accl, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+    accl = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accl, 0, 0, 0);
+}
+
 // Round 4: a DOUBLE-BUFFERED plane stage (split of tile t+1 between the S products and the softmax of tile t, one barrier per
 // tile) was built and measured: parity-green, 0...-5 % on the isolated launch, +0.4 % on the C5 step (twice the LDS per
 // workgroup) - not kept (profiles/r04_attn_bench.txt, r04_experiment_attn_double_buffer.patch).  A tile's cost is its VALU work -
 // the softmax (16 expf per lane), two run-time splits of P and the rescale of O - not the barrier count: what WAS kept are
 // the exact savings there (no key mask on full tiles, no rescale when no query's running maximum moved).
-template <int D, int NWQ>     // D = 64 or 96; workgroup = NWQ waves = NWQ consecutive query tiles of one (utterance, head)
+template <int D, int NWQ, bool H3 = false>     // D = 64 or 96; workgroup = NWQ waves = NWQ consecutive query tiles of one (utterance, head);
+                                               // H3: the fp16-pipe form (two planes, three products) instead of bf16 (three planes, six)
 __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) void attn_x6_kernel(AttnP p) {
     constexpr int NT = 64 * NWQ;
+    constexpr int NP = H3 ? 2 : 3;                  // planes per operand
+    float amax = 0.0f;                              // H3: largest |Q|, |K|, |V| value this thread split (range guard)
     constexpr int NB = D / 16, DT = D / 32;
     constexpr int RSK = D * 2 + 16;                 // bytes per key row of a K plane (padded)
     constexpr int RSV = 64 + 16;                    // bytes per channel row of a V^T plane: 32 keys (permuted) + pad
     constexpr int KPL = 32 * RSK, VPL = D * RSV;    // bytes per plane
     constexpr int KI = (4 * D + NT - 1) / NT;       // staging items per thread: K (32 rows x D/8 groups of 8 channels) ...
     constexpr int VI = (4 * D + NT - 1) / NT;       // ... and V (D channels x 4 groups of 8 keys)
-    extern __shared__ __attribute__((aligned(16))) char xmem[];          // [3 K planes][3 V^T planes]
+    extern __shared__ __attribute__((aligned(16))) char xmem[];          // [NP K planes][NP V^T planes]
     char* kp = xmem;
-    char* vp = xmem + 3 * KPL;
+    char* vp = xmem + NP * KPL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -696,11 +731,12 @@ __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) v
             if (i < 4 * D) {
                 const int row = i / (D / 8), grp = i - row * (D / 8);
                 au32x4 a, bq, c;
-                attn_split3(kreg[j][0], kreg[j][1], a, bq, c);
                 char* dst = kp + row * RSK + grp * 16;
+                if constexpr (H3) attn_split2(kreg[j][0], kreg[j][1], a, bq, amax);
+                else attn_split3(kreg[j][0], kreg[j][1], a, bq, c);
                 *reinterpret_cast<au32x4*>(dst) = a;
                 *reinterpret_cast<au32x4*>(dst + KPL) = bq;
-                *reinterpret_cast<au32x4*>(dst + 2 * KPL) = c;
+                if constexpr (!H3) *reinterpret_cast<au32x4*>(dst + 2 * KPL) = c;
             }
         }
 #pragma unroll
@@ -711,17 +747,18 @@ __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) v
                 const af32x4 lo = {vreg[j][0], vreg[j][1], vreg[j][2], vreg[j][3]};
                 const af32x4 hi = {vreg[j][4], vreg[j][5], vreg[j][6], vreg[j][7]};
                 au32x4 a, bq, c;
-                attn_split3(lo, hi, a, bq, c);
                 char* dst = vp + d * RSV + G * 16;
+                if constexpr (H3) attn_split2(lo, hi, a, bq, amax);
+                else attn_split3(lo, hi, a, bq, c);
                 *reinterpret_cast<au32x4*>(dst) = a;
                 *reinterpret_cast<au32x4*>(dst + VPL) = bq;
-                *reinterpret_cast<au32x4*>(dst + 2 * VPL) = c;
+                if constexpr (!H3) *reinterpret_cast<au32x4*>(dst + 2 * VPL) = c;
             }
         }
     };
 
     // ---- Q planes: lane (query l31, half) holds channels 16 f + 8 half + 0..7 of its row
-    au32x4 qp[NB][3];
+    au32x4 qp[NB][NP];
     {
         const float* __restrict__ qptr = p.Q + (long long)(qs + (qok ? qrow : 0)) * p.ldq + h * D + 8 * half;
 #pragma unroll
@@ -731,7 +768,8 @@ __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) v
                 lo = *reinterpret_cast<const af32x4*>(qptr + 16 * f);
                 hi = *reinterpret_cast<const af32x4*>(qptr + 16 * f + 4);
             }
-            attn_split3(lo, hi, qp[f][0], qp[f][1], qp[f][2]);
+            if constexpr (H3) attn_split2(lo, hi, qp[f][0], qp[f][1], amax);
+            else attn_split3(lo, hi, qp[f][0], qp[f][1], qp[f][NP - 1]);
         }
     }
     float m_run = -INFINITY, l_run = 0.0f;
@@ -746,12 +784,27 @@ __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) v
 #pragma unroll
         for (int e = 0; e < 16; ++e) sc[e] = 0.0f;
         const char* krow = kp + l31 * RSK + half * 16;
+        if constexpr (H3) {
+            f32x16 scl;
 #pragma unroll
-        for (int f = 0; f < NB; ++f) {
-            au32x4 ka[3];
+            for (int e = 0; e < 16; ++e) scl[e] = 0.0f;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) ka[pl] = *reinterpret_cast<const au32x4*>(krow + pl * KPL + f * 32);
-            attn_x6(sc, ka, qp[f]);
+            for (int f = 0; f < NB; ++f) {
+                au32x4 ka[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) ka[pl] = *reinterpret_cast<const au32x4*>(krow + pl * KPL + f * 32);
+                attn_x3h(sc, scl, ka, qp[f]);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sc[e] = __builtin_fmaf(scl[e], 1.0f / 2048.0f, sc[e]);
+        } else {
+#pragma unroll
+            for (int f = 0; f < NB; ++f) {
+                au32x4 ka[NP];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) ka[pl] = *reinterpret_cast<const au32x4*>(krow + pl * KPL + f * 32);
+                attn_x6(sc, ka, qp[f]);
+            }
         }
     };
     auto softmax_pv = [&](int kv0) {
@@ -792,20 +845,50 @@ __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) v
         }
         // P planes of key block kb: the lane's s[8 kb .. 8 kb + 7] (keys 16 kb + 4 half + {0..3, 8..11}: the permuted order
         // in which stage() laid out V^T)
+        if constexpr (H3) {
+            // both key blocks' planes first, then per output tile: the cross terms of the tile in a temporary accumulator, merged
+            // into o[t] once per key tile (16 fma) - one accumulator set stays resident, not two
+            au32x4 pp[2][2];
+            float pmax = 0.0f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const af32x4 lo = {s[8 * kb], s[8 * kb + 1], s[8 * kb + 2], s[8 * kb + 3]};
+                const af32x4 hi = {s[8 * kb + 4], s[8 * kb + 5], s[8 * kb + 6], s[8 * kb + 7]};
+                attn_split2(lo, hi, pp[kb][0], pp[kb][1], pmax);
+            }
+            (void)pmax;                    // P lies in [0, 1]: no guard
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                f32x16 ol;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ol[e] = 0.0f;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const char* vrow = vp + (t * 32 + l31) * RSV + (2 * kb + half) * 16;
+                    au32x4 va[2];
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) va[pl] = *reinterpret_cast<const au32x4*>(vrow + pl * VPL);
+                    attn_x3h(o[t], ol, va, pp[kb]);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[t][e] = __builtin_fmaf(ol[e], 1.0f / 2048.0f, o[t][e]);
+            }
+        } else {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const af32x4 lo = {s[8 * kb], s[8 * kb + 1], s[8 * kb + 2], s[8 * kb + 3]};
             const af32x4 hi = {s[8 * kb + 4], s[8 * kb + 5], s[8 * kb + 6], s[8 * kb + 7]};
-            au32x4 pp[3];
-            attn_split3(lo, hi, pp[0], pp[1], pp[2]);
+            au32x4 pp[NP];
+            attn_split3(lo, hi, pp[0], pp[1], pp[NP - 1]);
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
                 const char* vrow = vp + (t * 32 + l31) * RSV + (2 * kb + half) * 16;
-                au32x4 va[3];
+                au32x4 va[NP];
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) va[pl] = *reinterpret_cast<const au32x4*>(vrow + pl * VPL);
+                for (int pl = 0; pl < NP; ++pl) va[pl] = *reinterpret_cast<const au32x4*>(vrow + pl * VPL);
                 attn_x6(o[t], va, pp);
             }
+        }
         }
     };
 
@@ -819,6 +902,9 @@ __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) v
             softmax_pv(kv0);
         }
         __syncthreads();               // every wave is done with this tile's planes before the next stage() overwrites them
+    }
+    if constexpr (H3) {
+        if (__any(amax >= 65504.0f) && lane == 0 && p.x3h_flag) atomicOr(p.x3h_flag, 1);
     }
     if (!active || !qok) return;
     const float inv = 1.0f / l_run;
@@ -837,11 +923,11 @@ __global__ __launch_bounds__(64 * NWQ) __attribute__((amdgpu_waves_per_eu(2))) v
         }
 }
 
-template <int D, int NWQ>
+template <int D, int NWQ, bool H3 = false>
 static hipError_t launch_attn_x6(const AttnP& p, hipStream_t s) {
     static std::atomic<unsigned long long> attr_done{0};      // per device (dyn_lds_once)
-    void (*fn)(AttnP) = attn_x6_kernel<D, NWQ>;
-    const size_t lds = (size_t)3 * 32 * (D * 2 + 16) + (size_t)3 * D * 80;
+    void (*fn)(AttnP) = attn_x6_kernel<D, NWQ, H3>;
+    const size_t lds = (size_t)(H3 ? 2 : 3) * (32 * (D * 2 + 16) + D * 80);
     if (lds > 48 * 1024) {
         hipError_t e = dyn_lds_once(attr_done, reinterpret_cast<const void*>(fn), lds);
         if (e != hipSuccess) return e;
@@ -852,8 +938,9 @@ static hipError_t launch_attn_x6(const AttnP& p, hipStream_t s) {
 template <int D>
 static hipError_t launch_attn_x6_d(const AttnP& p, hipStream_t s) {
     // the K / V split of a tile is paid once per workgroup: 8 query tiles per workgroup once there are enough of them
-    if (p.lds_waves == 8 || (p.lds_waves != 4 && p.max_qlen >= 600)) return launch_attn_x6<D, 8>(p, s);   // profiles/r03_attn_bench.txt
-    return launch_attn_x6<D, 4>(p, s);
+    const bool w8 = p.lds_waves == 8 || (p.lds_waves != 4 && p.max_qlen >= 600);      // profiles/r03_attn_bench.txt
+    if (p.x3h) return w8 ? launch_attn_x6<D, 8, true>(p, s) : launch_attn_x6<D, 4, true>(p, s);
+    return w8 ? launch_attn_x6<D, 8>(p, s) : launch_attn_x6<D, 4>(p, s);
 }
 
 hipError_t launch_attention(const AttnP& p, hipStream_t s) {

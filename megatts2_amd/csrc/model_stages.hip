@@ -347,6 +347,7 @@ static void attention_self(const Ctx& c, const EncW& e, const AttnGeom& g, const
     a.B = g.B; a.H = e.heads; a.D = D; a.max_qlen = g.max_len; a.max_kvlen = g.max_len;
     a.scale = 1.0f / std::sqrt((float)D);
     a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves; a.x6_min_qlen = c.m.opts.attn_x6_min;
+    a.x3h = (c.m.opts.x3h & 8) ? 1 : 0; a.x3h_flag = c.m.opts.x3h_flag;
     a.ds_short = c.m.opts.attn_ds;
     MT2_HIP(launch_attention(a, c.s));
 }
@@ -587,6 +588,7 @@ static void encoder_layer_last(const Ctx& c, const EncW& e, const EncLayerW& w, 
     a.u_qlen = 1; a.u_kvstride = n; a.u_kvlen = n; a.B = A; a.H = e.heads; a.D = D; a.max_qlen = 1;
     a.scale = 1.0f / std::sqrt((float)D);
     a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves; a.x6_min_qlen = c.m.opts.attn_x6_min;
+    a.x3h = (c.m.opts.x3h & 8) ? 1 : 0; a.x3h_flag = c.m.opts.x3h_flag;
     a.ds_short = c.m.opts.attn_ds;
     MT2_HIP(launch_attention(a, c.s));
     // y = x[last rows] + out_proj(att): the residual rows sit n*d floats apart starting at row n-1
@@ -619,6 +621,7 @@ static Pending encoder_layer_first_cached(const Ctx& c, const EncW& e, const Enc
     a.u_qstride = cs; a.u_qlen = n; a.u_kvstride = cs; a.u_kvlen = n; a.u_ostride = n;
     a.B = A; a.H = e.heads; a.D = D; a.max_qlen = n; a.scale = 1.0f / std::sqrt((float)D);
     a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves; a.x6_min_qlen = c.m.opts.attn_x6_min;
+    a.x3h = (c.m.opts.x3h & 8) ? 1 : 0; a.x3h_flag = c.m.opts.x3h_flag;
     a.ds_short = c.m.opts.attn_ds;
     const bool opl = ar_outproj_takes_planes(c, e, w, x, M, s.att, s);
     a.o_planes = opl ? 1 : 0; a.x3h_flag = c.m.opts.x3h_flag;
@@ -921,6 +924,7 @@ static TcResult tc_latent_rows(const Ctx& c, const std::vector<PhoneSet>& sets, 
     a.kv_start = S > 1 ? ip2.dev(o_kvs) : mp.X.d_start; a.kv_len = S > 1 ? ip2.dev(o_kvl) : mp.X.d_len;
     a.B = BS; a.H = 1; a.D = H; a.max_qlen = P.maxlen; a.max_kvlen = mp.X.maxlen; a.scale = 1.0f / std::sqrt((float)H);
     a.lds_min_qlen = c.m.opts.attn_lds_min; a.lds_waves = c.m.opts.attn_lds_waves; a.x6_min_qlen = c.m.opts.attn_x6_min;
+    a.x3h = (c.m.opts.x3h & 8) ? 1 : 0; a.x3h_flag = c.m.opts.x3h_flag;
     a.ds_short = c.m.opts.attn_ds;
     MT2_HIP(launch_attention(a, c.s));
     float* o = c.ws.get<float>((size_t)P.R * H);

@@ -108,9 +108,10 @@ struct EngineOpts {
     bool x6_conv = true;         // ... on the bf16 matrix pipe, f32-equivalent 3-way split (6 products), where W3 planes exist
     bool x6_gemm = true;         // the implicit GEMMs likewise (loader-wave and K-split tiles)
     bool x6_splitk = true;       // K slices (through the next LayerNorm) to give the N = d AR GEMMs enough x6 tiles
-    int x3h = 7;                 // f32-equivalent THREE-product form on the fp16 pipe (gemm_x3h.hip) wherever an x6 tile has one and the
+    int x3h = 15;                // f32-equivalent THREE-product form on the fp16 pipe (gemm_x3h.hip) wherever an x6 tile has one and the
                                  // weights come with fp16 planes (GemmP::Wh); bits: 1 the 128x128 loader tile, 2 the K-split tiles of the
-                                 // AR steps, 4 the window convolutions; 0: everything stays x6
+                                 // AR steps, 4 the window convolutions, 8 the long-sequence attention kernel (AttnP::x3h: C5 -3.3 %,
+                                 // profiles/r06_opts_ab_block6_attention_x3h.txt); 0: everything stays x6
     int* x3h_flag = nullptr;     // device word of the range guard (GemmP::x3h_flag); the model handle owns one
     int t_x3h_128 = 72;          // x3h: from this many 128x128 tiles on the loader tile instead of the K-split tiles (t_x6_128's role)
     int t_x6_256 = 160, t_x6_128 = 72;   // ... from this many 256x128 / 128x128 tiles on (profiles/r02_gemm_sweep_x6.txt)
@@ -229,6 +230,7 @@ struct AttnP {
     int x6_min_qlen = 0;      // from this many queries on (D = 64 / 96) the f32-equivalent bf16-pipe kernel (attn_x6_kernel); 0: never
     int lds_waves = 0;        // query tiles per workgroup of that kernel: 8, otherwise 4
     int ds_short = 1;         // D = 64 / 96 and at most 128 keys: key tiles x head-dim slices per workgroup (attn_f32_ds_kernel)
+    int x3h = 0;              // 1: the long-sequence kernel in its fp16-pipe form (two planes, three products; range-guarded through x3h_flag)
     int o_planes = 0;         // 1: O receives fp16 planes (planes_store.h: the A operand of the out-projection's GemmP::a_planes launch; same
     int* x3h_flag = nullptr;  // bytes and row stride as f32; D % 32 == 0, ldo % 32 == 0, O on 128 bytes); x3h_flag: the range guard's device word
 };

@@ -816,6 +816,18 @@ def op_attention(Q, K, V, q_start, q_len, kv_start, kv_len, H, D, scale, lds_min
     return O
 
 
+def op_attention_x3h(Q, K, V, q_start, q_len, kv_start, kv_len, H, D, scale, lds_waves=0):
+    """mt2_op_attention_x3h: the fp16-pipe form of the long-sequence attention kernel -> (O, range flag)."""
+    import torch
+    lib = load_library()
+    O = torch.zeros(Q.shape[0], H * D, device=Q.device, dtype=torch.float32)
+    flag = torch.zeros(4, device=Q.device, dtype=torch.int32)
+    _check(lib.mt2_op_attention_x3h(_stream(), _ptr(Q), Q.stride(0), _ptr(K), K.stride(0), _ptr(V), V.stride(0), _ptr(O), O.stride(0),
+                                    _ptr(q_start), _ptr(q_len), _ptr(kv_start), _ptr(kv_len), q_start.shape[0], H, D,
+                                    int(q_len.max().item()), C.c_float(scale), lds_waves, int(kv_len.max().item()), _ptr(flag)))
+    return O, int(flag[0].item())
+
+
 def bench_gemm(M, N, K, taps=1, force_cfg=-1, iters=20, w_copies=1, dil=1, flags=0):
     lib = load_library()
     ms = C.c_float(0)

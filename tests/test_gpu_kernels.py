@@ -912,14 +912,47 @@ def test_attention_output_as_planes_for_the_out_projection(rt, kernel, H, D, n):
     assert rel(o[:n, :D], (pr / pr.sum(1, keepdims=True)) @ v) < 3e-6
 
 
-@pytest.mark.parametrize("waves", [0, 4, 8, "x6", "x6w4", "x6w8"])
+def test_attention_x3h_range_guard(rt):
+    """The fp16-pipe attention kernel's range behaviour: values up to 6e4 in Q, K or V stay f32-class accurate and leave the guard
+    quiet (the scores' magnitude does not matter - only the operands are converted); a value at or beyond 65504 in any of the
+    three raises the guard word, on which the model repeats the call on the bf16-pipe kernel - checked here: x6 on the same data
+    is accurate."""
+    rng = np.random.default_rng(5)
+    H, D, n = 16, 64, 200
+    d = H * D
+    st, ln = np.zeros(1, np.int32), np.full(1, n, np.int32)
+    def ref(Q, K, V):
+        out = np.zeros((n, d))
+        for h in range(H):
+            sl = slice(h * D, (h + 1) * D)
+            sc = Q[:, sl].astype(np.float64) @ K[:, sl].astype(np.float64).T / math.sqrt(D)
+            pr = np.exp(sc - sc.max(1, keepdims=True))
+            out[:, sl] = (pr / pr.sum(1, keepdims=True)) @ V[:, sl].astype(np.float64)
+        return out
+    Q, K, V = (rng.standard_normal((n, d)).astype(np.float32) for _ in range(3))
+    V[:, :D] *= 900.0                                  # large values, in range
+    V[7, 3] = 6.0e4
+    o, flag = rt.op_attention_x3h(dev(Q), dev(K), dev(V), dev(st), dev(ln), dev(st), dev(ln), H, D, 1.0 / math.sqrt(D))
+    assert flag == 0 and rel(o.cpu().numpy(), ref(Q, K, V)) < 3e-6
+    for which in range(3):
+        ops = [Q.copy(), K.copy(), V.copy()]
+        ops[which][11, 70] = 7.0e4 if which == 2 else 66000.0
+        o, flag = rt.op_attention_x3h(*(dev(x) for x in ops), dev(st), dev(ln), dev(st), dev(ln), H, D, 1.0 / math.sqrt(D))
+        assert flag == 1, which
+        o6 = rt.op_attention(*(dev(x) for x in ops), dev(st), dev(ln), dev(st), dev(ln), H, D, 1.0 / math.sqrt(D), lds_min_qlen=0,
+                             x6_min_qlen=1).cpu().numpy()
+        assert np.isfinite(o6).all() and rel(o6, ref(*ops)) < 3e-6
+
+
+@pytest.mark.parametrize("waves", [0, 4, 8, "x6", "x6w4", "x6w8", "x3h", "x3hw4", "x3hw8"])
 @pytest.mark.parametrize("H,D", [(16, 64), (8, 96), (2, 32), (1, 128)])
 def test_attention_long_sequences_lds_tiled(rt, H, D, waves):
     """attn_f32_lds_kernel (>= 128 queries: the C5 steps): 8 query tiles of a workgroup share the K / V tiles through a
     double-buffered LDS stage.  Ragged batch with lengths around the 256-query workgroup and the 32-key tile boundaries,
-    idle waves in the last workgroup, a score spike in a late key tile (rescale), cross-shaped ranges; against float64."""
+    idle waves in the last workgroup, a score spike in a late key tile (rescale), cross-shaped ranges; against float64.
+    x6*: the same on the bf16 pipe (three planes, six products); x3h*: on the fp16 pipe (two planes, three products) - same bar."""
     x6 = isinstance(waves, str)
-    xw = {"x6": 0, "x6w4": 4, "x6w8": 8}.get(waves, 0)
+    xw = {"x6": 0, "x6w4": 4, "x6w8": 8, "x3h": 128, "x3hw4": 128 + 4, "x3hw8": 128 + 8}.get(waves, 0)
     if x6 and D not in (64, 96):
         pytest.skip("the bf16-pipe attention kernel serves the AR heads (64, 96) only")
     rng = np.random.default_rng(H * 77 + D)

@@ -670,8 +670,8 @@ def main() -> None:
         result["roofline"] = {
             "bound": "mfma",
             "kernel": "gemm_x3h_ldr_kernel / gemm_x3h_ks_kernel / conv_win_x3h_kernel (implicit-GEMM conv/linear engine on the fp16 matrix "
-                      "pipe, f32-equivalent three-product form, loader waves; K-split tiles for the AR steps) + the x6 forms where no "
-                      "x3h form exists or pays (32-channel window convolutions with 3 taps) + gemm_skinny_tm_kernel (f32 MFMA 16x16x4 on tile-major "
+                      "pipe, f32-equivalent three-product form, loader waves; K-split tiles for the AR steps; the x6 forms are the range guard's "
+                      "fallback - no launch of a C3 step runs on them) + gemm_skinny_tm_kernel (f32 MFMA 16x16x4 on tile-major "
                       "weights, LayerNorm prologue) for launches of at most 64 rows",
             "achieved": round(achieved, 2), "peak": round(PEAK, 1), "unit": "TFLOP/s",
             "frac": round(achieved / PEAK, 4), "traffic": traffic, "traffic_detail": traffic_detail,
@@ -687,9 +687,9 @@ def main() -> None:
             "arithmetic": {"f32_mfma": "v_mfma_f32_16x16x4_f32 / 32x32x2_f32 (exact f32 fma chain): launches of at most 64 rows (gemm_skinny_tm_kernel), shapes without weight planes",
                            "x6": "f32-EQUIVALENT on the bf16 pipe: operands split exactly into 3 bf16 planes, 6 exact products, f32 "
                                  "accumulation (error vs float64 not above the f32-MFMA kernel's: tests/test_gpu_kernels.py::*x6*); "
-                                 "configurations named x6*: conv stacks, vocoder, large AR GEMMs",
+                                 "configurations named x6*: what a call repeated by the fp16 range guard runs on",
                            "x3h": "f32-EQUIVALENT on the fp16 pipe (round 6): a = a_hi + 2^-11 a_lo with fp16 planes (weights split at load "
-                                  "after an exact power-of-two row scale, activations in registers), 3 products, cross terms in their "
+                                  "after an exact power-of-two row scale, activations in registers or by the producer kernel), 3 products, cross terms in their "
                                   "own accumulator, range guard -> x6 rerun (tests/test_gpu_kernels.py::*x3h*); configurations named x3h*",
                            "x3h_share_of_executed_flops": round(exe_x3h / max(exe, 1.0), 4),
                            "x6_share_of_executed_flops": round(exe_x6 / max(exe, 1.0), 4),

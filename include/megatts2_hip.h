@@ -221,17 +221,24 @@ int mt2_synthesize_prompt_conditioned(mt2_model* m, void* stream, const int64_t*
                                       float* mel, int Tm_cap, int32_t* mel_lens /*host*/, int32_t* dur_out, int64_t* codes_out,
                                       float* wav, int64_t* prompt_codes);
 
-/* ---- tuning.  Every switch lives in the handle (no process-global state): two handles do not see each other's
- * settings.  Names: "ar_groups" (1..8, default 2: the sequences of an autoregressive run are dealt into that many
- * independent kernel chains on internal HIP streams that fork from and join back into `stream`; results do not
- * depend on it), "lnalg" (0: algebraic LayerNorm in the AR layers), "ln_pairs" (0; 1 / 2: LayerNorm statistics handed from GEMM to GEMM in the AR layers) with the per-stage overrides "ln_pairs_adm" (2) / "ln_pairs_plm" (-1), "skinny_pairs" (1: the same inside the <= 64-row kernel), "skinny_nw" (16), "splitk" (1), "lnfuse" (0), "voc_streams" (3),
- * "x6_conv" (1: window convolutions on the bf16 matrix pipe in the f32-equivalent 6-product form), "x6_gemm" (1: the same for
- * the implicit-GEMM launches with enough big tiles), "x6_splitk" (1), "t_x6_256" (160), "t_x6_128" (72), "t_x6_64" (0: tile-count thresholds of
- * the two x6 tile shapes), "nt_weights" (0) / "nt_row_tiles" (2: non-temporal weight loads for launches with at most that many
- * row tiles), "win_conv" (1), "stage_markers" (0), "force_gemm_config" (-1), "lnalg_rows" (4),
- * "t_ks4", "t_ks2", "t32", "t32x32" (tile-choice thresholds); round 4: "skinny_tm" (1: launches of at most "skinny_rows" = 64 rows on the
- * tile-major weight-streaming kernel incl. its LayerNorm prologue), "ldr_prio" (3: s_setprio of the loader waves), "adm_groups" /
- * "plm_groups" (0: per-stage override of "ar_groups").  Unknown names are an error. */
+/* ---- tuning.  Every switch lives in the handle (no process-global state): two handles do not see each other's settings.  None
+ * changes results beyond f32 summation order.  The 30 names of round 6 (default in parentheses; the options the A/B records closed
+ * were retired with their code and are unknown names now):
+ *   stream groups   "ar_groups" (2; 1..8: the sequences of an autoregressive run are dealt into that many independent kernel chains
+ *                   on internal HIP streams that fork from and join back into `stream`), "adm_groups" / "plm_groups" (0: per-stage
+ *                   override), "voc_streams" (3: the three ResBlocks of a HiFi-GAN MRF side by side);
+ *   arithmetic      "x3h" (15: bit mask of the fp16-pipe three-product forms - 1 loader-wave GEMM tiles, 2 K-split tiles of the AR
+ *                   steps, 4 window convolutions, 8 long-sequence attention; 0 = the bf16 six-product forms, what the range guard's
+ *                   repeat runs), "x6_conv" (1), "x6_gemm" (1), "x6_ks" (4), "win_conv" (1), "splitk" (1: K slices reduced by the next
+ *                   LayerNorm), "skinny_tm" (1: launches of at most "skinny_rows" = 64 rows on the tile-major weight-streaming
+ *                   kernel incl. its LayerNorm prologue), "skinny_nw" (16), "skinny_pairs" (1), "ln_pairs_adm" (2: LayerNorm
+ *                   statistics handed from GEMM to GEMM in the ADM's layers), "ln_pairs_maxm" (1280), "ldr_prio" (3: s_setprio of the
+ *                   loader waves), "a_planes" (3: bit mask of the producers that hand an activation to an x3h GEMM as fp16 planes -
+ *                   1 LayerNorm kernels, 2 ff.0's epilogue -> ff.3, 4 attention -> out-projection);
+ *   thresholds      "t_x3h_128" (72), "t_x6_256" (160), "t_x6_128" (72), "t_ks4" (256), "t_ks2" (640), "t32" (64), "t32x32" (160)
+ *                   (tile counts at which the tile choice changes), "attn_x6_min" (192), "attn_lds_min" (640) (queries per sequence);
+ *   measurement     "force_gemm_config" (-1), "stage_markers" (0), "ldr64" (0).
+ * Unknown names are an error. */
 int mt2_set_option(mt2_model* m, const char* name, int value);
 int mt2_get_option(mt2_model* m, const char* name, int* value);
 int mt2_set_ar_groups(mt2_model* m, int groups);
@@ -267,7 +274,7 @@ int mt2_op_gemm_x3h(void* stream, const float* X, int ldx, int Rx, int shift0, i
  * [rows][2 * ceil32(row_len)] uint16 (fp16 bit patterns; per row and 32-k chunk 32 hi values, then 32 lo values; K zero-padded to a
  * multiple of 32), inv [rows] */
 int mt2_x3h_split(const float* W, long long rows, long long row_len, uint16_t* planes, float* inv);
-/* Range guard of the fp16-pipe GEMMs inside a model handle (option "x3h", default 1): waits for the handle's last call, then
+/* Range guard of the fp16-pipe kernels inside a model handle (option "x3h", default 15): waits for the handle's last call, then
  * *tripped = 1 (and the guard is re-armed) when that call converted an activation outside the fp16 range - its outputs are then
  * to be discarded and the call repeated with mt2_set_option(m, "x3h", 0) (the bf16 six-product form has f32's exponent range). */
 int mt2_x3h_guard(mt2_model* m, int* tripped);

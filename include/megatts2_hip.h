@@ -257,15 +257,19 @@ int mt2_op_gemm(void* stream, const float* X, int ldx, int Rx, const int32_t* ro
                 float out_scale, int force_cfg);
 /* Window convolution with the weights additionally given as three bf16 planes W3 [3][N][K] (device uint16; truncation
  * split: W = W3[0] + W3[1] + W3[2] exactly): the kernel may then run on the bf16 matrix pipe in the f32-equivalent
- * 6-product form (conv_win_x6_kernel; force_cfg 34..36 or -1 for the automatic choice). */
+ * 6-product form (conv_win_x6_kernel; force_cfg 34 / 58 / 59 = 32 / 64 / 128 channels, or -1 for the automatic choice; a retired
+ * configuration index answers hipErrorNotSupported). */
 int mt2_op_gemm_x6(void* stream, const float* X, int ldx, int Rx, int shift0, int taps, int dil, int Cin, const float* W,
                    const void* W3, const float* bias, const float* R, int ldr, const int32_t* valid, float* C, int ldc,
                    int M, int N, int pro_act, float pro_slope, int epi_act, int force_cfg);
 /* The same launch with the weights ALSO as two fp16 planes (hi, lo * 2^11) of the row-scaled matrix - Wh: chunk-interleaved,
  * [N][ceil32(K) / 32] blocks of 128 bytes = 32 hi then 32 lo values of one row and 32-k chunk, 128-byte aligned - and the inverse
  * power-of-two row scales wh_inv [N] (mt2_x3h_split): the Linear / Conv1d of modules/transformer.py:35-57,88-102 and
- * modules/convnet.py:23-31 on the fp16 matrix pipe in the f32-equivalent THREE-product form (csrc/gemm_x3h.hip; force_cfg 91..94
- * or -1).  range_flag (device int32, may be NULL): |= 1 when an activation with |a| >= 65504 was converted (fp16 range). */
+ * modules/convnet.py:23-31 on the fp16 matrix pipe in the f32-equivalent THREE-product form (csrc/gemm_x3h.hip; force_cfg 103 = the
+ * 128x128 loader tile, 95 / 96 / 97 = the K-split tiles, 98 / 99 / 100 = window convolutions of 32 / 64 / 128 channels, or -1).  Test
+ * conventions of this entry point: force_cfg + 1000 = the loaders' 64-bit address form, + 2000 = X holds fp16 planes written by a
+ * producer kernel (mt2_op_layernorm with act + 100, or this entry with + 4000), + 4000 = C is stored as such planes (loader tile only).
+ * range_flag (device int32, may be NULL): |= 1 when an activation with |a| >= 65504 was converted (fp16 range). */
 int mt2_op_gemm_x3h(void* stream, const float* X, int ldx, int Rx, int shift0, int taps, int dil, int Cin, const float* W,
                     const void* W3, const void* Wh, const float* wh_inv, const float* bias, const float* R, int ldr,
                     const int32_t* valid, float* C, int ldc, int M, int N, int pro_act, float pro_slope, int epi_act, int force_cfg,

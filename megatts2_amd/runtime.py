@@ -805,6 +805,9 @@ def op_layernorm(x, gamma, beta, R1=None, valid=None, eps=1e-5, act=ACT_NONE):
 
 
 def op_attention(Q, K, V, q_start, q_len, kv_start, kv_len, H, D, scale, lds_min_qlen=-1, lds_waves=0, out=None, x6_min_qlen=-1):
+    """mt2_op_attention_tuned: one attention launch with the kernel choice exposed.  lds_waves: 0 / 4 / 8 query tiles per workgroup of
+    the LDS-tiled and matrix-pipe kernels; + 32 = the register kernel instead of the head-dim-split one; + 64 = the output rows as fp16
+    planes (AttnP::o_planes); + 128 = the fp16-pipe form of the long-sequence kernel (with x6_min_qlen >= 1)."""
     import torch
     lib = load_library()
     O = out if out is not None else torch.zeros(Q.shape[0], H * D, device=Q.device, dtype=torch.float32)
